@@ -1,0 +1,230 @@
+#!/usr/bin/env python
+"""Benchmark of the IIC training hot path on MI355X (BASELINE.json metric).
+
+One "step" = the reference's train step on a resident synthetic batch
+(/root/reference/code/scripts/cluster/cluster_sobel.py:235-272):
+  sobel_process x2 -> net(all_imgs), net(all_imgs_tf) (train-mode BN, two statistic groups)
+  -> IID_loss x5 sub-heads -> mean -> backward -> (grad all-reduce when N>1) -> Adam step.
+Workload: STL10-shaped 96x96, ClusterNet5g, output_k 70, 5 sub-heads, 660 pairs per GPU
+(BASELINE.json configs[1]).  Multi-GPU: one process per GPU (torchrun), batch sharded by
+pair, weak scaling (660 pairs per rank), RCCL all-reduce of the raw joint P (inside
+IID_loss) and of the parameter gradients.
+
+Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PAIRS_PER_GPU = 660
+INPUT_SZ = 96
+OUTPUT_K = 70
+SUB_HEADS = 5
+FLOP_PER_PAIR = 36.35e9      # BASELINE.md §4 (algorithmic, fwd + bwd-data + bwd-weight, 2 images)
+BF16_PEAK_TFLOPS = 2500.0    # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def make_batch(n_pairs, sz, device, seed=0):
+  """Synthetic (all_imgs, all_imgs_tf) in [0,1], fp32 [n,1,sz,sz]: smoothed noise base images
+  replicated 3x (the reference's num_dataloaders), tf = flip * gain + noise."""
+  g = torch.Generator(device="cpu").manual_seed(seed)
+  nb = n_pairs // 3
+  base = torch.rand(nb, 1, sz, sz, generator=g)
+  base = torch.nn.functional.avg_pool2d(torch.nn.functional.pad(base, (2, 2, 2, 2), mode="replicate"), 5, 1)
+  imgs = base.repeat(3, 1, 1, 1)
+  gain = torch.rand(n_pairs, 1, 1, 1, generator=g) * 0.8 + 0.6
+  noise = torch.randn(imgs.shape, generator=g) * 0.05
+  imgs_tf = torch.clamp(torch.flip(imgs, dims=[3]) * gain + noise, 0.0, 1.0)
+  return imgs.to(device).contiguous(), imgs_tf.to(device).contiguous()
+
+
+class ConvTimer(object):
+  """HIP-event timing of every implicit-GEMM conv launch on the launch stream (torch's
+  current stream == the stream handed to the C ABI)."""
+
+  def __init__(self):
+    self.records = []
+    self.pool = []
+
+  def install(self):
+    from iic_amd import ops
+    self._orig = ops.conv_igemm
+    timer = self
+
+    def timed(g, x_pt, w_t, out_pt, stats=None, res_grad=None, res_act=None, accumulate=False):
+      e0 = torch.cuda.Event(enable_timing=True)
+      e1 = torch.cuda.Event(enable_timing=True)
+      e0.record()
+      r = timer._orig(g, x_pt, w_t, out_pt, stats, res_grad, res_act, accumulate)
+      e1.record()
+      flops = 2.0 * g.N * g.MY * g.MX * g.Cout * g.Cin * g.ntaps
+      timer.records.append((e0, e1, flops))
+      return r
+    ops.conv_igemm = timed
+
+  def uninstall(self):
+    from iic_amd import ops
+    ops.conv_igemm = self._orig
+
+  def summary(self):
+    if not self.records:
+      return None
+    tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.records)
+    tot_fl = sum(f for _, _, f in self.records)
+    n = len(self.records)
+    return {"launches": n, "avg_us": 1e3 * tot_ms / n, "tflops": tot_fl / (tot_ms * 1e-3) / 1e12,
+            "total_ms": tot_ms}
+
+
+def cpu_baseline(n_pairs=48, steps=2):
+  """Reference-equivalent CPU path (oracle port of ClusterNet5g + IID_loss + torch Adam) on
+  the host cores, bounded sample of the same workload."""
+  from oracle import net_oracle
+  torch.set_num_threads(os.cpu_count() or 1)
+  params = net_oracle.make_net5g_params(2, OUTPUT_K, SUB_HEADS, True, seed=0)
+  leaves = []
+  for k, v in params.items():
+    if v.dtype.is_floating_point and "running" not in k:
+      v.requires_grad_(True)
+      leaves.append(v)
+  opt = torch.optim.Adam(leaves, lr=1e-4)
+  imgs, imgs_tf = net_oracle.make_paired_batch(n_pairs, INPUT_SZ, 3, seed=0)
+  times = []
+  for s in range(steps + 1):
+    t0 = time.time()
+    opt.zero_grad()
+    loss, _, _, _ = net_oracle.net5g_train_step_loss(params, imgs, imgs_tf, 1.0, INPUT_SZ, SUB_HEADS)
+    loss.backward()
+    opt.step()
+    times.append(time.time() - t0)
+  t = sorted(times[1:])[len(times[1:]) // 2]
+  return {"value": n_pairs / t, "unit": "paired-images/sec", "cores": torch.get_num_threads(),
+          "kind": "port",
+          "sample": "%d pairs/step x %d timed steps (+1 warm-up), fp32 torch-CPU restatement of the "
+                    "reference ClusterNet5g+IID_loss+Adam step, 96x96, k=70, 5 sub-heads" % (n_pairs, steps)}
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--gpus", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=10)
+  ap.add_argument("--warmup", type=int, default=3)
+  ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="pairs per GPU (default 660)")
+  ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--no-roofline", action="store_true")
+  args = ap.parse_args()
+
+  world = int(os.environ.get("WORLD_SIZE", "1"))
+  rank = int(os.environ.get("RANK", "0"))
+  local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  assert torch.cuda.is_available(), "bench.py needs an MI355X"
+  torch.cuda.set_device(local_rank)
+  dev = torch.device("cuda", local_rank)
+  if world > 1:
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    from iic_amd import dist as idist
+    idist.enable()
+  assert args.gpus == world or world == 1, "launch with torchrun --nproc-per-node == --gpus"
+
+  from iic_amd import archs, dist as idist
+  from iic_amd.losses import IID_loss_heads
+  from iic_amd.optim import Adam
+  from iic_amd.transforms import sobel_process
+
+  torch.manual_seed(0)
+  cfg = types.SimpleNamespace(in_channels=2, input_sz=INPUT_SZ, batchnorm_track=True,
+                              num_sub_heads=SUB_HEADS, output_k=OUTPUT_K)
+  net = archs.ClusterNet5g(cfg).to(dev).train()
+  if world > 1:   # identical weights on every rank
+    for p in net.parameters():
+      torch.distributed.broadcast(p.data, 0)
+  opt = Adam(net.parameters(), lr=1e-4)
+  # weak scaling: every rank owns `pairs` pairs (its shard of the global batch of pairs*world)
+  imgs, imgs_tf = make_batch(args.pairs, INPUT_SZ, dev, seed=rank)
+  params = list(net.parameters())
+
+  def step():
+    net.zero_grad(set_to_none=True)
+    a = sobel_process(imgs, False)
+    b = sobel_process(imgs_tf, False)
+    xo = net.forward_packed(a)
+    xt = net.forward_packed(b)
+    loss, _ = IID_loss_heads(xo, xt, lamb=1.0)
+    loss = loss.mean()
+    loss.backward()
+    idist.all_reduce_grads(params)
+    opt.step()
+    return loss
+
+  def fence():
+    torch.cuda.synchronize()
+    if world > 1:
+      torch.distributed.barrier()
+    torch.cuda.synchronize()
+
+  for _ in range(args.warmup):
+    last = step()
+  timer = None
+  if not args.no_roofline and rank == 0:
+    timer = ConvTimer()
+    timer.install()
+  fence()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    last = step()
+  fence()
+  dt = time.perf_counter() - t0
+  if timer is not None:
+    timer.uninstall()
+  loss_val = float(last)
+  if world > 1:
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    dt = float(t)
+  ms_per_step = 1e3 * dt / args.steps
+  value = args.pairs * world / (dt / args.steps)
+
+  if rank == 0:
+    out = {
+      "metric": "paired-images/sec, STL10 96x96 ClusterNet5g+IID_loss",
+      "value": value, "unit": "paired-images/sec", "n_gpus": world, "steps": args.steps,
+      "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+      "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+      "config": {"workload": "STL10 96x96 ClusterNet5g IID+ (cluster_sobel.py train step), "
+                             "batch %d pairs/GPU, 5 sub-heads, k=70, bf16 MFMA convs / fp32 "
+                             "stem+heads+loss, fused HIP Adam" % args.pairs,
+                 "global_batch_pairs": args.pairs * world, "input": "96x96x1 grey -> sobel 2ch",
+                 "parallelism": "dp%d" % world, "final_loss": loss_val},
+    }
+    if timer is not None:
+      s = timer.summary()
+      if s:
+        out["roofline"] = {
+          "bound": "mfma", "kernel": "conv_igemm_kernel (fwd + bwd-data implicit GEMM, bf16 MFMA)",
+          "achieved": s["tflops"], "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+          "frac": s["tflops"] / BF16_PEAK_TFLOPS, "traffic": None,
+          "launches_timed": s["launches"], "avg_launch_us": s["avg_us"],
+          "kernel_ms_per_step": s["total_ms"] / args.steps,
+          "step_algorithmic_tflops": value / world * FLOP_PER_PAIR / 1e12,
+          "step_frac_of_peak": value / world * FLOP_PER_PAIR / 1e12 / BF16_PEAK_TFLOPS,
+        }
+    if world == 1 and not args.no_cpu_baseline:
+      out["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(out))
+  if world > 1:
+    torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+  main()

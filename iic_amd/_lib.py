@@ -1,0 +1,114 @@
+"""ctypes binding of libiic_hip.so (the C ABI declared in include/iic_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol
+cannot be resolved, importing any op raises.  Build it with
+``python -c "import __graft_entry__ as g; g.build()"`` (or ``make -C iic_amd/csrc``).
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_double, c_float, c_int, c_int32, c_long, c_longlong, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libiic_hip.so")
+
+IIC_MAX_TAPS = 32
+IIC_STAT_STRIPES = 32
+
+
+class ConvGeom(Structure):
+  """Mirror of ``iic_conv_geom`` (include/iic_hip.h)."""
+  _fields_ = [
+    ("N", c_int32), ("MY", c_int32), ("MX", c_int32),
+    ("in_Hp", c_int32), ("in_Wp", c_int32), ("Cin", c_int32),
+    ("sy", c_int32), ("sx", c_int32), ("oy", c_int32), ("ox", c_int32),
+    ("out_Hp", c_int32), ("out_Wp", c_int32), ("Cout", c_int32),
+    ("ty", c_int32), ("tx", c_int32), ("py", c_int32), ("px", c_int32),
+    ("ntaps", c_int32),
+    ("tap_off", c_int32 * IIC_MAX_TAPS),
+    ("tap_w", c_int32 * IIC_MAX_TAPS),
+    ("NP", c_int32),
+  ]
+
+
+_P = c_void_p
+_SIGNATURES = {
+  "iic_version": (c_int, []),
+  "iic_iid_nsplit": (c_int, [c_int]),
+  "iic_iid_workspace_bytes": (c_long, [c_int, c_int]),
+  "iic_iid_joint_raw": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_long, c_long, c_int, _P]),
+  "iic_iid_loss_from_joint": (c_int, [_P, c_int, c_int, c_int, c_double, c_double, _P, _P, _P, _P, _P, _P]),
+  "iic_iid_grad": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_long, c_long, _P]),
+  "iic_conv_lds_bytes": (c_long, [POINTER(ConvGeom), c_int]),
+  "iic_conv_igemm": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P, _P, _P, c_int, _P]),
+  "iic_conv_wgrad_nsplit": (c_int, [POINTER(ConvGeom)]),
+  "iic_conv_wgrad": (c_int, [POINTER(ConvGeom), _P, _P, _P, c_int, c_int, _P]),
+  "iic_conv_wgrad_reduce": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _P]),
+  "iic_weight_prep": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
+  "iic_bn_finalize": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_long, c_float, c_float, c_int, _P]),
+  "iic_bn_apply": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+  "iic_bn_bwd_reduce": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+  "iic_bn_bwd_finalize": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_long, _P]),
+  "iic_bn_bwd_apply": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+  "iic_stem_stats": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+  "iic_stem_apply_pool": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+  "iic_stem_bwd_reduce": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+  "iic_stem_wgrad_partial_floats": (c_long, []),
+  "iic_stem_bwd_wgrad": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+  "iic_sobel": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+  "iic_avgpool_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+  "iic_avgpool_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+  "iic_gemm_f32": (c_int, [_P, c_long, c_long, _P, c_long, c_long, _P, _P, c_long, c_int, c_int, c_int, c_int, _P]),
+  "iic_softmax_fwd": (c_int, [_P, _P, c_int, c_int, _P]),
+  "iic_softmax_bwd": (c_int, [_P, _P, _P, c_int, c_int, _P]),
+  "iic_colsum_f32": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+  "iic_adam_step": (c_int, [c_int, POINTER(_P), POINTER(_P), POINTER(_P), POINTER(_P), POINTER(c_long),
+                            c_float, c_float, c_float, c_float, c_int, _P]),
+  "iic_probe_tr16": (c_int, [_P, _P]),
+}
+
+EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
+
+_lib = None
+
+
+class IICLibraryError(RuntimeError):
+  pass
+
+
+def lib():
+  """Load (once) and return the ctypes handle; raise loudly when it is absent."""
+  global _lib
+  if _lib is None:
+    if not os.path.exists(LIB_PATH):
+      raise IICLibraryError(
+        "libiic_hip.so not found at %s -- build the HIP extension first "
+        "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU/PyTorch "
+        "fallback for the IIC hot path." % LIB_PATH)
+    h = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+      try:
+        fn = getattr(h, name)
+      except AttributeError as e:
+        raise IICLibraryError("libiic_hip.so lacks symbol %s" % name) from e
+      fn.restype = res
+      fn.argtypes = args
+    _lib = h
+  return _lib
+
+
+_ERR = {-1: "IIC_ERR_ARG", -2: "IIC_ERR_LAUNCH", -3: "IIC_ERR_UNSUPPORTED"}
+
+
+def check(rc, what=""):
+  if rc != 0:
+    raise IICLibraryError("%s failed: %s (%d)" % (what or "libiic_hip call", _ERR.get(rc, "?"), rc))
+
+
+def ptr(t):
+  """Device pointer of a torch tensor (None -> NULL)."""
+  return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+  import torch
+  return torch.cuda.current_stream().cuda_stream

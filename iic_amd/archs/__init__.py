@@ -1,0 +1,5 @@
+"""Architecture registry mirroring /root/reference/code/archs/__init__.py: the reference
+builds a net with ``archs.__dict__[config.arch](config)`` (cluster_sobel.py:140)."""
+from .cluster import ClusterNet5g, ClusterNet5gTwoHead  # noqa: F401
+
+__all__ = ["ClusterNet5g", "ClusterNet5gTwoHead"]

@@ -1,0 +1,458 @@
+"""MI355X-native ClusterNet5g / ClusterNet5gTwoHead -- drop-in for
+/root/reference/code/archs/cluster/{net5g,net5g_two_head,residual}.py.
+
+Same constructor (an argparse-like ``config`` with in_channels, input_sz, batchnorm_track,
+num_sub_heads, output_k | output_k_A + output_k_B), same ``forward`` signature and return
+type (a list of per-sub-head softmax tensors), same ``state_dict`` keys / shapes / dtypes
+and the same init distributions (residual.py:75-85), so the reference's training scripts,
+checkpoints and torch.optim.Adam drive it unchanged.
+
+What differs is everything underneath: the nn.Conv2d / nn.BatchNorm2d / nn.Linear members
+are only PARAMETER HOLDERS (their own forward is never called).  The computation is
+three kinds of torch.autograd.Function whose forward/backward enqueue the hand-written
+gfx950 kernels of libiic_hip.so:
+
+  _StemFn    conv3x3 + BN + ReLU + maxpool, recomputed from the fp32 NCHW input (stem.hip)
+  _BlockFn   BasicBlock: 2-3 bf16-MFMA implicit-GEMM convs with BN statistics fused in the
+             conv epilogue, BN/ReLU/residual streaming kernels, MFMA weight-grad (conv_*.hip)
+  _HeadsFn   avgpool + all sub-heads as one fp32-MFMA GEMM + softmax (head.hip)
+
+Activations between Functions are "PT" tensors: bf16 [N, H+2, W+2, C] with a zero border.
+There is no PyTorch / CPU fallback: a CPU input raises.
+"""
+import torch
+import torch.nn as nn
+
+from .. import geom as G
+from .. import ops
+
+__all__ = ["ClusterNet5g", "ClusterNet5gTwoHead"]
+
+_WEIGHTS_EPOCH = [0]   # bumped by iic_amd.optim.Adam (raw-pointer updates do not bump _version)
+
+
+def bump_weights_epoch():
+  _WEIGHTS_EPOCH[0] += 1
+
+
+class _ConvHolder(object):
+  """Per-conv caches: bf16 operand copies of the fp32 parameter, geometries, BN stat buffers."""
+
+  def __init__(self, conv):
+    self.conv = conv
+    self.spec = G.ConvSpec(conv.in_channels, conv.out_channels, conv.kernel_size[0],
+                           conv.stride[0], conv.padding[0], conv.dilation[0])
+    self._wkey = None
+    self._w = None
+    self._geoms = {}
+    self._stats = {}
+
+  def weights(self):
+    w = self.conv.weight
+    key = (w.data_ptr(), w._version, _WEIGHTS_EPOCH[0])
+    if key != self._wkey:
+      self._w = ops.weight_prep(w.detach(), want_bwd=True)
+      self._wkey = key
+    return self._w
+
+  def geoms(self, N, H, W):
+    key = (N, H, W)
+    g = self._geoms.get(key)
+    if g is None:
+      g = (G.fwd_geom(self.spec, N, H, W, 1, 1), G.bwd_data_geoms(self.spec, N, H, W, 1, 1))
+      self._geoms[key] = g
+    return g
+
+  def stats(self, device, which="fwd"):
+    key = (str(device), which)
+    s = self._stats.get(key)
+    if s is None:
+      s = ops.new_stats(self.spec.cout, device)
+      self._stats[key] = s
+    return s
+
+
+def _bn_buffers(bn):
+  if bn.track_running_stats:
+    return bn.running_mean, bn.running_var, bn.num_batches_tracked
+  return None, None, None
+
+
+def _bn_training(bn):
+  # nn.BatchNorm2d semantics: batch statistics when training OR when no running stats exist
+  return bn.training or not bn.track_running_stats
+
+
+# ------------------------------------------------------------------------------------
+# Stem
+# ------------------------------------------------------------------------------------
+class _StemFn(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, x, w, gamma, beta, mod):
+    assert x.is_cuda, "ClusterNet5g (HIP): input must be a device tensor -- no CPU fallback"
+    x = x.contiguous().float()
+    N, C, H, W = x.shape
+    bn = mod.bn1
+    rm, rv, nbt = _bn_buffers(bn)
+    training = _bn_training(bn)
+    wd = w.detach()
+    if training:
+      st = mod._h_conv1.stats(x.device)
+      ops.stem_stats(x, wd, st)
+      coef = ops.bn_finalize(st, gamma.detach(), beta.detach(), rm if bn.training else None,
+                             rv if bn.training else None, nbt if bn.training else None, 64,
+                             N * H * W, True)
+    else:
+      coef = ops.bn_finalize(None, gamma.detach(), beta.detach(), rm, rv, None, 64, N * H * W, False)
+    Ho, Wo = H // 2 + 1, W // 2 + 1
+    out = ops.pt_alloc(N, Ho, Wo, 64, 1, x.device)
+    ops.stem_apply_pool(x, wd, coef, out)
+    ctx.mod = mod
+    ctx.training = training
+    ctx.save_for_backward(x, w, gamma, coef, out)
+    return out
+
+  @staticmethod
+  def backward(ctx, dpool):
+    x, w, gamma, coef, out = ctx.saved_tensors
+    if not ctx.training:
+      raise RuntimeError("HIP BatchNorm backward is implemented for batch statistics only")
+    N, C, H, W = x.shape
+    dpool = dpool.contiguous()
+    sums = ctx.mod._h_conv1.stats(x.device, "bwd")
+    ops.stem_bwd_reduce(x, w.detach(), coef, dpool, sums)
+    bcoef, dgamma, dbeta = ops.bn_bwd_finalize(sums, gamma.detach(), coef, 64, N * H * W)
+    dW = ops.stem_bwd_wgrad(x, w.detach(), coef, bcoef, dpool)
+    ops.POOL.release(dpool)
+    ops.POOL.release(out)
+    return None, dW, dgamma, dbeta, None
+
+
+# ------------------------------------------------------------------------------------
+# BasicBlock  (residual.py:10-43)
+# ------------------------------------------------------------------------------------
+class _BlockFn(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, x, w1, g1, b1, w2, g2, b2, wd, gd, bd, blk):
+    N, Hp, Wp, Cin = x.shape
+    H, W = Hp - 2, Wp - 2
+    dev = x.device
+    h1, h2, hd = blk._h1, blk._h2, blk._hd
+    planes = h1.spec.cout
+    Ho, Wo = h1.spec.out_size(H), h1.spec.out_size(W)
+    cnt = N * Ho * Wo
+    need_grad = any(ctx.needs_input_grad)   # (grad mode is off inside Function.forward)
+
+    def bn_coef(bn, holder, gamma, beta, y_stats):
+      rm, rv, nbt = _bn_buffers(bn)
+      if _bn_training(bn):
+        upd = bn.training
+        return ops.bn_finalize(y_stats, gamma.detach(), beta.detach(), rm if upd else None,
+                               rv if upd else None, nbt if upd else None, planes, cnt, True)
+      return ops.bn_finalize(None, gamma.detach(), beta.detach(), rm, rv, None, planes, cnt, False)
+
+    gf1, _ = h1.geoms(N, H, W)
+    gf2, _ = h2.geoms(N, Ho, Wo)
+    st1 = h1.stats(dev) if _bn_training(blk.bn1) else None
+    y1 = ops.pt_alloc(N, Ho, Wo, planes, 1, dev)
+    ops.conv_igemm(gf1, x, h1.weights()[0], y1, stats=st1)
+    coef1 = bn_coef(blk.bn1, h1, g1, b1, st1)
+    a1 = ops.pt_alloc(N, Ho, Wo, planes, 1, dev)
+    ops.bn_apply(y1, coef1, a1, N, Ho, Wo, 1, planes, relu=True)
+    st2 = h2.stats(dev) if _bn_training(blk.bn2) else None
+    y2 = ops.pt_alloc(N, Ho, Wo, planes, 1, dev)
+    ops.conv_igemm(gf2, a1, h2.weights()[0], y2, stats=st2)
+    coef2 = bn_coef(blk.bn2, h2, g2, b2, st2)
+    out = ops.pt_alloc(N, Ho, Wo, planes, 1, dev)
+    yd = coefd = None
+    if hd is not None:
+      gfd, _ = hd.geoms(N, H, W)
+      bnd = blk.downsample[1]
+      std = hd.stats(dev) if _bn_training(bnd) else None
+      yd = ops.pt_alloc(N, Ho, Wo, planes, 1, dev)
+      ops.conv_igemm(gfd, x, hd.weights()[0], yd, stats=std)
+      coefd = bn_coef(bnd, hd, gd, bd, std)
+      ops.bn_apply(y2, coef2, out, N, Ho, Wo, 1, planes, y2=yd, coef2=coefd, relu=True)
+    else:
+      ops.bn_apply(y2, coef2, out, N, Ho, Wo, 1, planes, res=x, relu=True)
+
+    if need_grad:
+      ctx.blk = blk
+      ctx.dims = (N, H, W, Ho, Wo, Cin, planes)
+      ctx.bn_batch = (_bn_training(blk.bn1) and _bn_training(blk.bn2))
+      ctx.save_for_backward(x, y1, a1, y2, out, yd, coef1, coef2, coefd, g1, g2, gd)
+    else:
+      for t in (y1, a1, y2, yd):
+        ops.POOL.release(t)
+    return out
+
+  @staticmethod
+  def backward(ctx, dout):
+    x, y1, a1, y2, out, yd, coef1, coef2, coefd, g1, g2, gd = ctx.saved_tensors
+    blk = ctx.blk
+    if not ctx.bn_batch:
+      raise RuntimeError("HIP BatchNorm backward is implemented for batch statistics only")
+    N, H, W, Ho, Wo, Cin, planes = ctx.dims
+    dev = x.device
+    h1, h2, hd = blk._h1, blk._h2, blk._hd
+    cnt = N * Ho * Wo
+    dout = dout.contiguous()
+    use_tr = blk._use_tr
+    gf1, gb1 = h1.geoms(N, H, W)
+    gf2, gb2 = h2.geoms(N, Ho, Wo)
+
+    # ---- bn2 (+ downsample bn) backward; g = dout * (out > 0)
+    s2 = h2.stats(dev, "bwd")
+    sd = hd.stats(dev, "bwd") if hd is not None else None
+    ops.bn_bwd_reduce(dout, out, y2, s2, N, Ho, Wo, 1, planes, y2=yd, sums2=sd)
+    bc2, dg2, db2 = ops.bn_bwd_finalize(s2, g2.detach(), coef2, planes, cnt)
+    dy2 = ops.pt_alloc(N, Ho, Wo, planes, 1, dev)
+    bcd = dgd = dbd = dyd = None
+    if hd is not None:
+      bcd, dgd, dbd = ops.bn_bwd_finalize(sd, gd.detach(), coefd, planes, cnt)
+      dyd = ops.pt_alloc(N, Ho, Wo, planes, 1, dev)
+    ops.bn_bwd_apply(dout, out, y2, bc2, dy2, N, Ho, Wo, 1, planes, y2=yd, bcoef2=bcd, dy2=dyd)
+
+    # ---- conv2 backward
+    da1 = ops.pt_alloc(N, Ho, Wo, planes, 1, dev)
+    for g in gb2:
+      ops.conv_igemm(g, dy2, h2.weights()[1], da1)
+    dW2 = ops.conv_wgrad(gf2, a1, dy2, 9, use_tr).view(planes, planes, 3, 3)
+
+    # ---- bn1 backward; g1 = da1 * (a1 > 0)
+    s1 = h1.stats(dev, "bwd")
+    ops.bn_bwd_reduce(da1, a1, y1, s1, N, Ho, Wo, 1, planes)
+    bc1, dg1, db1 = ops.bn_bwd_finalize(s1, g1.detach(), coef1, planes, cnt)
+    dy1 = ops.pt_alloc(N, Ho, Wo, planes, 1, dev)
+    ops.bn_bwd_apply(da1, a1, y1, bc1, dy1, N, Ho, Wo, 1, planes)
+
+    # ---- conv1 backward-data (+ residual / downsample gradient), weight grads
+    dx = ops.pt_alloc(N, H, W, Cin, 1, dev)
+    if hd is None:
+      for g in gb1:
+        ops.conv_igemm(g, dy1, h1.weights()[1], dx, res_grad=dout, res_act=out)
+    else:
+      for g in gb1:
+        ops.conv_igemm(g, dy1, h1.weights()[1], dx)
+      _, gbd = hd.geoms(N, H, W)
+      for g in gbd:
+        ops.conv_igemm(g, dyd, hd.weights()[1], dx, accumulate=True)
+    dW1 = ops.conv_wgrad(gf1, x, dy1, 9, use_tr).view(planes, Cin, 3, 3)
+    dWd = None
+    if hd is not None:
+      gfd, _ = hd.geoms(N, H, W)
+      dWd = ops.conv_wgrad(gfd, x, dyd, 1, use_tr).view(planes, Cin, 1, 1)
+
+    for t in (dout, dy2, dyd, da1, dy1, y1, a1, y2, yd, out):
+      ops.POOL.release(t)
+    return dx, dW1, dg1, db1, dW2, dg2, db2, dWd, dgd, dbd, None
+
+
+class BasicBlock(nn.Module):
+  expansion = 1
+
+  def __init__(self, inplanes, planes, stride=1, downsample=None, track_running_stats=None):
+    super(BasicBlock, self).__init__()
+    assert track_running_stats is not None
+    self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+    self.bn1 = nn.BatchNorm2d(planes, track_running_stats=track_running_stats)
+    self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=1, padding=1, bias=False)
+    self.bn2 = nn.BatchNorm2d(planes, track_running_stats=track_running_stats)
+    self.downsample = downsample
+    self.stride = stride
+    self._h1 = _ConvHolder(self.conv1)
+    self._h2 = _ConvHolder(self.conv2)
+    self._hd = _ConvHolder(downsample[0]) if downsample is not None else None
+    self._use_tr = True
+
+  def forward(self, x):
+    ds = self.downsample
+    return _BlockFn.apply(
+      x, self.conv1.weight, self.bn1.weight, self.bn1.bias, self.conv2.weight, self.bn2.weight,
+      self.bn2.bias, ds[0].weight if ds is not None else None,
+      ds[1].weight if ds is not None else None, ds[1].bias if ds is not None else None, self)
+
+
+# ------------------------------------------------------------------------------------
+# avgpool + heads  (net5g.py:31-39,53,61-80)
+# ------------------------------------------------------------------------------------
+class _AvgPoolFn(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, x):
+    N, Hp, Wp, C = x.shape
+    ctx.dims = (N, Hp - 2, Wp - 2, C)
+    return ops.avgpool_fwd(x, N, Hp - 2, Wp - 2, 1, C)
+
+  @staticmethod
+  def backward(ctx, dfeats):
+    N, H, W, C = ctx.dims
+    dx = ops.pt_alloc(N, H, W, C, 1, dfeats.device)
+    return ops.avgpool_bwd(dfeats.contiguous(), dx, N, H, W, 1, C)
+
+
+class _HeadsFn(torch.autograd.Function):
+  """feats [N, F] fp32, Wcat [H*k, F], bcat [H*k] -> probs [N, H, k] (sample-major)."""
+
+  @staticmethod
+  def forward(ctx, feats, Wcat, bcat, H, k):
+    N, F = feats.shape
+    feats = feats.contiguous()
+    Wcat = Wcat.contiguous()
+    KT = H * k
+    logits = torch.empty((N, KT), dtype=torch.float32, device=feats.device)
+    # logits[n][j] = sum_c feats[n][c] * Wcat[j][c] + b[j]
+    ops.gemm_f32(feats, F, 1, Wcat, 1, F, logits, KT, N, KT, F, bias=bcat.contiguous())
+    probs = ops.softmax_fwd(logits, N * H, k)
+    ctx.save_for_backward(feats, Wcat, probs)
+    ctx.hk = (H, k)
+    return probs.view(N, H, k)
+
+  @staticmethod
+  def backward(ctx, dprobs):
+    feats, Wcat, probs = ctx.saved_tensors
+    H, k = ctx.hk
+    N, F = feats.shape
+    KT = H * k
+    dlog = ops.softmax_bwd(probs, dprobs.contiguous().view(N, KT), N * H, k)
+    # dW[j][c] = sum_n dlog[n][j] feats[n][c]
+    dW = torch.empty((KT, F), dtype=torch.float32, device=feats.device)
+    ops.gemm_f32(dlog, 1, KT, feats, F, 1, dW, F, KT, F, N)
+    db = ops.colsum(dlog, N, KT)
+    # dfeats[n][c] = sum_j dlog[n][j] Wcat[j][c]
+    dfe = torch.empty((N, F), dtype=torch.float32, device=feats.device)
+    ops.gemm_f32(dlog, KT, 1, Wcat, F, 1, dfe, F, N, F, KT)
+    return dfe, dW, db, None, None
+
+
+class ClusterNet5gHead(nn.Module):
+  def __init__(self, config, output_k=None):
+    super(ClusterNet5gHead, self).__init__()
+    self.batchnorm_track = config.batchnorm_track
+    self.num_sub_heads = config.num_sub_heads
+    self.output_k = config.output_k if output_k is None else output_k
+    self.heads = nn.ModuleList([nn.Sequential(
+      nn.Linear(512 * BasicBlock.expansion, self.output_k),
+      nn.Softmax(dim=1)) for _ in range(self.num_sub_heads)])
+
+  def forward_packed(self, feats):
+    """probs [N, H, k] fp32 (all sub-heads, one GEMM)."""
+    Wcat = torch.cat([h[0].weight for h in self.heads], dim=0)
+    bcat = torch.cat([h[0].bias for h in self.heads], dim=0)
+    return _HeadsFn.apply(feats, Wcat, bcat, self.num_sub_heads, self.output_k)
+
+  def forward(self, x, kmeans_use_features=False):
+    if kmeans_use_features:
+      return [x for _ in range(self.num_sub_heads)]   # duplicates, as the reference
+    probs = self.forward_packed(x)
+    return [probs[:, i, :] for i in range(self.num_sub_heads)]
+
+
+# ------------------------------------------------------------------------------------
+# trunk  (net5g.py:10-58, residual.py:46-68)
+# ------------------------------------------------------------------------------------
+class ClusterNet5gTrunk(nn.Module):
+  def __init__(self, config):
+    super(ClusterNet5gTrunk, self).__init__()
+    self.batchnorm_track = config.batchnorm_track
+    layers = [3, 4, 6, 3]
+    self.inplanes = 64
+    self.conv1 = nn.Conv2d(config.in_channels, 64, kernel_size=3, stride=1, padding=1, bias=False)
+    self.bn1 = nn.BatchNorm2d(64, track_running_stats=self.batchnorm_track)
+    self.layer1 = self._make_layer(64, layers[0])
+    self.layer2 = self._make_layer(128, layers[1], stride=2)
+    self.layer3 = self._make_layer(256, layers[2], stride=2)
+    self.layer4 = self._make_layer(512, layers[3], stride=2)
+    assert config.input_sz in (96, 64, 32)
+    self.input_sz = config.input_sz
+    self._h_conv1 = _ConvHolder(self.conv1)
+
+  def _make_layer(self, planes, blocks, stride=1):
+    downsample = None
+    if stride != 1 or self.inplanes != planes:
+      downsample = nn.Sequential(
+        nn.Conv2d(self.inplanes, planes, kernel_size=1, stride=stride, bias=False),
+        nn.BatchNorm2d(planes, track_running_stats=self.batchnorm_track))
+    layers = [BasicBlock(self.inplanes, planes, stride, downsample,
+                         track_running_stats=self.batchnorm_track)]
+    self.inplanes = planes
+    for _ in range(1, blocks):
+      layers.append(BasicBlock(self.inplanes, planes, track_running_stats=self.batchnorm_track))
+    return nn.Sequential(*layers)
+
+  def forward(self, x, penultimate_features=False):
+    x = _StemFn.apply(x, self.conv1.weight, self.bn1.weight, self.bn1.bias, self)
+    x = self.layer1(x)
+    x = self.layer2(x)
+    x = self.layer3(x)
+    if penultimate_features:
+      return ops.pt_to_nchw(x, 1).reshape(x.size(0), -1)
+    x = self.layer4(x)
+    return _AvgPoolFn.apply(x)   # avg_pool_sz == final spatial size for 96 / 64 / 32 inputs
+
+
+def _initialize_weights(net):
+  """residual.py:75-85."""
+  for m in net.modules():
+    if isinstance(m, nn.Conv2d):
+      nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+    elif isinstance(m, nn.BatchNorm2d):
+      assert m.track_running_stats == net.batchnorm_track
+      m.weight.data.fill_(1)
+      m.bias.data.zero_()
+    elif isinstance(m, nn.Linear):
+      m.weight.data.normal_(0, 0.01)
+      m.bias.data.zero_()
+
+
+class ClusterNet5g(nn.Module):
+  def __init__(self, config):
+    super(ClusterNet5g, self).__init__()
+    self.batchnorm_track = config.batchnorm_track
+    self.trunk = ClusterNet5gTrunk(config)
+    self.head = ClusterNet5gHead(config)
+    _initialize_weights(self)
+
+  def set_wgrad_tr(self, flag):
+    for m in self.modules():
+      if isinstance(m, BasicBlock):
+        m._use_tr = bool(flag)
+
+  def forward_packed(self, x):
+    """All sub-head outputs as one [N, H, k] tensor (feeds IID_loss_heads; 3 loss launches)."""
+    return self.head.forward_packed(self.trunk(x))
+
+  def forward(self, x, kmeans_use_features=False, trunk_features=False, penultimate_features=False):
+    x = self.trunk(x, penultimate_features=penultimate_features)
+    if trunk_features:
+      return x
+    return self.head(x, kmeans_use_features=kmeans_use_features)
+
+
+class ClusterNet5gTwoHead(nn.Module):
+  """net5g_two_head.py:42-81 (head A = overclustering output_k_A, head B = output_k_B)."""
+
+  def __init__(self, config):
+    super(ClusterNet5gTwoHead, self).__init__()
+    self.batchnorm_track = config.batchnorm_track
+    self.trunk = ClusterNet5gTrunk(config)
+    self.head_A = ClusterNet5gHead(config, output_k=config.output_k_A)
+    semisup = hasattr(config, "semisup") and config.semisup
+    assert not semisup, "semisup head is outside the IIC hot path (SURVEY.md §2 row 13)"
+    self.head_B = ClusterNet5gHead(config, output_k=config.output_k_B)
+    _initialize_weights(self)
+
+  set_wgrad_tr = ClusterNet5g.set_wgrad_tr
+
+  def forward_packed(self, x, head="B"):
+    return (self.head_A if head == "A" else self.head_B).forward_packed(self.trunk(x))
+
+  def forward(self, x, head="B", kmeans_use_features=False, trunk_features=False,
+              penultimate_features=False):
+    x = self.trunk(x, penultimate_features=penultimate_features)
+    if trunk_features:
+      return x
+    if head == "A":
+      return self.head_A(x, kmeans_use_features=kmeans_use_features)
+    elif head == "B":
+      return self.head_B(x, kmeans_use_features=kmeans_use_features)
+    raise AssertionError("head must be A or B")

@@ -1,0 +1,299 @@
+// BatchNorm2d / ReLU / residual-add kernels on PT (padded NHWC bf16) tensors for gfx950.
+// HBM-bound streaming kernels: 16 B per lane, interior pixels only (zero border preserved).
+//
+// Replaces nn.BatchNorm2d + nn.ReLU + `out += residual` of
+//   /root/reference/code/archs/cluster/residual.py:20-41,56-57 and vgg.py:28-30
+// (train mode: biased batch variance, eps 1e-5; running stats momentum 0.1 with the
+// unbiased variance, exactly torch.nn.BatchNorm2d).
+//
+// Forward statistics (sum, sum of squares per channel) are produced by the conv kernel's
+// epilogue into IIC_STAT_STRIPES stripes; bn_finalize folds them into per-channel
+// scale/shift.  Backward: bn_bwd_reduce (sum g, sum g*y) -> bn_bwd_finalize (c1,c2,c3,
+// dgamma, dbeta) -> bn_bwd_apply (dy = c1*g + c2*y + c3), with g = dout * (act > 0).
+#include "common.h"
+#include "../../include/iic_hip.h"
+
+__device__ __forceinline__ void unpack8(const uint4 v, float* f) {
+  f[0] = bf16lo(v.x); f[1] = bf16hi(v.x); f[2] = bf16lo(v.y); f[3] = bf16hi(v.y);
+  f[4] = bf16lo(v.z); f[5] = bf16hi(v.z); f[6] = bf16lo(v.w); f[7] = bf16hi(v.w);
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+  return make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]),
+                    pack_bf16x2(f[6], f[7]));
+}
+
+// coef layout: [0]=scale [1]=shift [2]=mean [3]=invstd, each [C]
+__global__ void bn_finalize_kernel(float* __restrict__ stats, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, long long* __restrict__ nbt,
+                                   float* __restrict__ coef, int C, long count, float eps,
+                                   float momentum, int training) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && training && nbt) *nbt += 1;
+  if (c >= C) return;
+  float mean, var;
+  if (training) {
+    double s = 0.0, ss = 0.0;
+    for (int st = 0; st < IIC_STAT_STRIPES; ++st) {
+      float* p = stats + (long)st * 2 * C;
+      s += (double)p[c];
+      ss += (double)p[C + c];
+      p[c] = 0.f;          // self-cleaning: ready for the next accumulation
+      p[C + c] = 0.f;
+    }
+    const double m = s / (double)count;
+    double v = ss / (double)count - m * m;
+    if (v < 0.0) v = 0.0;
+    mean = (float)m;
+    var = (float)v;
+    if (running_mean) {
+      const double unb = count > 1 ? v * (double)count / (double)(count - 1) : v;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+  } else {
+    mean = running_mean[c];
+    var = running_var[c];
+  }
+  const float invstd = rsqrtf(var + eps);
+  // one Newton step: rsqrtf is ~1 ulp on gfx950, keep it exact enough for fp32 parity
+  const float sc = gamma[c] * invstd;
+  coef[c] = sc;
+  coef[C + c] = beta[c] - mean * sc;
+  coef[2 * C + c] = mean;
+  coef[3 * C + c] = invstd;
+}
+
+// out = act( scale*y + shift [+ res] [+ scale2*y2 + shift2] ), grid = (N*H, ceil(W*C/8/256))
+__global__ __launch_bounds__(256) void bn_apply_kernel(
+    const bf16_t* __restrict__ y, const float* __restrict__ coef, const bf16_t* __restrict__ res,
+    const bf16_t* __restrict__ y2, const float* __restrict__ coef2, bf16_t* __restrict__ out,
+    int H, int W, int P, int C, int relu) {
+  const int c8n = C >> 3;
+  const int item = blockIdx.y * blockDim.x + threadIdx.x;
+  if (item >= W * c8n) return;
+  const int xq = item / c8n, c8 = item - xq * c8n;
+  const int n = blockIdx.x / H, yy = blockIdx.x - n * H;
+  const int Hp = H + 2 * P, Wp = W + 2 * P;
+  const long off = (((long)n * Hp + yy + P) * Wp + xq + P) * C + c8 * 8;
+  float v[8], sc[8], sh[8];
+  unpack8(*reinterpret_cast<const uint4*>(y + off), v);
+  *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(coef + c8 * 8);
+  *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(coef + c8 * 8 + 4);
+  *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(coef + C + c8 * 8);
+  *reinterpret_cast<float4*>(sh + 4) = *reinterpret_cast<const float4*>(coef + C + c8 * 8 + 4);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = v[i] * sc[i] + sh[i];
+  if (res) {
+    float r[8];
+    unpack8(*reinterpret_cast<const uint4*>(res + off), r);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += r[i];
+  }
+  if (y2) {
+    float r[8];
+    unpack8(*reinterpret_cast<const uint4*>(y2 + off), r);
+    *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(coef2 + c8 * 8);
+    *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(coef2 + c8 * 8 + 4);
+    *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(coef2 + C + c8 * 8);
+    *reinterpret_cast<float4*>(sh + 4) = *reinterpret_cast<const float4*>(coef2 + C + c8 * 8 + 4);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += r[i] * sc[i] + sh[i];
+  }
+  if (relu) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+  }
+  *reinterpret_cast<uint4*>(out + off) = pack8(v);
+}
+
+// sums[stripe][0][C] += sum g ; sums[stripe][1][C] += sum g*y   (g = dout * (act > 0))
+// block = 256 threads: channel chunk = tid % (C/8), pixel lane = tid / (C/8); grid-stride over rows.
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
+    const bf16_t* __restrict__ dout, const bf16_t* __restrict__ act, const bf16_t* __restrict__ y,
+    const bf16_t* __restrict__ y2, float* __restrict__ sums, float* __restrict__ sums2, int N, int H,
+    int W, int P, int C) {
+  __shared__ float s_acc[256 * 8];
+  const int c8n = C >> 3;
+  const int PL = 256 / c8n;
+  const int c8 = threadIdx.x % c8n, pl = threadIdx.x / c8n;
+  const int Hp = H + 2 * P, Wp = W + 2 * P;
+  float sg[8], sgy[8], sgy2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) sg[i] = sgy[i] = sgy2[i] = 0.f;
+  const long rows = (long)N * H;
+  for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int n = (int)(row / H), yy = (int)(row - (long)n * H);
+    const long rbase = (((long)n * Hp + yy + P) * Wp + P) * C + c8 * 8;
+    for (int xq = pl; xq < W; xq += PL) {
+      const long off = rbase + (long)xq * C;
+      float g[8], v[8];
+      unpack8(*reinterpret_cast<const uint4*>(dout + off), g);
+      if (act) {
+        float a[8];
+        unpack8(*reinterpret_cast<const uint4*>(act + off), a);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g[i] = a[i] > 0.f ? g[i] : 0.f;
+      }
+      unpack8(*reinterpret_cast<const uint4*>(y + off), v);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { sg[i] += g[i]; sgy[i] += g[i] * v[i]; }
+      if (y2) {
+        unpack8(*reinterpret_cast<const uint4*>(y2 + off), v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sgy2[i] += g[i] * v[i];
+      }
+    }
+  }
+  const int stripe = blockIdx.x % IIC_STAT_STRIPES;
+  // three LDS reductions over the pixel lanes (sum g, sum g*y, sum g*y2)
+  for (int which = 0; which < (y2 ? 3 : 2); ++which) {
+    const float* src = which == 0 ? sg : (which == 1 ? sgy : sgy2);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s_acc[(pl * c8n + c8) * 8 + i] = src[i];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+      float t = 0.f;
+      for (int p = 0; p < PL; ++p) t += s_acc[(p * c8n + (c >> 3)) * 8 + (c & 7)];
+      if (which == 0) {
+        atomicAdd(sums + (long)stripe * 2 * C + c, t);
+        if (y2) atomicAdd(sums2 + (long)stripe * 2 * C + c, t);
+      } else if (which == 1) {
+        atomicAdd(sums + (long)stripe * 2 * C + C + c, t);
+      } else {
+        atomicAdd(sums2 + (long)stripe * 2 * C + C + c, t);
+      }
+    }
+  }
+}
+
+// bcoef: [0]=c1 [1]=c2 [2]=c3 ; dy = c1*g + c2*y + c3
+__global__ void bn_bwd_finalize_kernel(float* __restrict__ sums, const float* __restrict__ gamma,
+                                       const float* __restrict__ coef, float* __restrict__ bcoef,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int C,
+                                       long count) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, sy = 0.0;
+  for (int st = 0; st < IIC_STAT_STRIPES; ++st) {
+    float* p = sums + (long)st * 2 * C;
+    s += (double)p[c];
+    sy += (double)p[C + c];
+    p[c] = 0.f;
+    p[C + c] = 0.f;
+  }
+  const double mean = coef[2 * C + c], invstd = coef[3 * C + c];
+  const double sgx = (sy - mean * s) * invstd;   // sum g * xhat
+  const double c1 = (double)gamma[c] * invstd;
+  const double c2 = -c1 * sgx * invstd / (double)count;
+  const double c3 = -c1 * s / (double)count - c2 * mean;
+  bcoef[c] = (float)c1;
+  bcoef[C + c] = (float)c2;
+  bcoef[2 * C + c] = (float)c3;
+  if (dgamma) dgamma[c] = (float)sgx;
+  if (dbeta) dbeta[c] = (float)s;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const bf16_t* __restrict__ dout, const bf16_t* __restrict__ act, const bf16_t* __restrict__ y,
+    const float* __restrict__ bcoef, bf16_t* __restrict__ dy, const bf16_t* __restrict__ y2,
+    const float* __restrict__ bcoef2, bf16_t* __restrict__ dy2, int H, int W, int P, int C) {
+  const int c8n = C >> 3;
+  const int item = blockIdx.y * blockDim.x + threadIdx.x;
+  if (item >= W * c8n) return;
+  const int xq = item / c8n, c8 = item - xq * c8n;
+  const int n = blockIdx.x / H, yy = blockIdx.x - n * H;
+  const int Hp = H + 2 * P, Wp = W + 2 * P;
+  const long off = (((long)n * Hp + yy + P) * Wp + xq + P) * C + c8 * 8;
+  float g[8], v[8], o[8];
+  unpack8(*reinterpret_cast<const uint4*>(dout + off), g);
+  if (act) {
+    float a[8];
+    unpack8(*reinterpret_cast<const uint4*>(act + off), a);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g[i] = a[i] > 0.f ? g[i] : 0.f;
+  }
+  unpack8(*reinterpret_cast<const uint4*>(y + off), v);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = c8 * 8 + i;
+    o[i] = bcoef[c] * g[i] + bcoef[C + c] * v[i] + bcoef[2 * C + c];
+  }
+  *reinterpret_cast<uint4*>(dy + off) = pack8(o);
+  if (y2) {
+    unpack8(*reinterpret_cast<const uint4*>(y2 + off), v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = c8 * 8 + i;
+      o[i] = bcoef2[c] * g[i] + bcoef2[C + c] * v[i] + bcoef2[2 * C + c];
+    }
+    *reinterpret_cast<uint4*>(dy2 + off) = pack8(o);
+  }
+}
+
+extern "C" {
+
+int iic_bn_finalize(float* stats, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, long long* num_batches_tracked, float* coef, int C,
+                    long count, float eps, float momentum, int training, void* stream) {
+  if (!gamma || !beta || !coef || C <= 0) return IIC_ERR_ARG;
+  if (training && (!stats || count <= 0)) return IIC_ERR_ARG;
+  if (!training && (!running_mean || !running_var)) return IIC_ERR_ARG;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     stats, gamma, beta, running_mean, running_var, num_batches_tracked, coef, C,
+                     count, eps, momentum, training);
+  return iic_launch_status();
+}
+
+static int check_c(int C) { return (C % 64 == 0 && 256 % (C / 8) == 0 && C <= 2048) ? 0 : 1; }
+
+int iic_bn_apply(const void* y, const float* coef, const void* res, const void* y2,
+                 const float* coef2, void* out, int N, int H, int W, int P, int C, int relu,
+                 void* stream) {
+  if (!y || !coef || !out || N <= 0 || H <= 0 || W <= 0) return IIC_ERR_ARG;
+  if (C % 8 != 0) return IIC_ERR_UNSUPPORTED;
+  if ((y2 == nullptr) != (coef2 == nullptr)) return IIC_ERR_ARG;
+  dim3 grid(N * H, (W * (C / 8) + 255) / 256);
+  hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y,
+                     coef, (const bf16_t*)res, (const bf16_t*)y2, coef2, (bf16_t*)out, H, W, P, C,
+                     relu);
+  return iic_launch_status();
+}
+
+int iic_bn_bwd_reduce(const void* dout, const void* act, const void* y, const void* y2, float* sums,
+                      float* sums2, int N, int H, int W, int P, int C, void* stream) {
+  if (!dout || !y || !sums || N <= 0) return IIC_ERR_ARG;
+  if (check_c(C)) return IIC_ERR_UNSUPPORTED;
+  if ((y2 == nullptr) != (sums2 == nullptr)) return IIC_ERR_ARG;
+  long rows = (long)N * H;
+  int grid = (int)(rows < 2048 ? rows : 2048);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)dout, (const bf16_t*)act, (const bf16_t*)y, (const bf16_t*)y2,
+                     sums, sums2, N, H, W, P, C);
+  return iic_launch_status();
+}
+
+int iic_bn_bwd_finalize(float* sums, const float* gamma, const float* coef, float* bcoef,
+                        float* dgamma, float* dbeta, int C, long count, void* stream) {
+  if (!sums || !gamma || !coef || !bcoef || C <= 0 || count <= 0) return IIC_ERR_ARG;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, sums, gamma, coef, bcoef, dgamma, dbeta, C, count);
+  return iic_launch_status();
+}
+
+int iic_bn_bwd_apply(const void* dout, const void* act, const void* y, const float* bcoef, void* dy,
+                     const void* y2, const float* bcoef2, void* dy2, int N, int H, int W, int P,
+                     int C, void* stream) {
+  if (!dout || !y || !bcoef || !dy || N <= 0) return IIC_ERR_ARG;
+  if (C % 8 != 0) return IIC_ERR_UNSUPPORTED;
+  if ((y2 == nullptr) != (bcoef2 == nullptr) || (y2 == nullptr) != (dy2 == nullptr))
+    return IIC_ERR_ARG;
+  dim3 grid(N * H, (W * (C / 8) + 255) / 256);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)dout, (const bf16_t*)act, (const bf16_t*)y, bcoef, (bf16_t*)dy,
+                     (const bf16_t*)y2, bcoef2, (bf16_t*)dy2, H, W, P, C);
+  return iic_launch_status();
+}
+
+}  // extern "C"

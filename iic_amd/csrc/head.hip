@@ -1,0 +1,194 @@
+// Cluster heads for gfx950: global AvgPool -> Linear -> Softmax(dim=1) per sub-head, fp32.
+//
+// Replaces /root/reference/code/archs/cluster/net5g.py:31-39,53 (AvgPool2d + view) and
+// :69-80 (nn.Linear + nn.Softmax per sub-head); also used for ClusterNet6c's flatten +
+// Linear heads (net6c.py:47-59).
+//
+// All sub-heads are concatenated into ONE exact-fp32 MFMA GEMM (v_mfma_f32_32x32x2_f32):
+// logits[n][h*k + j]; the softmax kernel treats every (n, h) segment as a row.  These ops
+// are tiny (0.5 GFLOP / step) and launch-latency bound; fp32 keeps the loss inputs at
+// reference precision.
+#include "common.h"
+#include "../../include/iic_hip.h"
+
+// feats[n][c] = mean over the H*W interior pixels of in[n][.][.][c]   (PT bf16 -> fp32)
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const bf16_t* __restrict__ in,
+                                                          float* __restrict__ feats, int H, int W,
+                                                          int P, int C) {
+  const int n = blockIdx.x;
+  const int Hp = H + 2 * P, Wp = W + 2 * P;
+  const float inv = 1.f / (float)(H * W);
+  for (int c2 = threadIdx.x; c2 < C / 2; c2 += blockDim.x) {
+    float s0 = 0.f, s1 = 0.f;
+    for (int y = 0; y < H; ++y)
+      for (int x = 0; x < W; ++x) {
+        const uint32_t v = *reinterpret_cast<const uint32_t*>(
+            in + (((long)n * Hp + y + P) * Wp + x + P) * C + 2 * c2);
+        s0 += bf16lo(v);
+        s1 += bf16hi(v);
+      }
+    feats[(long)n * C + 2 * c2] = s0 * inv;
+    feats[(long)n * C + 2 * c2 + 1] = s1 * inv;
+  }
+}
+
+// din[n][y][x][c] = dfeats[n][c] / (H*W)
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dfeats,
+                                                          bf16_t* __restrict__ din, int H, int W,
+                                                          int P, int C) {
+  const int n = blockIdx.x;
+  const int Hp = H + 2 * P, Wp = W + 2 * P;
+  const float inv = 1.f / (float)(H * W);
+  for (int c2 = threadIdx.x; c2 < C / 2; c2 += blockDim.x) {
+    const uint32_t v = pack_bf16x2(dfeats[(long)n * C + 2 * c2] * inv,
+                                   dfeats[(long)n * C + 2 * c2 + 1] * inv);
+    for (int y = 0; y < H; ++y)
+      for (int x = 0; x < W; ++x)
+        *reinterpret_cast<uint32_t*>(din + (((long)n * Hp + y + P) * Wp + x + P) * C + 2 * c2) = v;
+  }
+}
+
+// C[m][n] (+)= sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] (+ bias[n]).  One wave per 32x32 tile.
+__global__ __launch_bounds__(64) void gemm_f32_kernel(const float* __restrict__ A, long sam,
+                                                      long sak, const float* __restrict__ B,
+                                                      long sbk, long sbn,
+                                                      const float* __restrict__ bias,
+                                                      float* __restrict__ Cm, long scm, int M, int Nn,
+                                                      int K, int accumulate) {
+  const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const int lane = threadIdx.x, i = lane & 31, kk = lane >> 5;
+  const bool vm = (m0 + i) < M, vn = (n0 + i) < Nn;
+  const float* ap = A + (long)(m0 + i) * sam;
+  const float* bp = B + (long)(n0 + i) * sbn;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  int k = 0;
+  for (; k + 8 <= K; k += 8) {
+    float a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int kq = k + 2 * u + kk;
+      a[u] = vm ? ap[(long)kq * sak] : 0.f;
+      b[u] = vn ? bp[(long)kq * sbk] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+  }
+  for (; k < K; k += 2) {
+    const int kq = k + kk;
+    const float a = (vm && kq < K) ? ap[(long)kq * sak] : 0.f;
+    const float b = (vn && kq < K) ? bp[(long)kq * sbk] : 0.f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  }
+  const int col = n0 + i;
+  const float bv = (bias && col < Nn) ? bias[col] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = m0 + mfma32_row(r, lane);
+    if (row < M && col < Nn) {
+      float v = acc[r] + bv;
+      float* o = Cm + (long)row * scm + col;
+      if (accumulate) v += *o;
+      *o = v;
+    }
+  }
+}
+
+// one wave per row of k logits
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ logits,
+                                                          float* __restrict__ probs, int rows,
+                                                          int k) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* x = logits + row * k;
+  float m = -INFINITY;
+  for (int j = lane; j < k; j += 64) m = fmaxf(m, x[j]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  float s = 0.f;
+  for (int j = lane; j < k; j += 64) s += expf(x[j] - m);
+  s = wave_sum(s);
+  const float inv = 1.f / s;
+  for (int j = lane; j < k; j += 64) probs[row * k + j] = expf(x[j] - m) * inv;
+}
+
+// dlogits = p * (dp - sum_j dp_j p_j)
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ probs,
+                                                          const float* __restrict__ dprobs,
+                                                          float* __restrict__ dlogits, int rows,
+                                                          int k) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* p = probs + row * k;
+  const float* dp = dprobs + row * k;
+  float s = 0.f;
+  for (int j = lane; j < k; j += 64) s += p[j] * dp[j];
+  s = wave_sum(s);
+  for (int j = lane; j < k; j += 64) dlogits[row * k + j] = p[j] * (dp[j] - s);
+}
+
+// out[c] (+)= sum_r A[r][c]
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A,
+                                                     float* __restrict__ out, int rows, int cols,
+                                                     int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int r = 0; r < rows; ++r) s += A[(long)r * cols + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+extern "C" {
+
+int iic_avgpool_fwd(const void* in_pt, float* feats, int N, int H, int W, int P, int C,
+                    void* stream) {
+  if (!in_pt || !feats || N <= 0 || (C & 1)) return IIC_ERR_ARG;
+  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)in_pt, feats, H, W, P, C);
+  return iic_launch_status();
+}
+
+int iic_avgpool_bwd(const float* dfeats, void* din_pt, int N, int H, int W, int P, int C,
+                    void* stream) {
+  if (!dfeats || !din_pt || N <= 0 || (C & 1)) return IIC_ERR_ARG;
+  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, dfeats,
+                     (bf16_t*)din_pt, H, W, P, C);
+  return iic_launch_status();
+}
+
+int iic_gemm_f32(const float* A, long sam, long sak, const float* B, long sbk, long sbn,
+                 const float* bias, float* C, long scm, int M, int Nn, int K, int accumulate,
+                 void* stream) {
+  if (!A || !B || !C || M <= 0 || Nn <= 0 || K <= 0) return IIC_ERR_ARG;
+  dim3 grid((M + 31) / 32, (Nn + 31) / 32);
+  hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(64), 0, (hipStream_t)stream, A, sam, sak, B, sbk,
+                     sbn, bias, C, scm, M, Nn, K, accumulate);
+  return iic_launch_status();
+}
+
+int iic_softmax_fwd(const float* logits, float* probs, int rows, int k, void* stream) {
+  if (!logits || !probs || rows <= 0 || k <= 0) return IIC_ERR_ARG;
+  hipLaunchKernelGGL(softmax_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                     logits, probs, rows, k);
+  return iic_launch_status();
+}
+
+int iic_softmax_bwd(const float* probs, const float* dprobs, float* dlogits, int rows, int k,
+                    void* stream) {
+  if (!probs || !dprobs || !dlogits || rows <= 0 || k <= 0) return IIC_ERR_ARG;
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                     probs, dprobs, dlogits, rows, k);
+  return iic_launch_status();
+}
+
+int iic_colsum_f32(const float* A, float* out, int rows, int cols, int accumulate, void* stream) {
+  if (!A || !out || rows <= 0 || cols <= 0) return IIC_ERR_ARG;
+  hipLaunchKernelGGL(colsum_kernel, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, A,
+                     out, rows, cols, accumulate);
+  return iic_launch_status();
+}
+
+}  // extern "C"

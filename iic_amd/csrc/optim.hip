@@ -1,0 +1,64 @@
+// Multi-tensor Adam for gfx950 -- replaces torch.optim.Adam as configured by
+// /root/reference/code/utils/cluster/general.py:5-9 + cluster_sobel.py:149,272
+// (betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad; torch's update formula).
+// HBM-bound: 4 reads + 3 writes of 4 B per parameter; up to ADAM_CHUNK tensors per launch
+// (pointer table in the kernel arguments), grid-stride inside each tensor.
+#include "common.h"
+#include "../../include/iic_hip.h"
+#include <math.h>
+
+#define ADAM_CHUNK 48
+struct AdamTable {
+  float* p[ADAM_CHUNK];
+  const float* g[ADAM_CHUNK];
+  float* m[ADAM_CHUNK];
+  float* v[ADAM_CHUNK];
+  long n[ADAM_CHUNK];
+};
+
+__global__ __launch_bounds__(256) void adam_kernel(const AdamTable t, float beta1, float beta2,
+                                                   float eps, float step_size, float inv_sqrt_bc2) {
+  const int ti = blockIdx.y;
+  float* __restrict__ p = t.p[ti];
+  const float* __restrict__ g = t.g[ti];
+  float* __restrict__ m = t.m[ti];
+  float* __restrict__ v = t.v[ti];
+  const long n = t.n[ti];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+    p[i] -= step_size * (mi / denom);
+  }
+}
+
+extern "C" int iic_adam_step(int n, float* const* params, const float* const* grads,
+                             float* const* exp_avg, float* const* exp_avg_sq, const long* numel,
+                             float lr, float beta1, float beta2, float eps, int step, void* stream) {
+  if (n <= 0 || !params || !grads || !exp_avg || !exp_avg_sq || !numel || step < 1)
+    return IIC_ERR_ARG;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  for (int base = 0; base < n; base += ADAM_CHUNK) {
+    AdamTable t;
+    const int cnt = (n - base) < ADAM_CHUNK ? (n - base) : ADAM_CHUNK;
+    long maxn = 0;
+    for (int i = 0; i < ADAM_CHUNK; ++i) {
+      const int j = i < cnt ? base + i : base;   // pad with a duplicate of n == 0 work
+      t.p[i] = params[j]; t.g[i] = grads[j]; t.m[i] = exp_avg[j]; t.v[i] = exp_avg_sq[j];
+      t.n[i] = i < cnt ? numel[j] : 0;
+      if (t.n[i] > maxn) maxn = t.n[i];
+    }
+    long gx = (maxn + 255) / 256;
+    if (gx > 256) gx = 256;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)gx, cnt), dim3(256), 0, (hipStream_t)stream, t,
+                       beta1, beta2, eps, step_size, inv_sqrt_bc2);
+  }
+  return iic_launch_status();
+}

@@ -1,0 +1,531 @@
+// ClusterNet5g stem for gfx950: conv3x3(Cin<=5 -> 64, pad 1) + BatchNorm + ReLU +
+// MaxPool(k2, s2, p1), plus the Sobel pre-op.
+//
+// Replaces /root/reference/code/archs/cluster/net5g.py:21-26,42-45 and
+//          /root/reference/code/utils/cluster/transforms.py:47-96 (sobel_process).
+//
+// The stem conv output (N x 96 x 96 x 64) is 20 % of all activation elements of the network
+// but costs only K = Cin*9 <= 45 MACs per output, so it is never written to HBM: every pass
+// that needs it RECOMPUTES it from the fp32 NCHW input (24-73 KB per image, L2 resident) on
+// the exact-fp32 matrix cores (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain):
+//   stem_stats      conv -> per-channel sum / sum^2                       (BN batch stats)
+//   stem_apply_pool conv -> BN -> ReLU -> 2x2/2 max-pool -> PT bf16 [N][Ho+2][Wo+2][64]
+//   stem_bwd_reduce conv -> BN/ReLU/pool-argmax routing of dpool -> sum g, sum g*y
+//   stem_bwd_wgrad  conv -> dy = c1*g + c2*y + c3 -> dW[64][K] += dy^T . patches (MFMA)
+// HBM traffic per pass = the input (+ the pooled tensor once), instead of 4 passes over a
+// 1.5 GB tensor.  (bwd-data is not needed: the input image has no gradient.)
+//
+// MFMA operand maps (32x32x2 f32): A[i = lane&31][k = lane>>5], B[k = lane>>5][j = lane&31],
+// D[row = (r&3)+8*(r>>2)+4*(lane>>5)][col = lane&31].
+#include "common.h"
+#include "../../include/iic_hip.h"
+
+#define STEM_CO 64
+#define STEM_PERSIST_BLOCKS 1024
+
+template <int CIN> struct StemK {
+  static constexpr int K = CIN * 9;
+  static constexpr int KS = (K + 1) / 2;       // MFMA k-steps (2 k per step)
+  static constexpr int NKT = (K + 31) / 32;    // 32-wide column tiles of the dW GEMM
+};
+
+template <int CIN>
+__device__ __forceinline__ void stem_load_w(const float* __restrict__ w, int lane,
+                                            float (&wr)[2][StemK<CIN>::KS]) {
+  constexpr int K = StemK<CIN>::K;
+  const int j = lane & 31, kk = lane >> 5;
+#pragma unroll
+  for (int s = 0; s < StemK<CIN>::KS; ++s) {
+    const int k = 2 * s + kk;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) wr[h][s] = k < K ? w[(j + 32 * h) * K + k] : 0.f;
+  }
+}
+
+// conv outputs for 32 pixels (row y, cols x0..x0+31) x 64 couts of one image.
+template <int CIN>
+__device__ __forceinline__ void stem_conv_tile(const float* __restrict__ xin, int H, int W, int y,
+                                               int x0, int lane,
+                                               const float (&wr)[2][StemK<CIN>::KS],
+                                               f32x16 (&acc)[2]) {
+  constexpr int K = StemK<CIN>::K;
+  const int px = x0 + (lane & 31);
+  const bool hi = (lane >> 5) != 0;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[h][r] = 0.f;
+#pragma unroll
+  for (int s = 0; s < StemK<CIN>::KS; ++s) {
+    const int k0 = 2 * s, k1 = 2 * s + 1;
+    const int c = hi ? (k1 / 9) : (k0 / 9);
+    const int dy = (hi ? ((k1 % 9) / 3) : ((k0 % 9) / 3)) - 1;
+    const int dx = (hi ? (k1 % 3) : (k0 % 3)) - 1;
+    const bool kval = hi ? (k1 < K) : true;
+    const int yy = y + dy, xx = px + dx;
+    float a = 0.f;
+    if (kval && yy >= 0 && yy < H && xx >= 0 && xx < W) a = xin[((long)c * H + yy) * W + xx];
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wr[0][s], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wr[1][s], acc[1], 0, 0, 0);
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// 1. batch statistics.  persistent grid, 4 waves / block, one 32-pixel tile per wave step.
+// ------------------------------------------------------------------------------------
+template <int CIN>
+__global__ __launch_bounds__(256) void stem_stats_kernel(const float* __restrict__ x,
+                                                         const float* __restrict__ w,
+                                                         float* __restrict__ stats, int N, int H,
+                                                         int W) {
+  __shared__ float s_red[4][2][2][32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float wr[2][StemK<CIN>::KS];
+  stem_load_w<CIN>(w, lane, wr);
+  const int nseg = (W + 31) / 32;
+  const long tiles = (long)N * H * nseg;
+  float s[2] = {0.f, 0.f}, ss[2] = {0.f, 0.f};
+  for (long t = (long)blockIdx.x * 4 + wave; t < tiles; t += (long)gridDim.x * 4) {
+    const int seg = (int)(t % nseg);
+    const long row = t / nseg;
+    const int y = (int)(row % H), n = (int)(row / H);
+    f32x16 acc[2];
+    stem_conv_tile<CIN>(x + (long)n * CIN * H * W, H, W, y, seg * 32, lane, wr, acc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const bool ok = seg * 32 + mfma32_row(r, lane) < W;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float v = ok ? acc[h][r] : 0.f;
+        s[h] += v;
+        ss[h] += v * v;
+      }
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    s[h] += __shfl_xor(s[h], 32, 64);
+    ss[h] += __shfl_xor(ss[h], 32, 64);
+    if (lane < 32) {
+      s_red[wave][h][0][lane] = s[h];
+      s_red[wave][h][1][lane] = ss[h];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int which = threadIdx.x >> 6, ch = threadIdx.x & 63;   // 0: sum, 1: sumsq
+    float t = 0.f;
+    for (int wv = 0; wv < 4; ++wv) t += s_red[wv][ch >> 5][which][ch & 31];
+    atomicAdd(stats + (long)(blockIdx.x % IIC_STAT_STRIPES) * 2 * STEM_CO + which * STEM_CO + ch, t);
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// 2. apply + pool.  block = (n, ho), one wave per 32-column segment, two conv rows.
+//    LDS: post-ReLU activations [2][W][64] bf16.
+// ------------------------------------------------------------------------------------
+template <int CIN>
+__global__ __launch_bounds__(512) void stem_apply_pool_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                       const float* __restrict__ coef, bf16_t* __restrict__ out,
+                                       int N, int H, int W) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* sP = reinterpret_cast<bf16_t*>(smem_raw);   // [2][W][64]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int Ho = H / 2 + 1, Wo = W / 2 + 1;
+  const int n = blockIdx.x / Ho, ho = blockIdx.x - n * Ho;
+  float wr[2][StemK<CIN>::KS];
+  stem_load_w<CIN>(w, lane, wr);
+  const int ch0 = lane & 31;
+  const float sc0 = coef[ch0], sc1 = coef[ch0 + 32];
+  const float sh0 = coef[STEM_CO + ch0], sh1 = coef[STEM_CO + ch0 + 32];
+#pragma unroll
+  for (int rs = 0; rs < 2; ++rs) {
+    const int y = 2 * ho - 1 + rs;
+    if (y < 0 || y >= H) continue;   // uniform per block
+    f32x16 acc[2];
+    stem_conv_tile<CIN>(x + (long)n * CIN * H * W, H, W, y, wave * 32, lane, wr, acc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int px = wave * 32 + mfma32_row(r, lane);
+      if (px < W) {
+        bf16_t* d = sP + ((long)rs * W + px) * STEM_CO;
+        d[ch0] = f32_to_bf16(fmaxf(acc[0][r] * sc0 + sh0, 0.f));
+        d[ch0 + 32] = f32_to_bf16(fmaxf(acc[1][r] * sc1 + sh1, 0.f));
+      }
+    }
+  }
+  __syncthreads();
+  const bool v0 = (2 * ho - 1) >= 0, v1 = (2 * ho) < H;
+  for (int item = threadIdx.x; item < Wo * 8; item += blockDim.x) {
+    const int wo = item >> 3, c8 = item & 7;
+    float m[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m[i] = 0.f;   // post-ReLU values are >= 0: 0 == -inf padding
+#pragma unroll
+    for (int rs = 0; rs < 2; ++rs) {
+      if (!(rs == 0 ? v0 : v1)) continue;
+#pragma unroll
+      for (int cs = 0; cs < 2; ++cs) {
+        const int cx = 2 * wo - 1 + cs;
+        if (cx < 0 || cx >= W) continue;
+        const uint4 v = *reinterpret_cast<const uint4*>(sP + ((long)rs * W + cx) * STEM_CO + c8 * 8);
+        const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          m[2 * i] = fmaxf(m[2 * i], bf16lo(vv[i]));
+          m[2 * i + 1] = fmaxf(m[2 * i + 1], bf16hi(vv[i]));
+        }
+      }
+    }
+    const long o = (((long)n * (Ho + 2) + ho + 1) * (Wo + 2) + wo + 1) * STEM_CO + c8 * 8;
+    *reinterpret_cast<uint4*>(out + o) =
+        make_uint4(pack_bf16x2(m[0], m[1]), pack_bf16x2(m[2], m[3]), pack_bf16x2(m[4], m[5]),
+                   pack_bf16x2(m[6], m[7]));
+  }
+}
+
+// Routing of the pooled gradient to the conv grid for one (window, channel): returns the
+// LDS index (0..3 -> (rs,cs)) of the arg-max of relu(bn(y)) in scan order (first max wins,
+// as torch's max_pool2d), or -1 when the max is not positive (ReLU kills the gradient).
+__device__ __forceinline__ int window_argmax(const float yv[4], const bool valid[4], float sc,
+                                             float sh) {
+  float best = -1.f;
+  int bi = -1;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (!valid[q]) continue;
+    const float a = fmaxf(yv[q] * sc + sh, 0.f);   // fp32 compare, like the fp32 reference
+    if (a > best) { best = a; bi = q; }
+  }
+  return best > 0.f ? bi : -1;
+}
+
+// ------------------------------------------------------------------------------------
+// 3/4. backward.  persistent over (n, ho) items; LDS: conv outputs y [2][W][64] fp32.
+//   MODE 0: sums[stripe][0][64] += sum g ; [1] += sum g*y
+//   MODE 1: dy = c1*g + c2*y + c3 (in LDS), dWpart[block][64][K] += dy^T . patch  (fp32 MFMA)
+// ------------------------------------------------------------------------------------
+template <int CIN, int MODE>
+__global__ __launch_bounds__(512) void stem_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                const float* __restrict__ coef, const float* __restrict__ bcoef,
+                                const bf16_t* __restrict__ dpool, float* __restrict__ outbuf, int N,
+                                int H, int W) {
+  constexpr int K = StemK<CIN>::K;
+  constexpr int NKT = StemK<CIN>::NKT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* sY = reinterpret_cast<float*>(smem_raw);   // [2][W][64]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int Ho = H / 2 + 1, Wo = W / 2 + 1;
+  float wr[2][StemK<CIN>::KS];
+  stem_load_w<CIN>(w, lane, wr);
+  const int ch0 = lane & 31;
+  const int c8 = threadIdx.x & 7;   // blockDim % 8 == 0: a thread always owns the same 8 channels
+  // per-channel coefficients live in LDS (keeps the MFMA accumulators out of scratch)
+  __shared__ float s_cf[5][STEM_CO];
+  for (int i = threadIdx.x; i < STEM_CO; i += blockDim.x) {
+    s_cf[0][i] = coef[i];
+    s_cf[1][i] = coef[STEM_CO + i];
+    s_cf[2][i] = MODE == 1 ? bcoef[i] : 0.f;
+    s_cf[3][i] = MODE == 1 ? bcoef[STEM_CO + i] : 0.f;
+    s_cf[4][i] = MODE == 1 ? bcoef[2 * STEM_CO + i] : 0.f;
+  }
+  float sg[8], sgy[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) sg[i] = sgy[i] = 0.f;
+  f32x16 dacc[2][NKT];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dacc[h][t][r] = 0.f;
+
+  const long items = (long)N * Ho;
+  for (long it = blockIdx.x; it < items; it += gridDim.x) {
+    const int n = (int)(it / Ho), ho = (int)(it - (long)n * Ho);
+    const float* xin = x + (long)n * CIN * H * W;
+    __syncthreads();   // previous item's LDS fully consumed
+#pragma unroll
+    for (int rs = 0; rs < 2; ++rs) {
+      const int y = 2 * ho - 1 + rs;
+      if (y < 0 || y >= H) continue;
+      f32x16 acc[2];
+      stem_conv_tile<CIN>(xin, H, W, y, wave * 32, lane, wr, acc);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int px = wave * 32 + mfma32_row(r, lane);
+        if (px < W) {
+          float* d = sY + ((long)rs * W + px) * STEM_CO;
+          d[ch0] = acc[0][r];
+          d[ch0 + 32] = acc[1][r];
+        }
+      }
+    }
+    __syncthreads();
+    const bool rv[2] = {(2 * ho - 1) >= 0, (2 * ho) < H};
+    for (int item = threadIdx.x; item < Wo * 8; item += blockDim.x) {
+      const int wo = item >> 3;   // (item & 7) == c8
+      const uint4 gv = *reinterpret_cast<const uint4*>(
+          dpool + (((long)n * (Ho + 2) + ho + 1) * (Wo + 2) + wo + 1) * STEM_CO + c8 * 8);
+      const uint32_t gg[4] = {gv.x, gv.y, gv.z, gv.w};
+      bool valid[4];
+      int lidx[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int rs = q >> 1, cx = 2 * wo - 1 + (q & 1);
+        valid[q] = rv[rs] && cx >= 0 && cx < W;
+        lidx[q] = (rs * W + (valid[q] ? cx : 0)) * STEM_CO + c8 * 8;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float yv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) yv[q] = valid[q] ? sY[lidx[q] + i] : 0.f;
+        const int am = window_argmax(yv, valid, s_cf[0][c8 * 8 + i], s_cf[1][c8 * 8 + i]);
+        const float g = (i & 1) ? bf16hi(gg[i >> 1]) : bf16lo(gg[i >> 1]);
+        if (MODE == 0) {
+          if (am >= 0) {
+            sg[i] += g;
+            sgy[i] += g * yv[am];
+          }
+        } else {
+          const float cb1 = s_cf[2][c8 * 8 + i], cb2 = s_cf[3][c8 * 8 + i], cb3 = s_cf[4][c8 * 8 + i];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (valid[q]) sY[lidx[q] + i] = cb1 * (q == am ? g : 0.f) + cb2 * yv[q] + cb3;
+        }
+      }
+    }
+    if (MODE == 1) {
+      __syncthreads();
+      // dW[co][k] += sum_pix dy[pix][co] * patch[pix][k];  this wave: its 32 columns, both rows
+      const int i = lane & 31, kk = lane >> 5;
+#pragma unroll
+      for (int rs = 0; rs < 2; ++rs) {
+        const int y = 2 * ho - 1 + rs;
+        if (!rv[rs]) continue;
+        for (int s = 0; s < 16; ++s) {
+          const int px = wave * 32 + 2 * s + kk;     // this lane's k-slot pixel
+          const bool pv = px < W;
+          const float* d = sY + ((long)rs * W + (pv ? px : 0)) * STEM_CO;
+          const float a0 = pv ? d[i] : 0.f, a1 = pv ? d[i + 32] : 0.f;
+#pragma unroll
+          for (int t = 0; t < NKT; ++t) {
+            const int k = t * 32 + i;
+            float b = 0.f;
+            if (pv && k < K) {
+              const int c = k / 9, dy = (k % 9) / 3 - 1, dx = (k % 3) - 1;
+              const int yy = y + dy, xx = px + dx;
+              if (yy >= 0 && yy < H && xx >= 0 && xx < W) b = xin[((long)c * H + yy) * W + xx];
+            }
+            dacc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, dacc[0][t], 0, 0, 0);
+            dacc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, dacc[1][t], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  __syncthreads();
+  if (MODE == 0) {
+    float* red = sY;   // [blockDim][16]
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      red[threadIdx.x * 16 + i] = sg[i];
+      red[threadIdx.x * 16 + 8 + i] = sgy[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      const int which = threadIdx.x >> 6, ch = threadIdx.x & 63;
+      float t = 0.f;
+      for (int th = (ch >> 3); th < (int)blockDim.x; th += 8) t += red[th * 16 + which * 8 + (ch & 7)];
+      atomicAdd(outbuf + (long)(blockIdx.x % IIC_STAT_STRIPES) * 2 * STEM_CO + which * STEM_CO + ch, t);
+    }
+  } else {
+    // reduce the waves' accumulators through LDS, then one partial [64][NKT*32] per block
+    float* red = sY;   // [nwaves][64][NKT*32]
+    constexpr int LD = NKT * 32;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int t = 0; t < NKT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          red[((long)wave * 64 + h * 32 + mfma32_row(r, lane)) * LD + t * 32 + (lane & 31)] =
+              dacc[h][t][r];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 64 * LD; idx += blockDim.x) {
+      float t = 0.f;
+      for (int wv = 0; wv < nwaves; ++wv) t += red[(long)wv * 64 * LD + idx];
+      outbuf[(long)blockIdx.x * 64 * LD + idx] = t;
+    }
+  }
+}
+
+// dW[co][k] = sum_b part[b][co][k]  (k < K), fp32 OIHW flatten
+__global__ void stem_wgrad_reduce_kernel(const float* __restrict__ part, int nblocks, int LD, int K,
+                                         float* __restrict__ dW) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 64 * K) return;
+  const int co = idx / K, k = idx - co * K;
+  float t = 0.f;
+  for (int b = 0; b < nblocks; ++b) t += part[((long)b * 64 + co) * LD + k];
+  dW[idx] = t;
+}
+
+// ------------------------------------------------------------------------------------
+// Sobel pre-op (transforms.py:47-96): grey -> dx, dy (zero padded 3x3 correlations), other
+// channels copied in the reference's concat order.  One thread per output pixel.
+// ------------------------------------------------------------------------------------
+__global__ void sobel_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int C,
+                             int Cout, int H, int W, int grey_c, int sob_c, int ncopy,
+                             const int4 copy_src, const int4 copy_dst) {
+  const long total = (long)N * H * W;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const int xq = (int)(idx % W);
+    const long r = idx / W;
+    const int y = (int)(r % H), n = (int)(r / H);
+    const float* gp = in + ((long)n * C + grey_c) * H * W;
+    float v[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const int yy = y + a - 1, xx = xq + b - 1;
+        v[a][b] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? gp[(long)yy * W + xx] : 0.f;
+      }
+    // same accumulation order as a direct 3x3 correlation (row-major taps)
+    float dx = 0.f, dy = 0.f;
+    dx += v[0][0] * 1.f; dx += v[0][2] * -1.f; dx += v[1][0] * 2.f; dx += v[1][2] * -2.f;
+    dx += v[2][0] * 1.f; dx += v[2][2] * -1.f;
+    dy += v[0][0] * 1.f; dy += v[0][1] * 2.f; dy += v[0][2] * 1.f; dy += v[2][0] * -1.f;
+    dy += v[2][1] * -2.f; dy += v[2][2] * -1.f;
+    float* op = out + (long)n * Cout * H * W + (long)y * W + xq;
+    op[(long)sob_c * H * W] = dx;
+    op[(long)(sob_c + 1) * H * W] = dy;
+    const int cs[4] = {copy_src.x, copy_src.y, copy_src.z, copy_src.w};
+    const int cd[4] = {copy_dst.x, copy_dst.y, copy_dst.z, copy_dst.w};
+    for (int i = 0; i < ncopy; ++i)
+      op[(long)cd[i] * H * W] = in[((long)n * C + cs[i]) * H * W + (long)y * W + xq];
+  }
+}
+
+#define STEM_DISPATCH(CIN_, CALL)            \
+  switch (CIN_) {                            \
+    case 1: { constexpr int CI = 1; CALL; } break; \
+    case 2: { constexpr int CI = 2; CALL; } break; \
+    case 3: { constexpr int CI = 3; CALL; } break; \
+    case 4: { constexpr int CI = 4; CALL; } break; \
+    case 5: { constexpr int CI = 5; CALL; } break; \
+    default: return IIC_ERR_UNSUPPORTED;     \
+  }
+
+static int stem_check(const void* x, const void* w, int N, int Cin, int H, int W) {
+  if (!x || !w || N <= 0) return IIC_ERR_ARG;
+  if (Cin < 1 || Cin > 5 || H < 2 || W < 2 || (H & 1) || (W & 1) || W > 256) return IIC_ERR_UNSUPPORTED;
+  return IIC_OK;
+}
+
+extern "C" {
+
+int iic_stem_stats(const float* x, const float* w, float* stats, int N, int Cin, int H, int W,
+                   void* stream) {
+  int rc = stem_check(x, w, N, Cin, H, W);
+  if (rc) return rc;
+  if (!stats) return IIC_ERR_ARG;
+  const long tiles = (long)N * H * ((W + 31) / 32);
+  int grid = (int)((tiles + 3) / 4);
+  if (grid > STEM_PERSIST_BLOCKS) grid = STEM_PERSIST_BLOCKS;
+  STEM_DISPATCH(Cin, hipLaunchKernelGGL(stem_stats_kernel<CI>, dim3(grid), dim3(256), 0,
+                                        (hipStream_t)stream, x, w, stats, N, H, W));
+  return iic_launch_status();
+}
+
+int iic_stem_apply_pool(const float* x, const float* w, const float* coef, void* out_pt, int N,
+                        int Cin, int H, int W, void* stream) {
+  int rc = stem_check(x, w, N, Cin, H, W);
+  if (rc) return rc;
+  if (!coef || !out_pt) return IIC_ERR_ARG;
+  const int nseg = (W + 31) / 32, Ho = H / 2 + 1;
+  const size_t lds = (size_t)2 * W * STEM_CO * sizeof(bf16_t);
+  STEM_DISPATCH(Cin, hipLaunchKernelGGL(stem_apply_pool_kernel<CI>, dim3(N * Ho), dim3(64 * nseg),
+                                        lds, (hipStream_t)stream, x, w, coef, (bf16_t*)out_pt, N, H,
+                                        W));
+  return iic_launch_status();
+}
+
+static size_t stem_bwd_lds(int Cin, int W, int nseg, int mode) {
+  size_t a = (size_t)2 * W * STEM_CO * sizeof(float);
+  size_t b = mode == 0 ? (size_t)64 * nseg * 16 * sizeof(float)
+                       : (size_t)nseg * 64 * ((Cin * 9 + 31) / 32) * 32 * sizeof(float);
+  return a > b ? a : b;
+}
+
+int iic_stem_bwd_reduce(const float* x, const float* w, const float* coef, const void* dpool_pt,
+                        float* sums, int N, int Cin, int H, int W, void* stream) {
+  int rc = stem_check(x, w, N, Cin, H, W);
+  if (rc) return rc;
+  if (!coef || !dpool_pt || !sums) return IIC_ERR_ARG;
+  const int nseg = (W + 31) / 32, Ho = H / 2 + 1;
+  long items = (long)N * Ho;
+  int grid = (int)(items < STEM_PERSIST_BLOCKS ? items : STEM_PERSIST_BLOCKS);
+  const size_t lds = stem_bwd_lds(Cin, W, nseg, 0);
+  STEM_DISPATCH(Cin, hipLaunchKernelGGL((stem_bwd_kernel<CI, 0>), dim3(grid), dim3(64 * nseg), lds,
+                                        (hipStream_t)stream, x, w, coef, (const float*)nullptr,
+                                        (const bf16_t*)dpool_pt, sums, N, H, W));
+  return iic_launch_status();
+}
+
+long iic_stem_wgrad_partial_floats(void) { return (long)STEM_PERSIST_BLOCKS * 64 * 64; }
+
+int iic_stem_bwd_wgrad(const float* x, const float* w, const float* coef, const float* bcoef,
+                       const void* dpool_pt, float* partials, float* dW, int N, int Cin, int H,
+                       int W, void* stream) {
+  int rc = stem_check(x, w, N, Cin, H, W);
+  if (rc) return rc;
+  if (!coef || !bcoef || !dpool_pt || !partials || !dW) return IIC_ERR_ARG;
+  const int nseg = (W + 31) / 32, Ho = H / 2 + 1;
+  long items = (long)N * Ho;
+  int grid = (int)(items < STEM_PERSIST_BLOCKS ? items : STEM_PERSIST_BLOCKS);
+  const size_t lds = stem_bwd_lds(Cin, W, nseg, 1);
+  static bool attr = false;
+  (void)attr;
+  STEM_DISPATCH(Cin, {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_bwd_kernel<CI, 1>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((stem_bwd_kernel<CI, 1>), dim3(grid), dim3(64 * nseg), lds,
+                       (hipStream_t)stream, x, w, coef, bcoef, (const bf16_t*)dpool_pt, partials, N,
+                       H, W);
+  });
+  const int K = Cin * 9, LD = ((K + 31) / 32) * 32;
+  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((64 * K + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, partials, grid, LD, K, dW);
+  return iic_launch_status();
+}
+
+int iic_sobel(const float* imgs, float* out, int N, int C, int H, int W, int include_rgb,
+              int using_IR, void* stream) {
+  if (!imgs || !out || N <= 0 || H <= 0 || W <= 0) return IIC_ERR_ARG;
+  // channel bookkeeping of transforms.py:50-67,83-94
+  int grey_c, sob_c, ncopy = 0, Cout;
+  int4 cs = make_int4(0, 0, 0, 0), cd = make_int4(0, 0, 0, 0);
+  if (!using_IR) {
+    if (!include_rgb) { if (C != 1) return IIC_ERR_ARG; grey_c = 0; sob_c = 0; Cout = 2; }
+    else { if (C != 4) return IIC_ERR_ARG; grey_c = 3; sob_c = 3; Cout = 5; ncopy = 3;
+           cs = make_int4(0, 1, 2, 0); cd = make_int4(0, 1, 2, 0); }
+  } else {
+    if (!include_rgb) { if (C != 2) return IIC_ERR_ARG; grey_c = 0; sob_c = 0; Cout = 3; ncopy = 1;
+                        cs = make_int4(1, 0, 0, 0); cd = make_int4(2, 0, 0, 0); }
+    else { if (C != 5) return IIC_ERR_ARG; grey_c = 3; sob_c = 3; Cout = 6; ncopy = 4;
+           cs = make_int4(0, 1, 2, 4); cd = make_int4(0, 1, 2, 5); }
+  }
+  const long total = (long)N * H * W;
+  int grid = (int)((total + 255) / 256);
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(sobel_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, imgs, out, N, C,
+                     Cout, H, W, grey_c, sob_c, ncopy, cs, cd);
+  return iic_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,238 @@
+"""Thin torch-tensor wrappers over the C ABI (include/iic_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every arithmetic op on
+the hot path is a kernel of libiic_hip.so.  All wrappers enqueue on torch's current stream.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import IIC_STAT_STRIPES, check, lib, ptr, stream_ptr
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+# ------------------------------------------------------------------------------------
+# PT ("padded tile") activation buffers: bf16 [N, H+2P, W+2P, C], zero border.
+# Kernels write interiors only, so buffers are zeroed ONCE and recycled through a pool
+# (no per-step memset traffic).  A buffer is handed out by `alloc`, and returned with
+# `release` once every kernel that reads it has been enqueued (stream-ordered reuse).
+# ------------------------------------------------------------------------------------
+class PTPool(object):
+  def __init__(self):
+    self.free = {}
+    self.allocated_bytes = 0
+
+  def alloc(self, shape, device):
+    key = (tuple(shape), str(device))
+    lst = self.free.get(key)
+    if lst:
+      return lst.pop()
+    t = torch.zeros(shape, dtype=BF16, device=device)
+    self.allocated_bytes += t.numel() * 2
+    return t
+
+  def release(self, t):
+    if t is None:
+      return
+    key = (tuple(t.shape), str(t.device))
+    self.free.setdefault(key, []).append(t)
+
+  def clear(self):
+    self.free.clear()
+
+
+POOL = PTPool()
+
+
+def pt_alloc(N, H, W, C, P, device):
+  return POOL.alloc((N, H + 2 * P, W + 2 * P, C), device)
+
+
+def pt_from_nchw(x, P):
+  """(test / boundary helper) NCHW float tensor -> PT bf16."""
+  n, c, h, w = x.shape
+  out = torch.zeros((n, h + 2 * P, w + 2 * P, c), dtype=BF16, device=x.device)
+  out[:, P:P + h, P:P + w, :] = x.permute(0, 2, 3, 1).to(BF16)
+  return out
+
+
+def pt_to_nchw(x, P):
+  n, hp, wp, c = x.shape
+  return x[:, P:hp - P, P:wp - P, :].permute(0, 3, 1, 2).float().contiguous()
+
+
+def new_stats(C, device):
+  return torch.zeros((IIC_STAT_STRIPES, 2, C), dtype=F32, device=device)
+
+
+# ------------------------------------------------------------------------------------
+# conv
+# ------------------------------------------------------------------------------------
+def weight_prep(w, want_bwd=True):
+  """fp32 OIHW parameter -> (bf16 [T][Co][Ci], bf16 [T][Ci][Co])."""
+  co, ci, kh, kw = w.shape
+  T = kh * kw
+  wf = torch.empty((T, co, ci), dtype=BF16, device=w.device)
+  wb = torch.empty((T, ci, co), dtype=BF16, device=w.device) if want_bwd else None
+  check(lib().iic_weight_prep(ptr(w), ptr(wf), ptr(wb), co, ci, T, stream_ptr()), "iic_weight_prep")
+  return wf, wb
+
+
+def conv_igemm(g, x_pt, w_t, out_pt, stats=None, res_grad=None, res_act=None, accumulate=False):
+  check(lib().iic_conv_igemm(ctypes.byref(g), ptr(x_pt), ptr(w_t), ptr(out_pt), ptr(stats),
+                             ptr(res_grad), ptr(res_act), 1 if accumulate else 0, stream_ptr()),
+        "iic_conv_igemm")
+  return out_pt
+
+
+_WG_PART = {}
+
+
+def conv_wgrad(g, x_pt, dy_pt, wtaps, use_tr=True, out=None, accumulate=False):
+  """Returns dW fp32 [Co][Ci][kh][kw] flattened as [Co, Ci, wtaps]."""
+  ns = lib().iic_conv_wgrad_nsplit(ctypes.byref(g))
+  need = ns * g.ntaps * g.Cout * g.Cin
+  key = str(x_pt.device)
+  part = _WG_PART.get(key)
+  if part is None or part.numel() < need:
+    part = torch.empty(max(need, 1 << 22), dtype=F32, device=x_pt.device)
+    _WG_PART[key] = part
+  check(lib().iic_conv_wgrad(ctypes.byref(g), ptr(x_pt), ptr(dy_pt), ptr(part), ns,
+                             1 if use_tr else 0, stream_ptr()), "iic_conv_wgrad")
+  if out is None:
+    out = torch.empty((g.Cout, g.Cin, wtaps), dtype=F32, device=x_pt.device)
+  assert g.ntaps == wtaps, "wgrad geometry must list every weight tap once"
+  check(lib().iic_conv_wgrad_reduce(ptr(part), ns, wtaps, g.Cout, g.Cin, ptr(out),
+                                    1 if accumulate else 0, stream_ptr()), "iic_conv_wgrad_reduce")
+  return out
+
+
+# ------------------------------------------------------------------------------------
+# batch norm
+# ------------------------------------------------------------------------------------
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def bn_finalize(stats, gamma, beta, running_mean, running_var, nbt, C, count, training):
+  coef = torch.empty((4, C), dtype=F32, device=gamma.device)
+  check(lib().iic_bn_finalize(ptr(stats), ptr(gamma), ptr(beta), ptr(running_mean),
+                              ptr(running_var), ptr(nbt), ptr(coef), C, count, BN_EPS,
+                              BN_MOMENTUM, 1 if training else 0, stream_ptr()), "iic_bn_finalize")
+  return coef
+
+
+def bn_apply(y, coef, out, N, H, W, P, C, res=None, y2=None, coef2=None, relu=True):
+  check(lib().iic_bn_apply(ptr(y), ptr(coef), ptr(res), ptr(y2), ptr(coef2), ptr(out), N, H, W, P,
+                           C, 1 if relu else 0, stream_ptr()), "iic_bn_apply")
+  return out
+
+
+def bn_bwd_reduce(dout, act, y, sums, N, H, W, P, C, y2=None, sums2=None):
+  check(lib().iic_bn_bwd_reduce(ptr(dout), ptr(act), ptr(y), ptr(y2), ptr(sums), ptr(sums2), N, H,
+                                W, P, C, stream_ptr()), "iic_bn_bwd_reduce")
+
+
+def bn_bwd_finalize(sums, gamma, coef, C, count):
+  bcoef = torch.empty((3, C), dtype=F32, device=gamma.device)
+  dgamma = torch.empty(C, dtype=F32, device=gamma.device)
+  dbeta = torch.empty(C, dtype=F32, device=gamma.device)
+  check(lib().iic_bn_bwd_finalize(ptr(sums), ptr(gamma), ptr(coef), ptr(bcoef), ptr(dgamma),
+                                  ptr(dbeta), C, count, stream_ptr()), "iic_bn_bwd_finalize")
+  return bcoef, dgamma, dbeta
+
+
+def bn_bwd_apply(dout, act, y, bcoef, dy, N, H, W, P, C, y2=None, bcoef2=None, dy2=None):
+  check(lib().iic_bn_bwd_apply(ptr(dout), ptr(act), ptr(y), ptr(bcoef), ptr(dy), ptr(y2),
+                               ptr(bcoef2), ptr(dy2), N, H, W, P, C, stream_ptr()),
+        "iic_bn_bwd_apply")
+
+
+# ------------------------------------------------------------------------------------
+# stem + sobel
+# ------------------------------------------------------------------------------------
+def sobel(imgs, include_rgb, using_IR=False):
+  n, c, h, w = imgs.shape
+  cout = {(False, False): 2, (True, False): 5, (False, True): 3, (True, True): 6}[
+    (bool(include_rgb), bool(using_IR))]
+  imgs = imgs.contiguous()
+  out = torch.empty((n, cout, h, w), dtype=F32, device=imgs.device)
+  check(lib().iic_sobel(ptr(imgs), ptr(out), n, c, h, w, 1 if include_rgb else 0,
+                        1 if using_IR else 0, stream_ptr()), "iic_sobel")
+  return out
+
+
+def stem_stats(x, w, stats):
+  n, c, h, wd = x.shape
+  check(lib().iic_stem_stats(ptr(x), ptr(w), ptr(stats), n, c, h, wd, stream_ptr()), "iic_stem_stats")
+
+
+def stem_apply_pool(x, w, coef, out_pt):
+  n, c, h, wd = x.shape
+  check(lib().iic_stem_apply_pool(ptr(x), ptr(w), ptr(coef), ptr(out_pt), n, c, h, wd, stream_ptr()),
+        "iic_stem_apply_pool")
+
+
+def stem_bwd_reduce(x, w, coef, dpool, sums):
+  n, c, h, wd = x.shape
+  check(lib().iic_stem_bwd_reduce(ptr(x), ptr(w), ptr(coef), ptr(dpool), ptr(sums), n, c, h, wd,
+                                  stream_ptr()), "iic_stem_bwd_reduce")
+
+
+_STEM_PART = {}
+
+
+def stem_bwd_wgrad(x, w, coef, bcoef, dpool):
+  n, c, h, wd = x.shape
+  key = str(x.device)
+  part = _STEM_PART.get(key)
+  if part is None:
+    part = torch.empty(lib().iic_stem_wgrad_partial_floats(), dtype=F32, device=x.device)
+    _STEM_PART[key] = part
+  dW = torch.empty_like(w)
+  check(lib().iic_stem_bwd_wgrad(ptr(x), ptr(w), ptr(coef), ptr(bcoef), ptr(dpool), ptr(part),
+                                 ptr(dW), n, c, h, wd, stream_ptr()), "iic_stem_bwd_wgrad")
+  return dW
+
+
+# ------------------------------------------------------------------------------------
+# heads
+# ------------------------------------------------------------------------------------
+def avgpool_fwd(x_pt, N, H, W, P, C):
+  feats = torch.empty((N, C), dtype=F32, device=x_pt.device)
+  check(lib().iic_avgpool_fwd(ptr(x_pt), ptr(feats), N, H, W, P, C, stream_ptr()), "iic_avgpool_fwd")
+  return feats
+
+
+def avgpool_bwd(dfeats, out_pt, N, H, W, P, C):
+  check(lib().iic_avgpool_bwd(ptr(dfeats), ptr(out_pt), N, H, W, P, C, stream_ptr()),
+        "iic_avgpool_bwd")
+  return out_pt
+
+
+def gemm_f32(A, sam, sak, B, sbk, sbn, C, scm, M, N, K, bias=None, accumulate=False):
+  check(lib().iic_gemm_f32(ptr(A), sam, sak, ptr(B), sbk, sbn, ptr(bias), ptr(C), scm, M, N, K,
+                           1 if accumulate else 0, stream_ptr()), "iic_gemm_f32")
+  return C
+
+
+def softmax_fwd(logits, rows, k):
+  probs = torch.empty_like(logits)
+  check(lib().iic_softmax_fwd(ptr(logits), ptr(probs), rows, k, stream_ptr()), "iic_softmax_fwd")
+  return probs
+
+
+def softmax_bwd(probs, dprobs, rows, k):
+  dl = torch.empty_like(probs)
+  check(lib().iic_softmax_bwd(ptr(probs), ptr(dprobs), ptr(dl), rows, k, stream_ptr()),
+        "iic_softmax_bwd")
+  return dl
+
+
+def colsum(A, rows, cols):
+  out = torch.empty(cols, dtype=F32, device=A.device)
+  check(lib().iic_colsum_f32(ptr(A), ptr(out), rows, cols, 0, stream_ptr()), "iic_colsum_f32")
+  return out

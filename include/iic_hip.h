@@ -1,0 +1,178 @@
+/* libiic_hip.so -- C ABI of the MI355X-native (gfx950) IIC training hot path.
+ *
+ * The reference (xu-ji/IIC, PyTorch 0.4.1) has no FFI layer: its operator API is a
+ * set of Python call signatures.  This library sits beneath Python
+ * shims that reproduce those signatures (the iic_amd Python package); every entry point below names
+ * the reference code it replaces.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers unless
+ *     a parameter is documented as host;
+ *   - the caller owns every buffer (workspace sizes via *_bytes helpers);
+ *   - kernels are enqueued asynchronously on `stream` (a hipStream_t passed as void*),
+ *     no hidden synchronisation or allocation;
+ *   - return 0 on success, negative on error (IIC_ERR_*); nothing throws.
+ *
+ * Activation tensor format "PT" (padded tile): bf16 [N][H+2P][W+2P][C] with a ZERO
+ * border of P pixels.  Kernels only ever write interior pixels, so a buffer zeroed
+ * once keeps its border.  C must be a multiple of 64 for the MFMA conv kernels.
+ */
+#ifndef IIC_HIP_H
+#define IIC_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IIC_OK 0
+#define IIC_ERR_ARG (-1)
+#define IIC_ERR_LAUNCH (-2)
+#define IIC_ERR_UNSUPPORTED (-3)
+
+int iic_version(void);
+
+/* ---------------------------------------------------------------------------------
+ * IID clustering loss -- replaces code/utils/cluster/IID_losses.py:6-47
+ * (IID_loss + compute_joint).  z / zt: post-softmax fp32, element (h, n, i) at
+ * z[h*head_stride + n*ld + i] (ld >= k: sub-heads may be interleaved per sample).  Two-phase so that the raw joint can be all-reduced over ranks
+ *  between phase 1 and phase 2.
+ * ------------------------------------------------------------------------------- */
+int iic_iid_nsplit(int bn);                       /* recommended sample-splits          */
+long iic_iid_workspace_bytes(int H, int k);       /* float64 scratch for phase 2        */
+/* phase 1: partials[s][h][k][k] = sum over sample-split s of z^T z' (exact fp32 MFMA) */
+int iic_iid_joint_raw(const float* z, const float* zt, float* partials, int H, int bn, int k,
+                      long head_stride, long ld, int nsplit, void* stream);
+/* phase 2: sum partials -> symmetrise, normalise, marginals, clamp (eps), the two losses
+ * (IID_losses.py:21-31) and dLoss/dR, dLossNoLamb/dR ([H][k][k] fp32 each).            */
+int iic_iid_loss_from_joint(const float* partials, int nparts, int H, int k, double lamb,
+                            double eps, void* workspace, float* loss, float* loss_no_lamb,
+                            float* dR_loss, float* dR_loss_no_lamb, void* stream);
+/* phase 3: dz = (g*dR1 + gnl*dR2) applied to z' (and z for dz'); g_* are DEVICE arrays
+ * [H] of upstream gradients (NULL => 1 and 0).                                        */
+int iic_iid_grad(const float* z, const float* zt, const float* dR_loss,
+                 const float* dR_loss_no_lamb, const float* g_loss, const float* g_loss_no_lamb,
+                 float* dz, float* dzt, int H, int bn, int k, long head_stride, long ld,
+                 void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Convolution as an im2col-free implicit GEMM on bf16 MFMA (fp32 accumulate).
+ * Replaces the cuDNN conv fwd / bwd-data / bwd-weight the reference reaches through
+ * nn.Conv2d in code/archs/cluster/residual.py:4-7,19,22,54-55, net5g.py:21-23,
+ * vgg.py:24-26.  One kernel serves forward and backward-data: the geometry maps GEMM
+ * row m=(n,y,x) to an input pixel and an output pixel, and lists the taps.
+ * ------------------------------------------------------------------------------- */
+#define IIC_MAX_TAPS 32
+typedef struct {
+  int32_t N, MY, MX;            /* GEMM rows M = N*MY*MX, m -> (n, y, x)                       */
+  int32_t in_Hp, in_Wp, Cin;    /* input  PT tensor dims (padded)                              */
+  int32_t sy, sx, oy, ox;       /* input pixel of row m, tap offset 0:                         */
+                                /*   (n*in_Hp + y*sy+oy)*in_Wp + x*sx+ox                       */
+  int32_t out_Hp, out_Wp, Cout; /* output PT tensor dims (padded)                              */
+  int32_t ty, tx, py, px;       /* output pixel (n*out_Hp + y*ty+py)*out_Wp + x*tx+px          */
+  int32_t ntaps;
+  int32_t tap_off[IIC_MAX_TAPS];/* >=0, added to the input pixel index                         */
+  int32_t tap_w[IIC_MAX_TAPS];  /* which [Cout][Cin] slice of the weight tensor the tap uses   */
+  int32_t NP;                   /* LDS patch pixels per 128-row tile (max input span + 1)      */
+} iic_conv_geom;
+
+long iic_conv_lds_bytes(const iic_conv_geom* g, int BN);
+/* out[pout(m)][co] = sum_t sum_ci in[pin(m)+tap_off[t]][ci] * w[tap_w[t]][co][ci]
+ * w: bf16 [wtaps][Cout][Cin].  stats (nullable): fp32 [IIC_STAT_STRIPES][2][Cout],
+ * += per-channel sum / sum of squares of the fp32 accumulators (BatchNorm batch stats).
+ * res_grad/res_act (nullable, PT like out): out += res_grad where res_act > 0 (fused
+ * ReLU-masked residual gradient).  accumulate != 0: out += previous contents.          */
+#define IIC_STAT_STRIPES 32
+int iic_conv_igemm(const iic_conv_geom* g, const void* in, const void* w, void* out,
+                   float* stats, const void* res_grad, const void* res_act, int accumulate,
+                   void* stream);
+/* bwd-weight: partial[s][t][co][ci] (fp32) = sum over the rows of split s of
+ * dy[pout(m)][co] * x[pin(m)+tap_off[t]][ci]; the geometry is the FORWARD geometry.
+ * use_tr != 0 selects ds_read_b64_tr_b16 operand reads (fast); 0 = scalar LDS gathers. */
+int iic_conv_wgrad_nsplit(const iic_conv_geom* g);
+int iic_conv_wgrad(const iic_conv_geom* g, const void* x, const void* dy, float* partials,
+                   int nsplit, int use_tr, void* stream);
+/* dW[co][ci][kh][kw] (fp32 OIHW, the nn.Conv2d parameter layout) (+)= sum_s partial[s][t][co][ci] */
+int iic_conv_wgrad_reduce(const float* partials, int nsplit, int T, int Cout, int Cin, float* dW,
+                          int accumulate, void* stream);
+/* fp32 OIHW parameter -> bf16 [T][Co][Ci] (forward operand) and [T][Ci][Co] (bwd-data operand) */
+int iic_weight_prep(const float* w_oihw, void* w_fwd, void* w_bwd, int Cout, int Cin, int T,
+                    void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * BatchNorm2d (train / eval), ReLU, residual add -- replaces nn.BatchNorm2d / nn.ReLU /
+ * `out += residual` in residual.py:20-41,56-57, vgg.py:28-30.
+ * Statistics: stats stripes produced by iic_conv_igemm; finalised per channel here.
+ * ------------------------------------------------------------------------------- */
+/* coef[0..3][C]: scale, shift, mean, invstd.  use_running: eval() with
+ * track_running_stats.  running_* nullable (track_running_stats=False).  Re-zeroes stats. */
+int iic_bn_finalize(float* stats, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, long long* num_batches_tracked, float* coef, int C,
+                    long count, float eps, float momentum, int training, void* stream);
+/* out = relu( scale*y+shift  [+ res]  [+ scale2*y2+shift2] ) on PT interiors.            */
+int iic_bn_apply(const void* y, const float* coef, const void* res, const void* y2,
+                 const float* coef2, void* out, int N, int H, int W, int P, int C, int relu,
+                 void* stream);
+/* sums[stripe][2][C] += sum g, sum g*y  with g = dout * (act > 0) (act nullable => g = dout);
+ * second BN (y2/sums2) optional (downsample branch shares g).                           */
+int iic_bn_bwd_reduce(const void* dout, const void* act, const void* y, const void* y2,
+                      float* sums, float* sums2, int N, int H, int W, int P, int C, void* stream);
+/* from sums -> bcoef[0..2][C] = c1,c2,c3 (dy = c1*g + c2*y + c3), dgamma, dbeta. Re-zeroes sums. */
+int iic_bn_bwd_finalize(float* sums, const float* gamma, const float* coef, float* bcoef,
+                        float* dgamma, float* dbeta, int C, long count, void* stream);
+int iic_bn_bwd_apply(const void* dout, const void* act, const void* y, const float* bcoef,
+                     void* dy, const void* y2, const float* bcoef2, void* dy2, int N, int H, int W,
+                     int P, int C, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Stem: conv3x3(Cin<=5 -> 64, pad 1, no bias) + BN + ReLU + MaxPool(k2,s2,p1), computed
+ * from the fp32 NCHW input with exact-fp32 MFMA and RECOMPUTED in every pass instead of
+ * materialising the 96x96x64 tensor.  Replaces net5g.py:21-26,42-45.
+ * ------------------------------------------------------------------------------- */
+int iic_stem_stats(const float* x, const float* w, float* stats, int N, int Cin, int H, int W,
+                   void* stream);
+int iic_stem_apply_pool(const float* x, const float* w, const float* coef, void* out_pt, int N,
+                        int Cin, int H, int W, void* stream);
+int iic_stem_bwd_reduce(const float* x, const float* w, const float* coef, const void* dpool_pt,
+                        float* sums, int N, int Cin, int H, int W, void* stream);
+long iic_stem_wgrad_partial_floats(void);
+int iic_stem_bwd_wgrad(const float* x, const float* w, const float* coef, const float* bcoef,
+                       const void* dpool_pt, float* partials, float* dW, int N, int Cin, int H,
+                       int W, void* stream);
+/* Sobel pre-op -- replaces code/utils/cluster/transforms.py:47-96 (grey channel -> dx,dy;
+ * other channels copied through in the reference's order).                              */
+int iic_sobel(const float* imgs, float* out, int N, int C, int H, int W, int include_rgb,
+              int using_IR, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Heads: AvgPool(global) + Linear + Softmax(dim=1) per sub-head -- replaces
+ * net5g.py:31-39,53,69-80.  fp32 throughout (feeds the loss).
+ * ------------------------------------------------------------------------------- */
+int iic_avgpool_fwd(const void* in_pt, float* feats, int N, int H, int W, int P, int C,
+                    void* stream);
+int iic_avgpool_bwd(const float* dfeats, void* din_pt, int N, int H, int W, int P, int C,
+                    void* stream);
+/* C[m][n] (+)= sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] (+ bias[n]); exact fp32 MFMA      */
+int iic_gemm_f32(const float* A, long sam, long sak, const float* B, long sbk, long sbn,
+                 const float* bias, float* C, long scm, int M, int Nn, int K, int accumulate,
+                 void* stream);
+int iic_softmax_fwd(const float* logits, float* probs, int rows, int k, void* stream);
+int iic_softmax_bwd(const float* probs, const float* dprobs, float* dlogits, int rows, int k,
+                    void* stream);
+int iic_colsum_f32(const float* A, float* out, int rows, int cols, int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Adam -- replaces torch.optim.Adam as used by code/utils/cluster/general.py:5-9
+ * (betas (0.9,0.999), eps 1e-8, no weight decay, no amsgrad).  Multi-tensor: `n` tensors.
+ * ptrs are HOST arrays of device pointers.
+ * ------------------------------------------------------------------------------- */
+int iic_adam_step(int n, float* const* params, const float* const* grads, float* const* exp_avg,
+                  float* const* exp_avg_sq, const long* numel, float lr, float beta1, float beta2,
+                  float eps, int step, void* stream);
+
+/* one-time device probes used by the test-suite (documented in DESIGN.md) */
+int iic_probe_tr16(void* out_u16_64x4, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IIC_HIP_H */

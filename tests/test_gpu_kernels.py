@@ -1,0 +1,402 @@
+"""Per-kernel parity of the HIP path (through the C ABI) against the CPU oracle / plain
+fp32 torch-CPU references on seeded inputs.  Needs a real MI355X:  pytest -m gpu.
+
+Tolerances
+  * fp32 kernels (IID loss, heads, stem statistics, Adam, sobel): the north-star clause
+    |ours - ref| <= 1e-5*|ref64| + 2e-7 for the loss, ||dg||/||g|| <= 1e-5 for its grads.
+  * bf16-operand MFMA convs: compared with an fp32 reference fed the SAME bf16-rounded
+    operands; what remains is fp32 accumulation order + the bf16 rounding of the stored
+    output (rel 2^-9), so |d| <= 1e-2*max|ref| is generous and catches any indexing bug.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def dev():
+  assert torch.cuda.is_available(), "no GPU visible"
+  return torch.device("cuda:0")
+
+
+def bf16_round(t):
+  return t.to(torch.bfloat16).float()
+
+
+# --------------------------------------------------------------------------------------
+def test_library_loaded_and_probe_tr16():
+  from iic_amd import _lib
+  L = _lib.lib()
+  assert L.iic_version() >= 1
+  out = torch.zeros(256, dtype=torch.int16, device=dev())
+  _lib.check(L.iic_probe_tr16(out.data_ptr(), _lib.stream_ptr()))
+  torch.cuda.synchronize()
+  got = out.cpu().numpy().astype(np.int64).reshape(64, 4)
+  l = np.arange(64)[:, None]
+  j = np.arange(4)[None, :]
+  want = (l & 15) + j * 16 + (l >> 4) * 64
+  os.makedirs("gpurun_out", exist_ok=True)
+  np.savetxt("gpurun_out/probe_tr16.txt", got, fmt="%d")
+  assert np.array_equal(got, want), "ds_read_b64_tr_b16 mapping differs from the model:\n%s" % got
+
+
+# --------------------------------------------------------------------------------------
+# IID loss
+# --------------------------------------------------------------------------------------
+def _iid_tol(ref64):
+  return 1e-5 * abs(ref64) + 2e-7
+
+
+def test_iid_loss_golden_cases():
+  from iic_amd.losses import IID_loss
+  from oracle import iid_oracle
+  from oracle.gen_golden import IID_CASES
+  g = np.load(os.path.join(G, "iid_loss.npz"), allow_pickle=True)
+  for ci, (bn, k, kind, lamb, seed) in enumerate(IID_CASES):
+    z, zt = iid_oracle.make_softmax_pair(bn, k, kind, seed)
+    a = torch.from_numpy(z).to(dev()).requires_grad_(True)
+    b = torch.from_numpy(zt).to(dev()).requires_grad_(True)
+    loss, loss_nl = IID_loss(a, b, lamb=lamb)
+    loss.backward()
+    ref64 = g["c%d_loss_f64" % ci]
+    assert abs(loss.item() - ref64[0]) <= _iid_tol(ref64[0]), (ci, loss.item(), ref64[0])
+    assert abs(loss_nl.item() - ref64[1]) <= _iid_tol(ref64[1]), (ci, loss_nl.item(), ref64[1])
+    for t, key in ((a, "dz"), (b, "dzt")):
+      gref = g["c%d_%s_f64" % (ci, key)]
+      err = np.linalg.norm(t.grad.cpu().numpy().astype(np.float64) - gref) / max(np.linalg.norm(gref), 1e-30)
+      assert err <= 1e-5, (ci, key, err)
+
+
+def test_iid_loss_packed_heads_full_size_and_no_lamb_grad():
+  """5 sub-heads x 660 x 70 in 3 launches; gradient through BOTH outputs."""
+  from iic_amd.losses import IID_loss_heads
+  from oracle import iid_oracle
+  H, bn, k = 5, 660, 70
+  zs, zts = [], []
+  for h in range(H):
+    z, zt = iid_oracle.make_softmax_pair(bn, k, "trained" if h % 2 == 0 else "init", 100 + h)
+    zs.append(z)
+    zts.append(zt)
+  Z = torch.from_numpy(np.stack(zs, 1)).to(dev()).requires_grad_(True)      # [bn, H, k]
+  ZT = torch.from_numpy(np.stack(zts, 1)).to(dev()).requires_grad_(True)
+  loss, loss_nl = IID_loss_heads(Z, ZT, lamb=1.5)
+  w1 = torch.tensor([1.0, 0.5, -2.0, 0.0, 3.0], device=dev())
+  w2 = torch.tensor([0.0, 1.0, 0.25, -1.0, 0.0], device=dev())
+  ((loss * w1).sum() + (loss_nl * w2).sum()).backward()
+  for h in range(H):
+    l, lnl, dz, dzt = iid_oracle.iid_loss_np(zs[h], zts[h], 1.5, float(w1[h]), float(w2[h]))
+    assert abs(loss[h].item() - l) <= _iid_tol(l)
+    assert abs(loss_nl[h].item() - lnl) <= _iid_tol(lnl)
+    for mine, ref in ((Z.grad[:, h].cpu().numpy(), dz), (ZT.grad[:, h].cpu().numpy(), dzt)):
+      if np.linalg.norm(ref) > 0:
+        assert np.linalg.norm(mine - ref) / np.linalg.norm(ref) <= 1e-5
+
+
+def test_iid_loss_analytic_pins_and_no_grad():
+  from iic_amd.losses import IID_loss
+  from oracle import iid_oracle
+  for k in (5, 10):
+    z, zt = iid_oracle.make_softmax_pair(10 * k, k, "onehot", 0)
+    with torch.no_grad():
+      l, lnl = IID_loss(torch.from_numpy(z).to(dev()), torch.from_numpy(zt).to(dev()))
+    assert abs(l.item() + math.log(k)) < 1e-5 and abs(l.item() - lnl.item()) < 1e-7
+    u = torch.full((30, k), 1.0 / k, device=dev())
+    l, _ = IID_loss(u, u)
+    assert abs(l.item()) < 2e-7
+  # ragged last batch / odd sizes
+  z, zt = iid_oracle.make_softmax_pair(333, 37, "trained", 9)
+  l, _ = IID_loss(torch.from_numpy(z).to(dev()), torch.from_numpy(zt).to(dev()), lamb=1.0)
+  ref, _, _, _ = iid_oracle.iid_loss_np(z, zt, 1.0)
+  assert abs(l.item() - ref) <= _iid_tol(ref)
+
+
+# --------------------------------------------------------------------------------------
+# conv: implicit GEMM forward / backward-data / backward-weight
+# --------------------------------------------------------------------------------------
+CONV_CASES = [  # cin, cout, K, stride, pad, N, H
+  (64, 64, 3, 1, 1, 5, 13),     # M = 845: tail tile, BN = 64
+  (64, 128, 3, 2, 1, 3, 25),    # stride 2, BN = 128
+  (128, 128, 3, 1, 1, 4, 7),    # two channel chunks
+  (64, 128, 1, 2, 0, 3, 13),    # 1x1 stride-2 downsample
+  (256, 512, 3, 2, 1, 2, 13),   # 4 chunks
+  (64, 64, 3, 1, 1, 2, 49),     # wide rows (layer1 geometry)
+]
+
+
+def _conv_inputs(cin, cout, K, N, H, seed=0):
+  rng = np.random.default_rng(seed)
+  x = torch.from_numpy(rng.standard_normal((N, cin, H, H)).astype(np.float32))
+  w = torch.from_numpy((rng.standard_normal((cout, cin, K, K)) / math.sqrt(cin * K * K)).astype(np.float32))
+  return bf16_round(x), w
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_forward_and_stats(case):
+  from iic_amd import geom, ops
+  cin, cout, K, s, p, N, H = case
+  x, w = _conv_inputs(cin, cout, K, N, H)
+  ref = F.conv2d(x, bf16_round(w), stride=s, padding=p)
+  spec = geom.ConvSpec(cin, cout, K, s, p)
+  Ho = spec.out_size(H)
+  g = geom.fwd_geom(spec, N, H, H, 1, 1)
+  wf, wb = ops.weight_prep(w.to(dev()))
+  xp = ops.pt_from_nchw(x.to(dev()), 1)
+  out = torch.zeros((N, Ho + 2, Ho + 2, cout), dtype=torch.bfloat16, device=dev())
+  stats = ops.new_stats(cout, dev())
+  ops.conv_igemm(g, xp, wf, out, stats=stats)
+  torch.cuda.synchronize()
+  got = ops.pt_to_nchw(out, 1).cpu()
+  scale = ref.abs().max().item()
+  assert (got - ref).abs().max().item() <= 1e-2 * scale, (got - ref).abs().max().item() / scale
+  o = out.float().cpu()
+  assert o[:, 0].abs().max() == 0 and o[:, :, 0].abs().max() == 0 and o[:, -1].abs().max() == 0
+  st = stats.sum(0).cpu()
+  cnt = N * Ho * Ho
+  assert torch.allclose(st[0] / cnt, ref.mean((0, 2, 3)), atol=2e-3 * scale)
+  assert torch.allclose(st[1] / cnt, (ref * ref).mean((0, 2, 3)), rtol=2e-3, atol=1e-4 * scale * scale)
+  # weight prep layouts
+  assert torch.equal(wf.float().cpu(), bf16_round(w).permute(2, 3, 0, 1).reshape(K * K, cout, cin))
+  assert torch.equal(wb.float().cpu(), bf16_round(w).permute(2, 3, 1, 0).reshape(K * K, cin, cout))
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_backward_data(case):
+  from iic_amd import geom, ops
+  cin, cout, K, s, p, N, H = case
+  x, w = _conv_inputs(cin, cout, K, N, H, 1)
+  wr = bf16_round(w)
+  xt = x.clone().requires_grad_(True)
+  y = F.conv2d(xt, wr, stride=s, padding=p)
+  dy = bf16_round(torch.from_numpy(np.random.default_rng(2).standard_normal(tuple(y.shape)).astype(np.float32)))
+  y.backward(dy)
+  ref = xt.grad
+  spec = geom.ConvSpec(cin, cout, K, s, p)
+  geoms = geom.bwd_data_geoms(spec, N, H, H, 1, 1)
+  _, wb = ops.weight_prep(w.to(dev()))
+  dyp = ops.pt_from_nchw(dy.to(dev()), 1)
+  dx = torch.zeros((N, H + 2, H + 2, cin), dtype=torch.bfloat16, device=dev())
+  for g in geoms:
+    ops.conv_igemm(g, dyp, wb, dx)
+  torch.cuda.synchronize()
+  got = ops.pt_to_nchw(dx, 1).cpu()
+  scale = ref.abs().max().item()
+  assert (got - ref).abs().max().item() <= 1e-2 * scale
+  if geom.bwd_data_covers_all(spec):
+    # epilogue variants: accumulate, fused ReLU-masked residual gradient
+    rng = np.random.default_rng(3)
+    rg = bf16_round(torch.from_numpy(rng.standard_normal((N, cin, H, H)).astype(np.float32)))
+    ra = bf16_round(torch.from_numpy(rng.standard_normal((N, cin, H, H)).astype(np.float32)))
+    dx2 = torch.zeros_like(dx)
+    for g in geoms:
+      ops.conv_igemm(g, dyp, wb, dx2, res_grad=ops.pt_from_nchw(rg.to(dev()), 1),
+                     res_act=ops.pt_from_nchw(ra.to(dev()), 1))
+    for g in geoms:
+      ops.conv_igemm(g, dyp, wb, dx2, accumulate=True)
+    torch.cuda.synchronize()
+    want = 2 * ref + rg * (ra > 0).float()
+    got2 = ops.pt_to_nchw(dx2, 1).cpu()
+    assert (got2 - want).abs().max().item() <= 2e-2 * want.abs().max().item()
+
+
+@pytest.mark.parametrize("use_tr", [False, True])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_backward_weight(case, use_tr):
+  from iic_amd import geom, ops
+  cin, cout, K, s, p, N, H = case
+  x, w = _conv_inputs(cin, cout, K, N, H, 4)
+  wt = w.clone().requires_grad_(True)
+  y = F.conv2d(x, wt, stride=s, padding=p)
+  dy = bf16_round(torch.from_numpy(np.random.default_rng(5).standard_normal(tuple(y.shape)).astype(np.float32)))
+  y.backward(dy)
+  ref = wt.grad
+  spec = geom.ConvSpec(cin, cout, K, s, p)
+  g = geom.fwd_geom(spec, N, H, H, 1, 1)
+  dW = ops.conv_wgrad(g, ops.pt_from_nchw(x.to(dev()), 1), ops.pt_from_nchw(dy.to(dev()), 1), K * K,
+                      use_tr=use_tr)
+  torch.cuda.synchronize()
+  got = dW.view(cout, cin, K, K).cpu()
+  scale = ref.abs().max().item()
+  assert (got - ref).abs().max().item() <= 2e-3 * scale, (got - ref).abs().max().item() / scale
+
+
+# --------------------------------------------------------------------------------------
+# batch norm streaming kernels
+# --------------------------------------------------------------------------------------
+def test_bn_forward_backward_kernels():
+  from iic_amd import ops
+  N, H, C = 6, 13, 128
+  rng = np.random.default_rng(7)
+  y = bf16_round(torch.from_numpy(rng.standard_normal((N, C, H, H)).astype(np.float32)) * 1.5 + 0.3)
+  y2 = bf16_round(torch.from_numpy(rng.standard_normal((N, C, H, H)).astype(np.float32)))
+  res = bf16_round(torch.from_numpy(rng.standard_normal((N, C, H, H)).astype(np.float32)))
+  gamma = torch.from_numpy((1 + 0.2 * rng.standard_normal(C)).astype(np.float32))
+  beta = torch.from_numpy((0.1 * rng.standard_normal(C)).astype(np.float32))
+  cnt = N * H * H
+  d = dev()
+
+  def stats_of(t):
+    st = ops.new_stats(C, d)
+    st[0, 0] = t.sum((0, 2, 3)).to(d)
+    st[0, 1] = (t * t).sum((0, 2, 3)).to(d)
+    return st
+  rm, rv = torch.zeros(C, device=d), torch.ones(C, device=d)
+  nbt = torch.zeros((), dtype=torch.long, device=d)
+  st = stats_of(y)
+  coef = ops.bn_finalize(st, gamma.to(d), beta.to(d), rm, rv, nbt, C, cnt, True)
+  torch.cuda.synchronize()
+  assert st.abs().max().item() == 0 and nbt.item() == 1
+  mean, var = y.mean((0, 2, 3)), y.var((0, 2, 3), unbiased=False)
+  assert torch.allclose(coef[2].cpu(), mean, atol=1e-5) and torch.allclose(coef[3].cpu(), (var + 1e-5).rsqrt(), rtol=1e-4)
+  assert torch.allclose(rm.cpu(), 0.1 * mean, atol=1e-6)
+  assert torch.allclose(rv.cpu(), 0.9 + 0.1 * y.var((0, 2, 3), unbiased=True), rtol=1e-5)
+  yp, y2p, rp = (ops.pt_from_nchw(t.to(d), 1) for t in (y, y2, res))
+  # relu(bn(y) + res)
+  out = torch.zeros_like(yp)
+  ops.bn_apply(yp, coef, out, N, H, H, 1, C, res=rp, relu=True)
+  ref = F.relu(F.batch_norm(y, None, None, gamma, beta, True, 0.1, 1e-5) + res)
+  assert (ops.pt_to_nchw(out, 1).cpu() - ref).abs().max() <= 2e-2
+  assert out[:, 0].abs().max() == 0 and out[:, :, -1].abs().max() == 0
+  # relu(bn(y) + bn2(y2))
+  coef2 = ops.bn_finalize(stats_of(y2), beta.to(d) + 1.0, gamma.to(d) * 0.1, None, None, None, C, cnt, True)
+  out2 = torch.zeros_like(yp)
+  ops.bn_apply(yp, coef, out2, N, H, H, 1, C, y2=y2p, coef2=coef2, relu=True)
+  ref2 = F.relu(F.batch_norm(y, None, None, gamma, beta, True, 0.1, 1e-5) +
+                F.batch_norm(y2, None, None, beta + 1.0, gamma * 0.1, True, 0.1, 1e-5))
+  assert (ops.pt_to_nchw(out2, 1).cpu() - ref2).abs().max() <= 2e-2
+  # eval mode with running stats
+  coef_e = ops.bn_finalize(None, gamma.to(d), beta.to(d), rm, rv, None, C, cnt, False)
+  oute = torch.zeros_like(yp)
+  ops.bn_apply(yp, coef_e, oute, N, H, H, 1, C, relu=False)
+  refe = F.batch_norm(y, rm.cpu(), rv.cpu(), gamma, beta, False, 0.1, 1e-5)
+  assert (ops.pt_to_nchw(oute, 1).cpu() - refe).abs().max() <= 2e-2
+  # backward of out = relu(bn(y) + res) w.r.t. y, gamma, beta
+  dout = bf16_round(torch.from_numpy(rng.standard_normal((N, C, H, H)).astype(np.float32)))
+  yt = y.clone().requires_grad_(True)
+  gt, bt = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+  o = F.relu(F.batch_norm(yt, None, None, gt, bt, True, 0.1, 1e-5) + res)
+  o.backward(dout)
+  act = ops.pt_from_nchw(bf16_round(o.detach()).to(d), 1)
+  dp = ops.pt_from_nchw(dout.to(d), 1)
+  sums = ops.new_stats(C, d)
+  ops.bn_bwd_reduce(dp, act, yp, sums, N, H, H, 1, C)
+  bcoef, dg, db = ops.bn_bwd_finalize(sums, gamma.to(d), coef, C, cnt)
+  dy = torch.zeros_like(yp)
+  ops.bn_bwd_apply(dp, act, yp, bcoef, dy, N, H, H, 1, C)
+  torch.cuda.synchronize()
+  assert sums.abs().max().item() == 0
+  assert torch.allclose(dg.cpu(), gt.grad, rtol=2e-3, atol=2e-3 * gt.grad.abs().max().item())
+  assert torch.allclose(db.cpu(), bt.grad, rtol=2e-3, atol=2e-3 * bt.grad.abs().max().item())
+  assert (ops.pt_to_nchw(dy, 1).cpu() - yt.grad).abs().max() <= 1e-2 * yt.grad.abs().max()
+
+
+# --------------------------------------------------------------------------------------
+# sobel + stem
+# --------------------------------------------------------------------------------------
+def test_sobel_matches_reference_golden():
+  from iic_amd.transforms import sobel_process
+  g = np.load(os.path.join(G, "nets.npz"))
+  o = sobel_process(torch.from_numpy(g["sobel_in1"]).to(dev()), False)
+  assert np.abs(o.cpu().numpy() - g["sobel_out1"]).max() <= 1e-6
+  o = sobel_process(torch.from_numpy(g["sobel_in4"]).to(dev()), True)
+  assert np.abs(o.cpu().numpy() - g["sobel_out4"]).max() <= 1e-6
+
+
+@pytest.mark.parametrize("cin,S", [(2, 32), (2, 96), (1, 24)])
+def test_stem_forward_backward(cin, S):
+  from iic_amd import ops
+  N = 3
+  rng = np.random.default_rng(11)
+  x = torch.from_numpy(rng.standard_normal((N, cin, S, S)).astype(np.float32))
+  w = torch.from_numpy((rng.standard_normal((64, cin, 3, 3)) * 0.3).astype(np.float32))
+  gamma = torch.from_numpy((1 + 0.2 * rng.standard_normal(64)).astype(np.float32))
+  beta = torch.from_numpy((0.1 * rng.standard_normal(64)).astype(np.float32))
+  wt, gt, bt = (t.clone().requires_grad_(True) for t in (w, gamma, beta))
+  y = F.conv2d(x, wt, padding=1)
+  a = F.relu(F.batch_norm(y, None, None, gt, bt, True, 0.1, 1e-5))
+  pool = F.max_pool2d(a, 2, 2, padding=1)
+  d = dev()
+  xd, wd = x.to(d), w.to(d)
+  st = ops.new_stats(64, d)
+  ops.stem_stats(xd, wd, st)
+  torch.cuda.synchronize()
+  cnt = N * S * S
+  ssum = st.sum(0).cpu()
+  assert torch.allclose(ssum[0] / cnt, y.detach().mean((0, 2, 3)), atol=1e-4)
+  assert torch.allclose(ssum[1] / cnt, (y.detach() ** 2).mean((0, 2, 3)), rtol=1e-4, atol=1e-4)
+  coef = ops.bn_finalize(st, gamma.to(d), beta.to(d), None, None, None, 64, cnt, True)
+  So = S // 2 + 1
+  out = torch.zeros((N, So + 2, So + 2, 64), dtype=torch.bfloat16, device=d)
+  ops.stem_apply_pool(xd, wd, coef, out)
+  torch.cuda.synchronize()
+  got = ops.pt_to_nchw(out, 1).cpu()
+  assert got.shape == pool.shape
+  assert (got - pool.detach()).abs().max() <= 1e-2 * pool.abs().max().item()
+  # backward
+  dpool = bf16_round(torch.from_numpy(rng.standard_normal(tuple(pool.shape)).astype(np.float32)))
+  pool.backward(dpool)
+  dpp = ops.pt_from_nchw(dpool.to(d), 1)
+  sums = ops.new_stats(64, d)
+  ops.stem_bwd_reduce(xd, wd, coef, dpp, sums)
+  bcoef, dg, db = ops.bn_bwd_finalize(sums, gamma.to(d), coef, 64, cnt)
+  dW = ops.stem_bwd_wgrad(xd, wd, coef, bcoef, dpp)
+  torch.cuda.synchronize()
+  assert torch.allclose(db.cpu(), bt.grad, rtol=1e-3, atol=1e-3 * bt.grad.abs().max().item())
+  assert torch.allclose(dg.cpu(), gt.grad, rtol=1e-3, atol=1e-3 * gt.grad.abs().max().item())
+  assert (dW.cpu() - wt.grad).abs().max() <= 2e-3 * wt.grad.abs().max().item()
+
+
+# --------------------------------------------------------------------------------------
+# heads, adam
+# --------------------------------------------------------------------------------------
+def test_heads_forward_backward():
+  from iic_amd import ops
+  from iic_amd.archs.cluster import _AvgPoolFn, _HeadsFn
+  N, F_, H, k = 37, 512, 5, 70
+  rng = np.random.default_rng(13)
+  xin = bf16_round(torch.from_numpy(rng.standard_normal((N, F_, 7, 7)).astype(np.float32)))
+  W = torch.from_numpy((rng.standard_normal((H * k, F_)) * 0.05).astype(np.float32))
+  b = torch.from_numpy((rng.standard_normal(H * k) * 0.1).astype(np.float32))
+  xt, Wt, bt = (t.clone().requires_grad_(True) for t in (xin, W, b))
+  feats = xt.mean((2, 3))
+  probs = F.softmax((feats @ Wt.t() + bt).view(N, H, k), dim=2)
+  gout = torch.from_numpy(rng.standard_normal((N, H, k)).astype(np.float32))
+  (probs * gout).sum().backward()
+  d = dev()
+  xp = ops.pt_from_nchw(xin.to(d), 1).requires_grad_(True)
+  Wd, bd = W.to(d).requires_grad_(True), b.to(d).requires_grad_(True)
+  f = _AvgPoolFn.apply(xp)
+  p = _HeadsFn.apply(f, Wd, bd, H, k)
+  (p * gout.to(d)).sum().backward()
+  torch.cuda.synchronize()
+  assert (p.detach().cpu() - probs.detach()).abs().max() <= 2e-6
+  assert torch.allclose(Wd.grad.cpu(), Wt.grad, rtol=1e-4, atol=1e-6)
+  assert torch.allclose(bd.grad.cpu(), bt.grad, rtol=1e-4, atol=1e-6)
+  gx = ops.pt_to_nchw(xp.grad, 1).cpu()
+  assert (gx - xt.grad).abs().max() <= 1e-2 * xt.grad.abs().max().item()
+
+
+def test_adam_matches_torch():
+  from iic_amd.optim import Adam
+  d = dev()
+  rng = np.random.default_rng(17)
+  shapes = [(64, 2, 3, 3), (64,), (128, 64, 3, 3), (70, 512), (1,)] + [(33,)] * 60
+  ps = [torch.from_numpy(rng.standard_normal(s).astype(np.float32)) for s in shapes]
+  mine = [p.clone().to(d).requires_grad_(True) for p in ps]
+  theirs = [p.clone().to(d).requires_grad_(True) for p in ps]
+  o1, o2 = Adam(mine, lr=1e-2), torch.optim.Adam(theirs, lr=1e-2)
+  for step in range(3):
+    for a, b in zip(mine, theirs):
+      gr = torch.from_numpy(rng.standard_normal(tuple(a.shape)).astype(np.float32)).to(d)
+      a.grad, b.grad = gr.clone(), gr.clone()
+    o1.step()
+    o2.step()
+  torch.cuda.synchronize()
+  for a, b in zip(mine, theirs):
+    assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
