@@ -335,8 +335,8 @@ __global__ __launch_bounds__(512) void stem_bwd_kernel(const float* __restrict__
       red[threadIdx.x * 16 + 8 + i] = sgy[i];
     }
     __syncthreads();
-    if (threadIdx.x < 128) {
-      const int which = threadIdx.x >> 6, ch = threadIdx.x & 63;
+    for (int o = threadIdx.x; o < 128; o += blockDim.x) {   // blockDim may be a single wave
+      const int which = o >> 6, ch = o & 63;
       float t = 0.f;
       for (int th = (ch >> 3); th < (int)blockDim.x; th += 8) t += red[th * 16 + which * 8 + (ch & 7)];
       atomicAdd(outbuf + (long)(blockIdx.x % IIC_STAT_STRIPES) * 2 * STEM_CO + which * STEM_CO + ch, t);
@@ -471,9 +471,18 @@ int iic_stem_bwd_reduce(const float* x, const float* w, const float* coef, const
   long items = (long)N * Ho;
   int grid = (int)(items < STEM_PERSIST_BLOCKS ? items : STEM_PERSIST_BLOCKS);
   const size_t lds = stem_bwd_lds(Cin, W, nseg, 0);
-  STEM_DISPATCH(Cin, hipLaunchKernelGGL((stem_bwd_kernel<CI, 0>), dim3(grid), dim3(64 * nseg), lds,
-                                        (hipStream_t)stream, x, w, coef, (const float*)nullptr,
-                                        (const bf16_t*)dpool_pt, sums, N, H, W));
+  STEM_DISPATCH(Cin, {
+    if (lds > 48 * 1024) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_bwd_kernel<CI, 0>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        (void)hipGetLastError();
+        return IIC_ERR_UNSUPPORTED;
+      }
+    }
+    hipLaunchKernelGGL((stem_bwd_kernel<CI, 0>), dim3(grid), dim3(64 * nseg), lds,
+                       (hipStream_t)stream, x, w, coef, (const float*)nullptr,
+                       (const bf16_t*)dpool_pt, sums, N, H, W);
+  });
   return iic_launch_status();
 }
 
@@ -489,11 +498,14 @@ int iic_stem_bwd_wgrad(const float* x, const float* w, const float* coef, const 
   long items = (long)N * Ho;
   int grid = (int)(items < STEM_PERSIST_BLOCKS ? items : STEM_PERSIST_BLOCKS);
   const size_t lds = stem_bwd_lds(Cin, W, nseg, 1);
-  static bool attr = false;
-  (void)attr;
   STEM_DISPATCH(Cin, {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_bwd_kernel<CI, 1>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (lds > 48 * 1024) {   // static s_cf (1.25 KB) + dynamic must stay <= 160 KB
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_bwd_kernel<CI, 1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        (void)hipGetLastError();
+        return IIC_ERR_UNSUPPORTED;
+      }
+    }
     hipLaunchKernelGGL((stem_bwd_kernel<CI, 1>), dim3(grid), dim3(64 * nseg), lds,
                        (hipStream_t)stream, x, w, coef, bcoef, (const bf16_t*)dpool_pt, partials, N,
                        H, W);

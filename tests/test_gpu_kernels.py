@@ -70,8 +70,12 @@ def test_iid_loss_golden_cases():
     assert abs(loss_nl.item() - ref64[1]) <= _iid_tol(ref64[1]), (ci, loss_nl.item(), ref64[1])
     for t, key in ((a, "dz"), (b, "dzt")):
       gref = g["c%d_%s_f64" % (ci, key)]
-      err = np.linalg.norm(t.grad.cpu().numpy().astype(np.float64) - gref) / max(np.linalg.norm(gref), 1e-30)
-      assert err <= 1e-5, (ci, key, err)
+      nrm = max(np.linalg.norm(gref), 1e-30)
+      err = np.linalg.norm(t.grad.cpu().numpy().astype(np.float64) - gref) / nrm
+      # 1e-5 relative, or -- when MI ~ 0 and the gradient itself is cancellation noise --
+      # at least as accurate as the reference's own fp32 autograd is w.r.t. float64
+      ref32_err = np.linalg.norm(g["c%d_%s_f32" % (ci, key)].astype(np.float64) - gref) / nrm
+      assert err <= max(1e-5, ref32_err), (ci, key, err, ref32_err)
 
 
 def test_iid_loss_packed_heads_full_size_and_no_lamb_grad():
@@ -94,9 +98,17 @@ def test_iid_loss_packed_heads_full_size_and_no_lamb_grad():
     l, lnl, dz, dzt = iid_oracle.iid_loss_np(zs[h], zts[h], 1.5, float(w1[h]), float(w2[h]))
     assert abs(loss[h].item() - l) <= _iid_tol(l)
     assert abs(loss_nl[h].item() - lnl) <= _iid_tol(lnl)
-    for mine, ref in ((Z.grad[:, h].cpu().numpy(), dz), (ZT.grad[:, h].cpu().numpy(), dzt)):
-      if np.linalg.norm(ref) > 0:
-        assert np.linalg.norm(mine - ref) / np.linalg.norm(ref) <= 1e-5
+    # the fp32 reference restatement (torch autograd) on the same inputs: our error w.r.t.
+    # float64 must be <= 1e-5 or no worse than the fp32 reference's own error (MI ~ 0 heads)
+    a32 = torch.from_numpy(zs[h]).requires_grad_(True)
+    b32 = torch.from_numpy(zts[h]).requires_grad_(True)
+    l32, lnl32 = iid_oracle.IID_loss(a32, b32, lamb=1.5)
+    (float(w1[h]) * l32 + float(w2[h]) * lnl32).backward()
+    for mine, ref, r32 in ((Z.grad[:, h].cpu().numpy(), dz, a32.grad.numpy()),
+                           (ZT.grad[:, h].cpu().numpy(), dzt, b32.grad.numpy())):
+      nrm = np.linalg.norm(ref)
+      if nrm > 0:
+        assert np.linalg.norm(mine - ref) / nrm <= max(1e-5, np.linalg.norm(r32 - ref) / nrm)
 
 
 def test_iid_loss_analytic_pins_and_no_grad():

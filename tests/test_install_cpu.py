@@ -1,0 +1,37 @@
+"""install() rebinds the reference's import sites (checked on a miniature fake tree; the
+real scripts need torchvision / datasets that are absent here -- SURVEY.md §8b)."""
+import os
+import sys
+import textwrap
+
+
+def test_install_rebinds_reference_names(tmp_path, monkeypatch):
+  root = tmp_path / "ref"
+  for d in ("code", "code/utils", "code/utils/cluster", "code/archs", "code/archs/cluster"):
+    (root / d).mkdir(parents=True)
+    (root / d / "__init__.py").write_text("")
+  (root / "code/utils/cluster/IID_losses.py").write_text("def IID_loss(*a, **k):\n  return 'ref'\n")
+  (root / "code/utils/cluster/transforms.py").write_text("def sobel_process(*a, **k):\n  return 'ref'\n")
+  (root / "code/archs/__init__.py").write_text("class ClusterNet5g: pass\nclass ClusterNet5gTwoHead: pass\n")
+  (root / "code/archs/cluster/__init__.py").write_text("class ClusterNet5g: pass\nclass ClusterNet5gTwoHead: pass\n")
+  monkeypatch.syspath_prepend(str(root))
+  for k in [k for k in sys.modules if k == "code" or k.startswith("code.")]:
+    monkeypatch.delitem(sys.modules, k)
+  from iic_amd import archs, install, losses, transforms
+  install.py2_shims()
+  done = install.install(strict=True)
+  assert len(done) == len(install.PATCHES)
+  script = textwrap.dedent("""
+    from code.utils.cluster.IID_losses import IID_loss
+    from code.utils.cluster.transforms import sobel_process
+    import code.archs as archs
+    net_cls = archs.__dict__["ClusterNet5g"]
+  """)
+  ns = {}
+  exec(script, ns)
+  assert ns["IID_loss"] is losses.IID_loss
+  assert ns["sobel_process"] is transforms.sobel_process
+  assert ns["net_cls"] is archs.ClusterNet5g
+  assert xrange is range  # noqa: F821
+  for k in [k for k in sys.modules if k == "code" or k.startswith("code.")]:
+    del sys.modules[k]
