@@ -28,6 +28,7 @@ from .. import ops
 
 __all__ = ["ClusterNet5g", "ClusterNet5gTwoHead"]
 
+SHARD_INPUTS = [False]  # set by iic_amd.run under torchrun: forward keeps only this rank's rows
 _WEIGHTS_EPOCH = [0]   # bumped by iic_amd.optim.Adam (raw-pointer updates do not bump _version)
 
 
@@ -380,6 +381,10 @@ class ClusterNet5gTrunk(nn.Module):
     return nn.Sequential(*layers)
 
   def forward(self, x, penultimate_features=False):
+    if SHARD_INPUTS[0]:
+      from .. import dist as idist
+      lo, hi = idist.shard_rows(x.size(0))
+      x = x[lo:hi]
     x = _StemFn.apply(x, self.conv1.weight, self.bn1.weight, self.bn1.bias, self)
     x = self.layer1(x)
     x = self.layer2(x)

@@ -18,7 +18,17 @@ def main():
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     dist.init_process_group("nccl")
     from . import dist as idist
+    from .archs import cluster as _cl
     idist.enable()
+    # every rank's data loaders produce the full batch (the scripts are unchanged): keep this
+    # rank's contiguous rows (pairs stay together: both views are sliced identically) ...
+    _cl.SHARD_INPUTS[0] = True
+    # ... and SUM-all-reduce the parameter gradients right before any optimiser step.
+    from torch.optim.optimizer import register_optimizer_step_pre_hook
+
+    def _allreduce_hook(opt, args, kwargs):
+      idist.all_reduce_grads([p for g in opt.param_groups for p in g["params"]])
+    register_optimizer_step_pre_hook(_allreduce_hook)
   install()
   target = sys.argv[1]
   sys.argv = sys.argv[1:]
