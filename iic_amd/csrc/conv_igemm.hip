@@ -17,65 +17,63 @@
 //   ("patch", 128 B per pixel) and every tap reads it at a shifted pixel index -- so L2
 //   sees each input byte ~span/128 times instead of ntaps times;
 //   the [BN][64] weight slice of each (tap, chunk) is double-buffered in LDS.
-// LDS rows are 128 B; 16-B chunks are XOR-swizzled with (row>>1)&7 so that the 16-lane
-// groups of ds_read_b128 hit 16 distinct 16-B slots (conflict-free for unit-stride rows).
+// LDS rows are 128 B of data at a 144-B pitch (see ROWB): conflict-free ds_read_b128 and
+// immediate-offset k-steps.  1-tap convs (1x1 stride-2 downsample) skip the patch and gather
+// the 128 rows' own pixels.
 #include "common.h"
 #include "../../include/iic_hip.h"
 
 #define BM 128
 #define NTHREADS 256
+#define ROWB 144   // LDS row pitch in bytes: 128 B of data + 16 B pad.  144*r mod 256 visits all
+                   // sixteen 16-B slots over 16 consecutive rows => the 16-lane groups of
+                   // ds_read_b128 are conflict-free, and every k-step is an IMMEDIATE offset
+                   // (ks*32 B) from one per-tap row address: no address VALU in the MFMA loop.
 
-__device__ __forceinline__ int swz(int row, int chunk) { return row * 8 + (chunk ^ ((row >> 1) & 7)); }
-
-template <int BPASS>
-__device__ __forceinline__ void igemm_load_b(u32x4 (&breg)[BPASS], const iic_conv_geom& g,
-                                             const bf16_t* __restrict__ w, int n0, int it, int tid) {
-  const int chunk = it / g.ntaps, tap = it - chunk * g.ntaps;
-  const bf16_t* wt = w + ((long)g.tap_w[tap] * g.Cout + n0) * g.Cin + chunk * 64;
+// Stage the input patch (NP pixels x 64 channels) or, in gather mode (1-tap convs), the 128
+// rows' own pixels.  4 independent 16-B loads in flight per thread.
+template <bool GATHER>
+__device__ __forceinline__ void igemm_load_patch(unsigned char* sA, const bf16_t* __restrict__ in,
+                                                 int Cin, int c0, int p_lo, int npix,
+                                                 int in_pixels, const int* s_pin, int tid) {
+  const int n8 = npix * 8;
+  for (int base = 0; base < n8; base += NTHREADS * 4) {
+    u32x4 v[4];
 #pragma unroll
-  for (int u = 0; u < BPASS; ++u) {
-    const int idx = u * NTHREADS + tid;
-    breg[u] = *reinterpret_cast<const u32x4*>(wt + (long)(idx >> 3) * g.Cin + (idx & 7) * 8);
-  }
-}
-template <int BPASS>
-__device__ __forceinline__ void igemm_store_b(const u32x4 (&breg)[BPASS], u32x4* dst, int tid) {
+    for (int u = 0; u < 4; ++u) {
+      const int idx = base + u * NTHREADS + tid;
+      v[u] = (u32x4){0u, 0u, 0u, 0u};
+      if (idx < n8) {
+        const long p = GATHER ? (long)s_pin[idx >> 3] : (long)p_lo + (idx >> 3);
+        if (p < in_pixels) v[u] = *reinterpret_cast<const u32x4*>(in + (p * Cin + c0 + (idx & 7) * 8));
+      }
+    }
 #pragma unroll
-  for (int u = 0; u < BPASS; ++u) {
-    const int idx = u * NTHREADS + tid;
-    dst[swz(idx >> 3, idx & 7)] = breg[u];
-  }
-}
-__device__ __forceinline__ void igemm_load_patch(uint4* sA, const bf16_t* __restrict__ in, int Cin,
-                                                 int c0, int p_lo, int np8, long in_pixels, int tid) {
-  for (int base = 0; base < np8; base += NTHREADS * 4) {
-    uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0, v2 = v0, v3 = v0;
-    const int i0 = base + tid, i1 = i0 + NTHREADS, i2 = i1 + NTHREADS, i3 = i2 + NTHREADS;
-    const long q0 = (long)p_lo + (i0 >> 3), q1 = (long)p_lo + (i1 >> 3);
-    const long q2 = (long)p_lo + (i2 >> 3), q3 = (long)p_lo + (i3 >> 3);
-    if (i0 < np8 && q0 < in_pixels) v0 = *reinterpret_cast<const uint4*>(in + (q0 * Cin + c0 + (i0 & 7) * 8));
-    if (i1 < np8 && q1 < in_pixels) v1 = *reinterpret_cast<const uint4*>(in + (q1 * Cin + c0 + (i1 & 7) * 8));
-    if (i2 < np8 && q2 < in_pixels) v2 = *reinterpret_cast<const uint4*>(in + (q2 * Cin + c0 + (i2 & 7) * 8));
-    if (i3 < np8 && q3 < in_pixels) v3 = *reinterpret_cast<const uint4*>(in + (q3 * Cin + c0 + (i3 & 7) * 8));
-    if (i0 < np8) sA[swz(i0 >> 3, i0 & 7)] = v0;
-    if (i1 < np8) sA[swz(i1 >> 3, i1 & 7)] = v1;
-    if (i2 < np8) sA[swz(i2 >> 3, i2 & 7)] = v2;
-    if (i3 < np8) sA[swz(i3 >> 3, i3 & 7)] = v3;
+    for (int u = 0; u < 4; ++u) {
+      const int idx = base + u * NTHREADS + tid;
+      if (idx < n8) *reinterpret_cast<u32x4*>(sA + (idx >> 3) * ROWB + (idx & 7) * 16) = v[u];
+    }
   }
 }
 
-template <int BN>
+
+template <int BN, bool GATHER, bool ABL>
 __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(
     const iic_conv_geom g, const bf16_t* __restrict__ in, const bf16_t* __restrict__ w,
     bf16_t* __restrict__ out, float* __restrict__ stats, const bf16_t* __restrict__ res_grad,
-    const bf16_t* __restrict__ res_act, int accumulate, int num_mtiles, int lds_a_bytes) {
-  constexpr int NS = BN / 64;          // 32-wide N sub-tiles per wave
-  constexpr int BPASS = BN * 8 / NTHREADS;  // uint4 per thread per weight tile
-  constexpr int CLD = BN + 8;          // epilogue tile row stride (bf16 elements)
+    const bf16_t* __restrict__ res_act, int accumulate, int num_mtiles, int lds_a_bytes,
+    int ablate_arg) {
+  const int ablate = ABL ? ablate_arg : 0;
+  constexpr int NS = BN / 64;               // 32-wide N sub-tiles per wave
+  constexpr int BPASS = BN * 8 / NTHREADS;  // 16-B pieces per thread per weight tile
+  constexpr int CLD = BN + 8;               // epilogue tile row stride (bf16 elements)
+  // 16-B patch pieces per thread prefetched in registers across a chunk (0 = reload in place;
+  // the BN = 64 convs of this network have a single 64-channel chunk or small patches)
+  constexpr int PATCH_PF_MAX = (BN == 128) ? 8 : 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  uint4* sA = reinterpret_cast<uint4*>(smem_raw);
-  uint4* sB = reinterpret_cast<uint4*>(smem_raw + lds_a_bytes);
-  int* s_pin = reinterpret_cast<int*>(sB + 2 * BN * 8);
+  unsigned char* sA = smem_raw;                          // [NP][ROWB]
+  unsigned char* sB = smem_raw + lds_a_bytes;            // [2][BN][ROWB]
+  int* s_pin = reinterpret_cast<int*>(sB + 2 * BN * ROWB);
   int* s_pout = s_pin + BM;
   float* s_red = reinterpret_cast<float*>(s_pout + BM);   // [2(wm)][2][BN]
   bf16_t* sC = reinterpret_cast<bf16_t*>(smem_raw);        // epilogue reuse of sA
@@ -94,29 +92,40 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(
     const int b = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = b & 7, idx = b >> 3;
     tix = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int mtile = tix / nt, ntile = tix % nt;
+  const int mtile = tix / nt, ntile = tix - mtile * nt;
   const int n0 = ntile * BN;
-  const long M = (long)g.N * g.MY * g.MX;
-  const long m0 = (long)mtile * BM;
-  const long in_pixels = (long)g.N * g.in_Hp * g.in_Wp;
+  const int M = g.N * g.MY * g.MX;          // < 2^31 (checked on the host)
+  const int m0 = mtile * BM;
+  const int in_pixels = g.N * g.in_Hp * g.in_Wp;
+
+  // tap tables live in VGPRs (lane t holds tap t) and are broadcast with v_readlane: the
+  // main loop has no scalar-memory load on its critical path.
+  const int v_tapoff = g.tap_off[lane & (IIC_MAX_TAPS - 1)];
+  const int v_tapw = g.tap_w[lane & (IIC_MAX_TAPS - 1)];
 
   // ---- per-row pixel indices --------------------------------------------------------
   if (tid < BM) {
-    long m = m0 + tid;
+    int m = m0 + tid;
     const bool valid = m < M;
     if (!valid) m = M - 1;
     const int plane = g.MY * g.MX;
-    const int n = (int)(m / plane);
-    const int r = (int)(m - (long)n * plane);
+    const int n = m / plane;
+    const int r = m - n * plane;
     const int y = r / g.MX, x = r - y * g.MX;
     s_pin[tid] = (n * g.in_Hp + y * g.sy + g.oy) * g.in_Wp + x * g.sx + g.ox;
     s_pout[tid] = valid ? (n * g.out_Hp + y * g.ty + g.py) * g.out_Wp + x * g.tx + g.px : -1;
   }
   __syncthreads();
   const int p_lo = s_pin[0];
-  int lp[2];
+  const int npix = GATHER ? BM : g.NP;
+  // byte address (within sA) of this lane's A rows at tap offset 0, k-chunk g5
+  int arow[2];
 #pragma unroll
-  for (int ms = 0; ms < 2; ++ms) lp[ms] = s_pin[wm * 64 + ms * 32 + l31] - p_lo;
+  for (int ms = 0; ms < 2; ++ms) {
+    const int row = wm * 64 + ms * 32 + l31;
+    arow[ms] = (GATHER ? row : (s_pin[row] - p_lo)) * ROWB + g5 * 16;
+  }
+  const int brow = (wn * (BN / 2) + l31) * ROWB + g5 * 16;   // within one weight buffer
 
   f32x16 acc[2][NS];
 #pragma unroll
@@ -127,50 +136,123 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(
       for (int r = 0; r < 16; ++r) acc[ms][ns][r] = 0.f;
 
   const int nchunks = g.Cin >> 6;
-  const int NIT = nchunks * g.ntaps;
-  const int np8 = g.NP * 8;
+  const int ntaps = g.ntaps;
+  const int NIT = nchunks * ntaps;
+  // per-thread weight-tile pieces: row co = tid>>3 (+32 per pass), 16-B piece tid&7
+  const int wrow = tid >> 3, wpc = tid & 7;
+  const bf16_t* wbase = w + ((long)n0 + wrow) * g.Cin + wpc * 8;
+  const long wtap_stride = (long)g.Cout * g.Cin;
+  const long wrow32 = 32L * g.Cin;
+  unsigned char* const sBw = sB + wrow * ROWB + wpc * 16;   // this thread's store slot, pass 0
+
+  // weight tile of flat iteration (tap, chunk) -> registers
+  auto bload = [&](u32x4(&R)[BPASS], int tap, int chunk) {
+    const int tw = __builtin_amdgcn_readlane(v_tapw, tap);
+    const bf16_t* wt = wbase + (long)tw * wtap_stride + chunk * 64;
+#pragma unroll
+    for (int u = 0; u < BPASS; ++u) R[u] = *reinterpret_cast<const u32x4*>(wt + u * wrow32);
+  };
+  auto bstore = [&](const u32x4(&R)[BPASS], int b) {
+    unsigned char* dst = sBw + b * (BN * ROWB);
+#pragma unroll
+    for (int u = 0; u < BPASS; ++u) *reinterpret_cast<u32x4*>(dst + u * 32 * ROWB) = R[u];
+  };
+  // patch of the NEXT chunk held in registers while the current chunk computes
+  const int n8 = npix * 8;
+  const bool patch_pf = (BN == 128) && (n8 <= PATCH_PF_MAX * NTHREADS);
+  u32x4 P[PATCH_PF_MAX];
+  auto pload = [&](int c0) {
+#pragma unroll
+    for (int u = 0; u < PATCH_PF_MAX; ++u) {
+      const int idx = u * NTHREADS + tid;
+      P[u] = (u32x4){0u, 0u, 0u, 0u};
+      if (idx < n8) {
+        const int p = GATHER ? s_pin[idx >> 3] : p_lo + (idx >> 3);
+        if (p < in_pixels)
+          P[u] = *reinterpret_cast<const u32x4*>(in + ((long)p * g.Cin + c0 + (idx & 7) * 8));
+      }
+    }
+  };
+  auto pstore = [&]() {
+#pragma unroll
+    for (int u = 0; u < PATCH_PF_MAX; ++u) {
+      const int idx = u * NTHREADS + tid;
+      if (idx < n8) *reinterpret_cast<u32x4*>(sA + (idx >> 3) * ROWB + (idx & 7) * 16) = P[u];
+    }
+  };
 
   // ---- prologue ------------------------------------------------------------------------
-  u32x4 breg[BPASS];
-  igemm_load_patch(sA, in, g.Cin, 0, p_lo, np8, in_pixels, tid);
-  igemm_load_b<BPASS>(breg, g, w, n0, 0, tid);
-  igemm_store_b<BPASS>(breg, reinterpret_cast<u32x4*>(sB), tid);
+  u32x4 R0[BPASS], R1[BPASS];
+  int tap2 = 0, chunk2 = 0;                    // (tap, chunk) of flat iteration it + 2
+  auto advance = [&](int& t, int& c) { if (++t == ntaps) { t = 0; ++c; } };
+  if (!(ablate & 16))
+    igemm_load_patch<GATHER>(sA, in, g.Cin, 0, p_lo, npix, in_pixels, s_pin, tid);
+  bload(R0, 0, 0);
+  bstore(R0, 0);
+  advance(tap2, chunk2);
+  if (NIT > 1) bload(R1, tap2, chunk2);        // B(1) in flight
+  advance(tap2, chunk2);
   __syncthreads();
 
-  // ---- main loop over (chunk, tap) -------------------------------------------------------
-  for (int it = 0; it < NIT; ++it) {
-    const int chunk = it / g.ntaps, tap = it - chunk * g.ntaps;
-    const bool has_next = it + 1 < NIT;
-    if (has_next) igemm_load_b<BPASS>(breg, g, w, n0, it + 1, tid);   // in flight during the MFMAs below
-    const int toff = g.tap_off[tap];
-    const uint4* bB = sB + (it & 1) * BN * 8;
-    const int pa0 = lp[0] + toff, pa1 = lp[1] + toff;
+  // ---- main loop: flat (chunk, tap) iterations, weight tiles prefetched TWO ahead ----------
+  int tap = 0, chunk = 0;
+  auto body = [&](u32x4(&Rnext)[BPASS], u32x4(&Rfree)[BPASS], int it, int buf) {
+    // Rnext holds B(it+1) (loaded one iteration ago); Rfree is loaded with B(it+2) now.
+    const bool last_tap = (tap + 1 == ntaps);
+    if (it + 2 < NIT && !(ablate & 2)) bload(Rfree, tap2, chunk2);
+    if (tap == 0 && chunk + 1 < nchunks && patch_pf && !(ablate & 16)) pload((chunk + 1) * 64);
+    const int toffb = GATHER ? 0 : __builtin_amdgcn_readlane(v_tapoff, tap) * ROWB;
+    const unsigned char* pa0 = sA + arow[0] + toffb;
+    const unsigned char* pa1 = sA + arow[1] + toffb;
+    const unsigned char* pb = sB + buf * (BN * ROWB) + brow;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const int ch = 2 * ks + g5;
       bf16x8 a[2], b[NS];
-      a[0] = __builtin_bit_cast(bf16x8, sA[swz(pa0, ch)]);
-      a[1] = __builtin_bit_cast(bf16x8, sA[swz(pa1, ch)]);
-#pragma unroll
-      for (int ns = 0; ns < NS; ++ns)
-        b[ns] = __builtin_bit_cast(bf16x8, bB[swz(wn * (BN / 2) + ns * 32 + l31, ch)]);
-#pragma unroll
-      for (int ms = 0; ms < 2; ++ms)
+      if (!(ablate & 8)) {
+        a[0] = *reinterpret_cast<const bf16x8*>(pa0 + ks * 32);
+        a[1] = *reinterpret_cast<const bf16x8*>(pa1 + ks * 32);
 #pragma unroll
         for (int ns = 0; ns < NS; ++ns)
-          acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ms], b[ns], acc[ms][ns], 0, 0, 0);
-    }
-    if (has_next) {
-      if (tap + 1 == g.ntaps) {        // next iteration starts a new channel chunk
-        __syncthreads();               // everyone is done reading the patch
-        igemm_load_patch(sA, in, g.Cin, (chunk + 1) * 64, p_lo, np8, in_pixels, tid);
+          b[ns] = *reinterpret_cast<const bf16x8*>(pb + ns * 32 * ROWB + ks * 32);
+      } else {
+        a[0] = a[1] = __builtin_bit_cast(bf16x8, Rnext[0]);
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) b[ns] = __builtin_bit_cast(bf16x8, Rnext[0]);
       }
-      igemm_store_b<BPASS>(breg, reinterpret_cast<u32x4*>(sB + ((it + 1) & 1) * BN * 8), tid);
-      __syncthreads();
+      if (!(ablate & 1)) {
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+          for (int ns = 0; ns < NS; ++ns)
+            acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ms], b[ns], acc[ms][ns], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms) asm volatile("" ::"v"(a[ms]));
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) asm volatile("" ::"v"(b[ns]));
+      }
     }
+    if (it + 1 < NIT) {
+      if (last_tap) {                        // next iteration starts a new channel chunk
+        if (!(ablate & 4)) __syncthreads();  // everyone is done reading the patch
+        if (!(ablate & 16)) {
+          if (patch_pf) pstore();
+          else igemm_load_patch<GATHER>(sA, in, g.Cin, (chunk + 1) * 64, p_lo, npix, in_pixels, s_pin, tid);
+        }
+      }
+      if (!(ablate & 2)) bstore(Rnext, buf ^ 1);
+      if (!(ablate & 4)) __syncthreads();
+    }
+    advance(tap, chunk);
+    advance(tap2, chunk2);
+  };
+  for (int it = 0; it < NIT; it += 2) {
+    body(R1, R0, it, 0);
+    if (it + 1 < NIT) body(R0, R1, it + 1, 1);
   }
 
   // ---- epilogue ------------------------------------------------------------------------
+  if (ABL && (ablate & 32)) return;
   const bool tail = (m0 + BM > M);
   if (stats) {
 #pragma unroll
@@ -266,10 +348,15 @@ __global__ void weight_prep_kernel(const float* __restrict__ w, bf16_t* __restri
   }
 }
 
+static int g_ablate = 0;
+extern "C" void iic_debug_set_ablate(int v) { g_ablate = v; }
+
 static int pick_bn(int Cout) { return (Cout % 128 == 0) ? 128 : 64; }
 
+static int geom_gather(const iic_conv_geom* g) { return g->ntaps == 1; }
+
 static long lds_a_bytes_for(const iic_conv_geom* g, int BN) {
-  long a = (long)g->NP * 128;
+  long a = (long)(geom_gather(g) ? BM : g->NP) * ROWB;
   long c = (long)BM * (BN + 8) * 2;
   long m = a > c ? a : c;
   return (m + 15) & ~15L;
@@ -279,7 +366,7 @@ extern "C" {
 
 long iic_conv_lds_bytes(const iic_conv_geom* g, int BN) {
   if (BN == 0) BN = pick_bn(g->Cout);
-  return lds_a_bytes_for(g, BN) + 2L * BN * 128 + 2L * BM * 4 + 4L * BN * 4;
+  return lds_a_bytes_for(g, BN) + 2L * BN * ROWB + 2L * BM * 4 + 4L * BN * 4;
 }
 
 int iic_conv_igemm(const iic_conv_geom* g, const void* in, const void* w, void* out, float* stats,
@@ -291,32 +378,36 @@ int iic_conv_igemm(const iic_conv_geom* g, const void* in, const void* w, void* 
   const int BN = pick_bn(g->Cout);
   const long M = (long)g->N * g->MY * g->MX;
   if (M <= 0 || g->NP <= 0) return IIC_ERR_ARG;
+  if (M >= (1L << 31) || (long)g->N * g->in_Hp * g->in_Wp >= (1L << 31)) return IIC_ERR_UNSUPPORTED;
   const int mt = (int)((M + BM - 1) / BM);
   const int grid = mt * (g->Cout / BN);
   const long lds = iic_conv_lds_bytes(g, BN);
   if (lds > 160 * 1024) return IIC_ERR_UNSUPPORTED;
   const int la = (int)lds_a_bytes_for(g, BN);
   hipStream_t s = (hipStream_t)stream;
+#define IGEMM_LAUNCH2(BN_, GA_, AB_)                                                              \
+  do {                                                                                           \
+    static bool attr = false;                                                                    \
+    if (!attr) {                                                                                 \
+      (void)hipFuncSetAttribute(                                                                 \
+          reinterpret_cast<const void*>(&conv_igemm_kernel<BN_, GA_, AB_>),                      \
+          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                               \
+      attr = true;                                                                               \
+    }                                                                                            \
+    hipLaunchKernelGGL((conv_igemm_kernel<BN_, GA_, AB_>), dim3(grid), dim3(NTHREADS), lds, s,   \
+                       *g, (const bf16_t*)in, (const bf16_t*)w, (bf16_t*)out, stats,             \
+                       (const bf16_t*)res_grad, (const bf16_t*)res_act, accumulate, mt, la,      \
+                       g_ablate);                                                                \
+  } while (0)
+#define IGEMM_LAUNCH(BN_, GA_)                                                                   \
+  do {                                                                                           \
+    if (g_ablate) IGEMM_LAUNCH2(BN_, GA_, true); else IGEMM_LAUNCH2(BN_, GA_, false);            \
+  } while (0)
+  const bool ga = geom_gather(g);
   if (BN == 128) {
-    static bool attr = false;
-    if (!attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<128>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr = true;
-    }
-    hipLaunchKernelGGL(conv_igemm_kernel<128>, dim3(grid), dim3(NTHREADS), lds, s, *g,
-                       (const bf16_t*)in, (const bf16_t*)w, (bf16_t*)out, stats,
-                       (const bf16_t*)res_grad, (const bf16_t*)res_act, accumulate, mt, la);
+    if (ga) IGEMM_LAUNCH(128, true); else IGEMM_LAUNCH(128, false);
   } else {
-    static bool attr = false;
-    if (!attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<64>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr = true;
-    }
-    hipLaunchKernelGGL(conv_igemm_kernel<64>, dim3(grid), dim3(NTHREADS), lds, s, *g,
-                       (const bf16_t*)in, (const bf16_t*)w, (bf16_t*)out, stats,
-                       (const bf16_t*)res_grad, (const bf16_t*)res_act, accumulate, mt, la);
+    if (ga) IGEMM_LAUNCH(64, true); else IGEMM_LAUNCH(64, false);
   }
   return iic_launch_status();
 }

@@ -1,0 +1,80 @@
+"""Per-layer timing of the conv kernels at the north-star shapes (660 images per pass).
+python tools/conv_perf.py [--n 660] [--iters 20] -> table of us and TFLOP/s per geometry."""
+import argparse
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from iic_amd import geom, ops
+
+LAYERS = [  # name, cin, cout, K, stride, pad, H
+  ("l1 3x3 64->64 @49", 64, 64, 3, 1, 1, 49),
+  ("l2.0 3x3s2 64->128 @49", 64, 128, 3, 2, 1, 49),
+  ("l2.0 1x1s2 64->128 @49", 64, 128, 1, 2, 0, 49),
+  ("l2 3x3 128->128 @25", 128, 128, 3, 1, 1, 25),
+  ("l3.0 3x3s2 128->256 @25", 128, 256, 3, 2, 1, 25),
+  ("l3.0 1x1s2 128->256 @25", 128, 256, 1, 2, 0, 25),
+  ("l3 3x3 256->256 @13", 256, 256, 3, 1, 1, 13),
+  ("l4.0 3x3s2 256->512 @13", 256, 512, 3, 2, 1, 13),
+  ("l4.0 1x1s2 256->512 @13", 256, 512, 1, 2, 0, 13),
+  ("l4 3x3 512->512 @7", 512, 512, 3, 1, 1, 7),
+]
+COUNT = {0: 6, 1: 1, 2: 1, 3: 7, 4: 1, 5: 1, 6: 11, 7: 1, 8: 1, 9: 5}
+
+
+def timeit(fn, iters):
+  for _ in range(3):
+    fn()
+  torch.cuda.synchronize()
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  e0.record()
+  for _ in range(iters):
+    fn()
+  e1.record()
+  torch.cuda.synchronize()
+  return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--n", type=int, default=660)
+  ap.add_argument("--iters", type=int, default=20)
+  ap.add_argument("--only", type=str, default="")
+  ap.add_argument("--ablate", type=int, default=0)
+  a = ap.parse_args()
+  dev = torch.device("cuda:0")
+  N = a.n
+  if a.ablate:
+    import ctypes
+    from iic_amd import _lib
+    ctypes.CDLL(_lib.LIB_PATH).iic_debug_set_ablate(a.ablate)
+    print('ABLATE', a.ablate)
+  tot = {"fwd": 0.0, "bwd": 0.0, "wg": 0.0}
+  print("%-28s %9s %8s | %9s %8s | %9s %8s | NP" % ("layer", "fwd us", "TF/s", "bwdD us", "TF/s", "wgrad us", "TF/s"))
+  for li, (name, cin, cout, K, s, p, H) in enumerate(LAYERS):
+    if a.only and a.only not in name:
+      continue
+    spec = geom.ConvSpec(cin, cout, K, s, p)
+    Ho = spec.out_size(H)
+    gf = geom.fwd_geom(spec, N, H, H, 1, 1)
+    gb = geom.bwd_data_geoms(spec, N, H, H, 1, 1)
+    x = torch.randn(N, H + 2, H + 2, cin, device=dev).to(torch.bfloat16)
+    dy = torch.randn(N, Ho + 2, Ho + 2, cout, device=dev).to(torch.bfloat16)
+    y = torch.zeros(N, Ho + 2, Ho + 2, cout, device=dev, dtype=torch.bfloat16)
+    dx = torch.zeros(N, H + 2, H + 2, cin, device=dev, dtype=torch.bfloat16)
+    w = torch.randn(cout, cin, K, K, device=dev) * 0.05
+    wf, wb = ops.weight_prep(w)
+    st = ops.new_stats(cout, dev)
+    flops = 2.0 * N * Ho * Ho * cout * cin * K * K
+    t_f = timeit(lambda: ops.conv_igemm(gf, x, wf, y, stats=st), a.iters)
+    t_b = timeit(lambda: [ops.conv_igemm(g, dy, wb, dx) for g in gb], a.iters)
+    t_w = timeit(lambda: ops.conv_wgrad(gf, x, dy, K * K, True), a.iters)
+    c = COUNT[li]
+    tot["fwd"] += c * t_f; tot["bwd"] += c * t_b; tot["wg"] += c * t_w
+    print("%-28s %9.1f %8.1f | %9.1f %8.1f | %9.1f %8.1f | %d" % (
+      name, t_f, flops / t_f / 1e6, t_b, flops / t_b / 1e6, t_w, flops / t_w / 1e6, gf.NP))
+  print("per pass (x count): fwd %.2f ms, bwd-data %.2f ms, wgrad(+reduce) %.2f ms; x2 passes = %.2f ms/step" % (
+    tot["fwd"] / 1e3, tot["bwd"] / 1e3, tot["wg"] / 1e3, 2 * sum(tot.values()) / 1e3))
+
+
+if __name__ == "__main__":
+  main()
