@@ -23,152 +23,263 @@
 #include "common.h"
 #include "../../include/iic_hip.h"
 
-#define BM 128
-#define NTHREADS 256
-#define NTP 9   // taps per pass
-
-__device__ __forceinline__ int swz(int row, int chunk) { return row * 8 + (chunk ^ ((row >> 1) & 7)); }
+#define BM 128      // K-tile: 128 output pixels
+#define ROWB 144    // LDS row pitch of the input patch: 128 B of data + 16 B pad
+#define TPG 3       // taps per wave (tap group)
+#define NTG 3       // tap groups per pass => 9 taps per pass
+#define PFX 4       // patch 16-B pieces per thread prefetched in registers (NP <= 384 at 768 threads)
 
 typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
 
+// MFMA operand fragment for lane (i = lane&31, g = lane>>5): the 8 values
+//   tile[row_j][col], j = 0..7, rows = the 8 k-slots 8g..8g+7 of this k-step.
+// USE_TR: two ds_read_b64_tr_b16; lane (q = lane>>4, i16 = lane&15) supplies the address of
+// row 8*(q>>1) + 4*rd + (i16>>2), 8-byte segment (i16&3) of the 16-column block (q&1);
+// a0/a1 are that lane's two row byte-addresses (column offset included).
+// !USE_TR (semantic cross-check of the transpose-load model): 8 scalar LDS reads.
+typedef uint16_t __attribute__((address_space(3))) * lds_u16_ptr;
+// a0/a1/tile are 32-bit LDS byte addresses (keeps all address arithmetic in one VGPR each).
 template <bool USE_TR>
-__device__ __forceinline__ bf16x8 read_frag_T(const unsigned char* tile, const int* s_pin, int p_lo,
-                                              bool via_lp, int toff, int ks, int colhalf, int lane) {
-  // Returns, for MFMA lane (i = lane&31, g = lane>>5), the 8 values
-  //   tile[row(ks*16 + 8g + j)][colhalf*32 + i],  j = 0..7
-  // where row(k) = k (via_lp == false) or s_pin[k] - p_lo + toff (input patch).
+__device__ __forceinline__ bf16x8 frag_T(uint32_t a0, uint32_t a1, uint32_t tile, int pitch,
+                                         const int* rows8, int col) {
   union { bf16x8 v; s16x4 h[2]; uint16_t e[8]; } u;
   if (USE_TR) {
-    const int q = lane >> 4, i16 = lane & 15;
-#pragma unroll
-    for (int rd = 0; rd < 2; ++rd) {
-      const int k = ks * 16 + 8 * (q >> 1) + 4 * rd + (i16 >> 2);
-      const int row = via_lp ? (s_pin[k] - p_lo + toff) : k;
-      const int chunk = colhalf * 4 + 2 * (q & 1) + ((i16 & 3) >> 1);
-      const unsigned char* a = tile + swz(row, chunk) * 16 + (i16 & 1) * 8;
-      u.h[rd] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)a);
-    }
+    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(uintptr_t)a0);
+    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(uintptr_t)a1);
   } else {
-    const int i = lane & 31, g5 = lane >> 5;
-    const int col = colhalf * 32 + i;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int k = ks * 16 + 8 * g5 + j;
-      const int row = via_lp ? (s_pin[k] - p_lo + toff) : k;
-      u.e[j] = reinterpret_cast<const uint16_t*>(tile)[swz(row, col >> 3) * 8 + (col & 7)];
-    }
+    for (int j = 0; j < 8; ++j)
+      u.e[j] = *(lds_u16_ptr)(uintptr_t)(tile + rows8[j] * pitch + col * 2);
   }
   return u.v;
 }
 
-template <bool USE_TR>
-__global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_kernel(
+// Workgroup = COT (64|128) output channels x 64 input channels x all taps.
+//   non-gather: 12 waves = 2 (co halves) x 2 (ci halves) x 3 tap groups; a wave owns
+//               (COT/2) co x 32 ci x 3 taps  (48 or 96 fp32 accumulators)
+//   gather (1-tap convs): 4 waves, one tap.
+// K-tiles (128 pixels) are software-pipelined: the next tile's input patch and dY rows are
+// fetched into registers while the current tile is multiplied, then stored to LDS.
+template <bool USE_TR, bool GATHER, int COT>
+__global__ __launch_bounds__(GATHER ? 256 : 768) void conv_wgrad_kernel(
     const iic_conv_geom g, const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
     float* __restrict__ partials, int nsplit, int num_ktiles, int lds_x_bytes) {
+  constexpr int NT = GATHER ? 256 : 768;
+  constexpr int CS = COT / 64;                 // 32-wide co sub-tiles per wave
+  constexpr int DPITCH = COT == 64 ? 144 : 288;  // dY tile row pitch (bytes)
+  constexpr int DPIECES = BM * (COT / 8);      // 16-B pieces of the dY tile
+  constexpr int PDN = (DPIECES + NT - 1) / NT;
+  constexpr int MYT = GATHER ? 1 : TPG;        // taps per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  unsigned char* sX = smem_raw;                    // [NP][128 B]   input patch, this WG's 64 ci
-  unsigned char* sD = smem_raw + lds_x_bytes;      // [BM][128 B]   dY rows, this WG's 64 co
-  int* s_pin = reinterpret_cast<int*>(sD + BM * 128);
-  int* s_pout = s_pin + BM;
+  unsigned char* sX = smem_raw;                    // [NP][ROWB]   input patch, this WG's 64 ci
+  unsigned char* sD = smem_raw + lds_x_bytes;      // [BM][DPITCH] dY rows,    this WG's COT co
+  int* s_pin = reinterpret_cast<int*>(sD + BM * DPITCH);   // [2][BM]
+  int* s_pout = s_pin + 2 * BM;                            // [2][BM]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int l31 = lane & 31;
+  const int tg = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+  const int l31 = lane & 31, g5 = lane >> 5;
+  const int q = lane >> 4, i16 = lane & 15;
   const int ncit = g.Cin >> 6;
   const int cot = blockIdx.x / ncit, cit = blockIdx.x - cot * ncit;
-  const int co0 = cot * 64, ci0 = cit * 64;
+  const int co0 = cot * COT, ci0 = cit * 64;
   const int split = blockIdx.y;
   const int per = (num_ktiles + nsplit - 1) / nsplit;
   const int kt0 = split * per;
   const int kt1 = min(num_ktiles, kt0 + per);
-  const long M = (long)g.N * g.MY * g.MX;
-  const long in_pixels = (long)g.N * g.in_Hp * g.in_Wp;
-  const int np8 = g.NP * 8;
-  uint4* sX4 = reinterpret_cast<uint4*>(sX);
-  uint4* sD4 = reinterpret_cast<uint4*>(sD);
+  const int M = g.N * g.MY * g.MX;
+  const int in_pixels = g.N * g.in_Hp * g.in_Wp;
+  const int npix = GATHER ? BM : g.NP;
+  const int n8 = npix * 8;
+  const bool pf = (n8 <= PFX * NT);
+  const int v_tapoff = g.tap_off[lane & (IIC_MAX_TAPS - 1)];
 
-  for (int t0 = 0; t0 < g.ntaps; t0 += NTP) {
-    const int tcount = min(NTP, g.ntaps - t0);
-    f32x16 acc[NTP];
-#pragma unroll
-    for (int t = 0; t < NTP; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  // lane constants of the transposing reads
+  const int trow = 8 * (q >> 1) + (i16 >> 2);                         // + 16*ks (+4 for rd=1)
+  const int tsub = (2 * (q & 1) + ((i16 & 3) >> 1)) * 16 + (i16 & 1) * 8;
+  typedef unsigned char __attribute__((address_space(3))) * lds_u8_ptr;
+  const uint32_t sXo = (uint32_t)(uintptr_t)(lds_u8_ptr)sX, sDo = (uint32_t)(uintptr_t)(lds_u8_ptr)sD;
+  const uint32_t aBase = sDo + trow * DPITCH + wm * (COT / 2) * 2 + tsub;
+  const int tcolB = wn * 64 + tsub;
 
+  auto rowinfo = [&](int kt, int b) {
+    if (tid < BM) {
+      int m = kt * BM + tid;
+      const bool valid = m < M;
+      if (!valid) m = M - 1;
+      const int plane = g.MY * g.MX;
+      const int n = m / plane;
+      const int r = m - n * plane;
+      const int y = r / g.MX, xx = r - y * g.MX;
+      s_pin[b * BM + tid] = (n * g.in_Hp + y * g.sy + g.oy) * g.in_Wp + xx * g.sx + g.ox;
+      s_pout[b * BM + tid] =
+          valid ? (n * g.out_Hp + y * g.ty + g.py) * g.out_Wp + xx * g.tx + g.px : -1;
+    }
+  };
+  u32x4 PX[PFX], PD[PDN];
+  // `launder` hides tid from loop-invariant code motion: the per-piece address arithmetic is
+  // recomputed where used instead of living in ~40 registers across the MFMA loop.
+  auto launder = [](int v) { asm volatile("" : "+v"(v)); return v; };
+  auto gload_d = [&](int b) {
+    const int tl = launder(tid);
+#pragma unroll
+    for (int u = 0; u < PDN; ++u) {
+      const int idx = u * NT + tl;
+      PD[u] = (u32x4){0u, 0u, 0u, 0u};        // rows past M are zero => contribute nothing
+      if (idx < DPIECES) {
+        const int po = s_pout[b * BM + idx / (COT / 8)];
+        if (po >= 0)
+          PD[u] = *reinterpret_cast<const u32x4*>(
+              dy + ((long)po * g.Cout + co0 + (idx % (COT / 8)) * 8));
+      }
+    }
+  };
+  auto lstore_d = [&]() {
+    const int tl = launder(tid);
+#pragma unroll
+    for (int u = 0; u < PDN; ++u) {
+      const int idx = u * NT + tl;
+      if (idx < DPIECES)
+        *reinterpret_cast<u32x4*>(sD + (idx / (COT / 8)) * DPITCH + (idx % (COT / 8)) * 16) = PD[u];
+    }
+  };
+  auto gload_x = [&](int b) {
+    const int p_lo = s_pin[b * BM];
+    const int tl = launder(tid);
+#pragma unroll
+    for (int u = 0; u < PFX; ++u) {
+      const int idx = u * NT + tl;
+      PX[u] = (u32x4){0u, 0u, 0u, 0u};
+      if (idx < n8) {
+        const int p = GATHER ? s_pin[b * BM + (idx >> 3)] : p_lo + (idx >> 3);
+        if (p < in_pixels)
+          PX[u] = *reinterpret_cast<const u32x4*>(x + ((long)p * g.Cin + ci0 + (idx & 7) * 8));
+      }
+    }
+  };
+  auto lstore_x = [&]() {
+    const int tl = launder(tid);
+#pragma unroll
+    for (int u = 0; u < PFX; ++u) {
+      const int idx = u * NT + tl;
+      if (idx < n8) *reinterpret_cast<u32x4*>(sX + (idx >> 3) * ROWB + (idx & 7) * 16) = PX[u];
+    }
+  };
+  auto load_x_sync_big = [&](int b) {   // patches too large for the register prefetch
+    const int p_lo = s_pin[b * BM];
+    for (int base = 0; base < n8; base += NT * 4) {
+      u32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = base + u * NT + tid;
+        v[u] = (u32x4){0u, 0u, 0u, 0u};
+        if (idx < n8) {
+          const int p = p_lo + (idx >> 3);
+          if (p < in_pixels)
+            v[u] = *reinterpret_cast<const u32x4*>(x + ((long)p * g.Cin + ci0 + (idx & 7) * 8));
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = base + u * NT + tid;
+        if (idx < n8) *reinterpret_cast<u32x4*>(sX + (idx >> 3) * ROWB + (idx & 7) * 16) = v[u];
+      }
+    }
+  };
+
+  for (int t0 = 0; t0 < g.ntaps; t0 += (GATHER ? 1 : NTG * TPG)) {
+    const int tfirst = t0 + tg * MYT;                      // this wave's first tap
+    const int tcount = max(0, min(MYT, g.ntaps - tfirst));
+    f32x16 acc[MYT][CS];
+#pragma unroll
+    for (int t = 0; t < MYT; ++t)
+#pragma unroll
+      for (int c = 0; c < CS; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][c][r] = 0.f;
+
+    // ---- prologue: first tile of this split -----------------------------------------------
+    __syncthreads();
+    if (kt0 < kt1) {
+      rowinfo(kt0, 0);
+      __syncthreads();
+      gload_d(0);
+      if (pf) { gload_x(0); lstore_x(); } else load_x_sync_big(0);
+      lstore_d();
+      if (kt0 + 1 < kt1) rowinfo(kt0 + 1, 1);
+      __syncthreads();
+    }
     for (int kt = kt0; kt < kt1; ++kt) {
-      const long m0 = (long)kt * BM;
-      __syncthreads();   // previous K-tile fully consumed
-      if (tid < BM) {
-        long m = m0 + tid;
-        const bool valid = m < M;
-        if (!valid) m = M - 1;
-        const int plane = g.MY * g.MX;
-        const int n = (int)(m / plane);
-        const int r = (int)(m - (long)n * plane);
-        const int y = r / g.MX, xx = r - y * g.MX;
-        s_pin[tid] = (n * g.in_Hp + y * g.sy + g.oy) * g.in_Wp + xx * g.sx + g.ox;
-        s_pout[tid] = valid ? (n * g.out_Hp + y * g.ty + g.py) * g.out_Wp + xx * g.tx + g.px : -1;
+      const int b = (kt - kt0) & 1;
+      const bool more = kt + 1 < kt1;
+      if (more) {                              // next tile in flight during the MFMAs below
+        gload_d(b ^ 1);
+        if (pf) gload_x(b ^ 1);
       }
-      __syncthreads();
-      const int p_lo = s_pin[0];
-      // input patch (64 channels of this ci tile)
-      for (int base = 0; base < np8; base += NTHREADS * 4) {
-        uint4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int idx = base + u * NTHREADS + tid;
-          const long p = (long)p_lo + (idx >> 3);
-          v[u] = make_uint4(0, 0, 0, 0);
-          if (idx < np8 && p < in_pixels)
-            v[u] = *reinterpret_cast<const uint4*>(x + (p * g.Cin + ci0 + (idx & 7) * 8));
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int idx = base + u * NTHREADS + tid;
-          if (idx < np8) sX4[swz(idx >> 3, idx & 7)] = v[u];
-        }
-      }
-      // dY rows (64 channels of this co tile); rows past M are zero => contribute nothing
-      {
-        uint4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int idx = u * NTHREADS + tid;      // BM*8 = 1024 = 4*256
-          const int po = s_pout[idx >> 3];
-          v[u] = make_uint4(0, 0, 0, 0);
-          if (po >= 0)
-            v[u] = *reinterpret_cast<const uint4*>(dy + ((long)po * g.Cout + co0 + (idx & 7) * 8));
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int idx = u * NTHREADS + tid;
-          sD4[swz(idx >> 3, idx & 7)] = v[u];
-        }
-      }
-      __syncthreads();
-#pragma unroll 1
+      const int p_lo = s_pin[b * BM];
+      const int* spin = s_pin + b * BM;
+#pragma unroll 2
       for (int ks = 0; ks < BM / 16; ++ks) {
-        const bf16x8 a = read_frag_T<USE_TR>(sD, s_pin, p_lo, false, 0, ks, wm, lane);
+        int rows8[8], rowsA[8];
+        uint32_t b0, b1;
+        {
+          const int k0 = ks * 16 + trow, k1 = k0 + 4;
+          const int r0 = GATHER ? k0 : spin[k0] - p_lo;
+          const int r1 = GATHER ? k1 : spin[k1] - p_lo;
+          b0 = sXo + r0 * ROWB + tcolB;
+          b1 = sXo + r1 * ROWB + tcolB;
+        }
+        if (!USE_TR) {
 #pragma unroll
-        for (int t = 0; t < NTP; ++t) {
-          if (t < tcount) {
-            const bf16x8 b = read_frag_T<USE_TR>(sX, s_pin, p_lo, true, g.tap_off[t0 + t], ks, wn, lane);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+          for (int j = 0; j < 8; ++j) {
+            const int k = ks * 16 + 8 * g5 + j;
+            rows8[j] = GATHER ? k : spin[k] - p_lo;
+            rowsA[j] = k;
           }
         }
+        bf16x8 a[CS];
+#pragma unroll
+        for (int c = 0; c < CS; ++c)
+          a[c] = frag_T<USE_TR>(aBase + ks * 16 * DPITCH + c * 64, aBase + (ks * 16 + 4) * DPITCH + c * 64,
+                                sDo, DPITCH, rowsA, wm * (COT / 2) + c * 32 + l31);
+#pragma unroll
+        for (int t = 0; t < MYT; ++t) {
+          if (t < tcount) {
+            const int toff = GATHER ? 0 : __builtin_amdgcn_readlane(v_tapoff, tfirst + t);
+            int rows8t[8];
+            if (!USE_TR) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) rows8t[j] = rows8[j] + toff;
+            }
+            const bf16x8 bf = frag_T<USE_TR>(b0 + toff * ROWB, b1 + toff * ROWB, sXo, ROWB, rows8t,
+                                             wn * 32 + l31);
+#pragma unroll
+            for (int c = 0; c < CS; ++c)
+              acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[c], bf, acc[t][c], 0, 0, 0);
+          }
+        }
+      }
+      __syncthreads();                        // tile kt fully consumed
+      if (more) {
+        lstore_d();
+        if (pf) lstore_x(); else load_x_sync_big(b ^ 1);
+        if (kt + 2 < kt1) rowinfo(kt + 2, b);
+        __syncthreads();
       }
     }
     // partial[split][t][co][ci]
 #pragma unroll
-    for (int t = 0; t < NTP; ++t) {
+    for (int t = 0; t < MYT; ++t) {
       if (t < tcount) {
-        float* dst = partials + (((long)split * g.ntaps + (t0 + t)) * g.Cout + co0) * g.Cin + ci0;
+        float* dst = partials + (((long)split * g.ntaps + (tfirst + t)) * g.Cout + co0) * g.Cin + ci0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = wm * 32 + mfma32_row(r, lane);
-          const int col = wn * 32 + l31;
-          dst[(long)row * g.Cin + col] = acc[t][r];
-        }
+        for (int c = 0; c < CS; ++c)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = wm * (COT / 2) + c * 32 + mfma32_row(r, lane);
+            const int col = wn * 32 + l31;
+            dst[(long)row * g.Cin + col] = acc[t][c][r];
+          }
       }
     }
   }
@@ -203,11 +314,13 @@ __global__ void probe_tr16_kernel(uint16_t* out) {
 
 extern "C" {
 
+static int wgrad_cot(const iic_conv_geom* g) { return (g->Cout % 128 == 0) ? 128 : 64; }
+
 int iic_conv_wgrad_nsplit(const iic_conv_geom* g) {
   const long M = (long)g->N * g->MY * g->MX;
   const int kt = (int)((M + BM - 1) / BM);
-  const int tiles = (g->Cout / 64) * (g->Cin / 64);
-  int ns = 512 / (tiles > 0 ? tiles : 1);
+  const int tiles = (g->Cout / wgrad_cot(g)) * (g->Cin / 64);
+  int ns = 256 / (tiles > 0 ? tiles : 1);   // one workgroup (12 waves) per CU
   if (ns < 1) ns = 1;
   if (ns > kt) ns = kt;
   return ns;
@@ -219,26 +332,33 @@ int iic_conv_wgrad(const iic_conv_geom* g, const void* x, const void* dy, float*
   if (g->Cin % 64 != 0 || g->Cout % 64 != 0 || g->ntaps < 1 || g->ntaps > IIC_MAX_TAPS)
     return IIC_ERR_UNSUPPORTED;
   const long M = (long)g->N * g->MY * g->MX;
+  if (M >= (1L << 31) || (long)g->N * g->in_Hp * g->in_Wp >= (1L << 31)) return IIC_ERR_UNSUPPORTED;
   const int kt = (int)((M + BM - 1) / BM);
-  const int lx = (g->NP * 128 + 15) & ~15;
-  const long lds = (long)lx + BM * 128 + 2 * BM * 4;
+  const bool ga = g->ntaps == 1;
+  const int cot = wgrad_cot(g);
+  const int lx = ((ga ? BM : g->NP) * ROWB + 15) & ~15;
+  const long lds = (long)lx + BM * (cot == 64 ? 144 : 288) + 4 * BM * 4;
   if (lds > 160 * 1024) return IIC_ERR_UNSUPPORTED;
-  dim3 grid((g->Cout / 64) * (g->Cin / 64), nsplit);
+  dim3 grid((g->Cout / cot) * (g->Cin / 64), nsplit);
   hipStream_t s = (hipStream_t)stream;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<true>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<false>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
-  }
-  if (use_tr)
-    hipLaunchKernelGGL(conv_wgrad_kernel<true>, grid, dim3(NTHREADS), lds, s, *g, (const bf16_t*)x,
-                       (const bf16_t*)dy, partials, nsplit, kt, lx);
-  else
-    hipLaunchKernelGGL(conv_wgrad_kernel<false>, grid, dim3(NTHREADS), lds, s, *g,
-                       (const bf16_t*)x, (const bf16_t*)dy, partials, nsplit, kt, lx);
+#define WGRAD_LAUNCH(TR_, GA_, COT_)                                                            \
+  do {                                                                                          \
+    static bool attr = false;                                                                   \
+    if (!attr) {                                                                                \
+      (void)hipFuncSetAttribute(                                                                \
+          reinterpret_cast<const void*>(&conv_wgrad_kernel<TR_, GA_, COT_>),                    \
+          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                              \
+      attr = true;                                                                              \
+    }                                                                                           \
+    hipLaunchKernelGGL((conv_wgrad_kernel<TR_, GA_, COT_>), grid, dim3(GA_ ? 256 : 768), lds,   \
+                       s, *g, (const bf16_t*)x, (const bf16_t*)dy, partials, nsplit, kt, lx);   \
+  } while (0)
+#define WGRAD_LAUNCH2(TR_, GA_)                                                                 \
+  do {                                                                                          \
+    if (cot == 128) WGRAD_LAUNCH(TR_, GA_, 128); else WGRAD_LAUNCH(TR_, GA_, 64);               \
+  } while (0)
+  if (use_tr) { if (ga) WGRAD_LAUNCH2(true, true); else WGRAD_LAUNCH2(true, false); }
+  else        { if (ga) WGRAD_LAUNCH2(false, true); else WGRAD_LAUNCH2(false, false); }
   return iic_launch_status();
 }
 

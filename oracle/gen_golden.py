@@ -148,11 +148,11 @@ def gen_nets():
   archs = ref_import.ref_cluster_archs()
   cfg = types.SimpleNamespace(in_channels=2, input_sz=32, batchnorm_track=True,
                               num_sub_heads=2, output_k=10)
-  params = net_oracle.make_net5g_params(2, 10, 2, True, seed=3, randomize_bn=True)
+  params = net_oracle.make_net5g_params(2, 10, 2, True, seed=3, randomize_bn=True, head_std=0.3)
   net = archs["net5g"].ClusterNet5g(cfg)
   _load(net, params)
   net.train()
-  imgs, imgs_tf = net_oracle.make_paired_batch(6, 32, 3, seed=5)
+  imgs, imgs_tf = net_oracle.make_paired_batch(24, 32, 3, seed=5)
   a, b = sob(imgs, False), sob(imgs_tf, False)
   ref_loss = ref_import.ref_cluster_losses()
   xo, xt = net(a), net(b)

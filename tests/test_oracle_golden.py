@@ -109,8 +109,8 @@ def _req(params):
 
 
 def test_net5g_oracle_matches_reference(g_nets):
-  params = _req(net_oracle.make_net5g_params(2, 10, 2, True, seed=3, randomize_bn=True))
-  imgs, imgs_tf = net_oracle.make_paired_batch(6, 32, 3, seed=5)
+  params = _req(net_oracle.make_net5g_params(2, 10, 2, True, seed=3, randomize_bn=True, head_std=0.3))
+  imgs, imgs_tf = net_oracle.make_paired_batch(24, 32, 3, seed=5)
   loss, _, xo, xt = net_oracle.net5g_train_step_loss(params, imgs, imgs_tf, 1.0, 32, 2)
   assert np.abs(np.stack([o.detach().numpy() for o in xo]) - g_nets["net5g_out"]).max() < 2e-6
   assert np.abs(np.stack([o.detach().numpy() for o in xt]) - g_nets["net5g_out_tf"]).max() < 2e-6
