@@ -27,6 +27,7 @@ class ConvGeom(Structure):
     ("tap_off", c_int32 * IIC_MAX_TAPS),
     ("tap_w", c_int32 * IIC_MAX_TAPS),
     ("NP", c_int32),
+    ("NP256", c_int32),
   ]
 
 

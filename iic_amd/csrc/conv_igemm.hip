@@ -23,8 +23,6 @@
 #include "common.h"
 #include "../../include/iic_hip.h"
 
-#define BM 128
-#define NTHREADS 256
 #define ROWB 144   // LDS row pitch in bytes: 128 B of data + 16 B pad.  144*r mod 256 visits all
                    // sixteen 16-B slots over 16 consecutive rows => the 16-lane groups of
                    // ds_read_b128 are conflict-free, and every k-step is an IMMEDIATE offset
@@ -32,7 +30,7 @@
 
 // Stage the input patch (NP pixels x 64 channels) or, in gather mode (1-tap convs), the 128
 // rows' own pixels.  4 independent 16-B loads in flight per thread.
-template <bool GATHER>
+template <bool GATHER, int NTHREADS>
 __device__ __forceinline__ void igemm_load_patch(unsigned char* sA, const bf16_t* __restrict__ in,
                                                  int Cin, int c0, int p_lo, int npix,
                                                  int in_pixels, const int* s_pin, int tid) {
@@ -57,13 +55,15 @@ __device__ __forceinline__ void igemm_load_patch(unsigned char* sA, const bf16_t
 }
 
 
-template <int BN, bool GATHER, bool ABL>
-__global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(
+template <int BN, bool GATHER, bool ABL, int BM>
+__global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv_igemm_kernel(
     const iic_conv_geom g, const bf16_t* __restrict__ in, const bf16_t* __restrict__ w,
     bf16_t* __restrict__ out, float* __restrict__ stats, const bf16_t* __restrict__ res_grad,
     const bf16_t* __restrict__ res_act, int accumulate, int num_mtiles, int lds_a_bytes,
     int ablate_arg) {
   const int ablate = ABL ? ablate_arg : 0;
+  constexpr int NTHREADS = BM * 2;          // 4 (BM=128) or 8 (BM=256) waves: (BM/64) x 2
+  constexpr int WM = BM / 64;
   constexpr int NS = BN / 64;               // 32-wide N sub-tiles per wave
   constexpr int BPASS = BN * 8 / NTHREADS;  // 16-B pieces per thread per weight tile
   constexpr int CLD = BN + 8;               // epilogue tile row stride (bf16 elements)
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(
   unsigned char* sB = smem_raw + lds_a_bytes;            // [2][BN][ROWB]
   int* s_pin = reinterpret_cast<int*>(sB + 2 * BN * ROWB);
   int* s_pout = s_pin + BM;
-  float* s_red = reinterpret_cast<float*>(s_pout + BM);   // [2(wm)][2][BN]
+  float* s_red = reinterpret_cast<float*>(s_pout + BM);   // [WM][2][BN]
   bf16_t* sC = reinterpret_cast<bf16_t*>(smem_raw);        // epilogue reuse of sA
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(
   }
   __syncthreads();
   const int p_lo = s_pin[0];
-  const int npix = GATHER ? BM : g.NP;
+  const int npix = GATHER ? BM : (BM == 128 ? g.NP : g.NP256);
   // byte address (within sA) of this lane's A rows at tap offset 0, k-chunk g5
   int arow[2];
 #pragma unroll
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(
   const int wrow = tid >> 3, wpc = tid & 7;
   const bf16_t* wbase = w + ((long)n0 + wrow) * g.Cin + wpc * 8;
   const long wtap_stride = (long)g.Cout * g.Cin;
-  const long wrow32 = 32L * g.Cin;
+  const long wrow32 = (long)(NTHREADS / 8) * g.Cin;
   unsigned char* const sBw = sB + wrow * ROWB + wpc * 16;   // this thread's store slot, pass 0
 
   // weight tile of flat iteration (tap, chunk) -> registers
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(
   auto bstore = [&](const u32x4(&R)[BPASS], int b) {
     unsigned char* dst = sBw + b * (BN * ROWB);
 #pragma unroll
-    for (int u = 0; u < BPASS; ++u) *reinterpret_cast<u32x4*>(dst + u * 32 * ROWB) = R[u];
+    for (int u = 0; u < BPASS; ++u) *reinterpret_cast<u32x4*>(dst + u * (NTHREADS / 8) * ROWB) = R[u];
   };
   // patch of the NEXT chunk held in registers while the current chunk computes
   const int n8 = npix * 8;
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(
   int tap2 = 0, chunk2 = 0;                    // (tap, chunk) of flat iteration it + 2
   auto advance = [&](int& t, int& c) { if (++t == ntaps) { t = 0; ++c; } };
   if (!(ablate & 16))
-    igemm_load_patch<GATHER>(sA, in, g.Cin, 0, p_lo, npix, in_pixels, s_pin, tid);
+    igemm_load_patch<GATHER, NTHREADS>(sA, in, g.Cin, 0, p_lo, npix, in_pixels, s_pin, tid);
   bload(R0, 0, 0);
   bstore(R0, 0);
   advance(tap2, chunk2);
@@ -199,6 +199,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(
   auto body = [&](u32x4(&Rnext)[BPASS], u32x4(&Rfree)[BPASS], int it, int buf) {
     // Rnext holds B(it+1) (loaded one iteration ago); Rfree is loaded with B(it+2) now.
     const bool last_tap = (tap + 1 == ntaps);
+    // B(it+1) (fetched one iteration ago) goes to the idle LDS buffer NOW, so the stores
+    // overlap this iteration's MFMAs and only the barrier remains at the end.
+    if (it + 1 < NIT && !(ablate & 2)) bstore(Rnext, buf ^ 1);
     if (it + 2 < NIT && !(ablate & 2)) bload(Rfree, tap2, chunk2);
     if (tap == 0 && chunk + 1 < nchunks && patch_pf && !(ablate & 16)) pload((chunk + 1) * 64);
     const int toffb = GATHER ? 0 : __builtin_amdgcn_readlane(v_tapoff, tap) * ROWB;
@@ -237,10 +240,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(
         if (!(ablate & 4)) __syncthreads();  // everyone is done reading the patch
         if (!(ablate & 16)) {
           if (patch_pf) pstore();
-          else igemm_load_patch<GATHER>(sA, in, g.Cin, (chunk + 1) * 64, p_lo, npix, in_pixels, s_pin, tid);
+          else igemm_load_patch<GATHER, NTHREADS>(sA, in, g.Cin, (chunk + 1) * 64, p_lo, npix, in_pixels, s_pin, tid);
         }
       }
-      if (!(ablate & 2)) bstore(Rnext, buf ^ 1);
       if (!(ablate & 4)) __syncthreads();
     }
     advance(tap, chunk);
@@ -279,8 +281,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(
   __syncthreads();   // all waves finished reading sA/sB; s_red complete
   if (stats && tid < BN) {
     float* st = stats + (long)(blockIdx.x % IIC_STAT_STRIPES) * 2 * g.Cout;
-    atomicAdd(st + n0 + tid, s_red[0 * BN + tid] + s_red[2 * BN + tid]);
-    atomicAdd(st + g.Cout + n0 + tid, s_red[1 * BN + tid] + s_red[3 * BN + tid]);
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < WM; ++q) {
+      a0 += s_red[(q * 2 + 0) * BN + tid];
+      a1 += s_red[(q * 2 + 1) * BN + tid];
+    }
+    atomicAdd(st + n0 + tid, a0);
+    atomicAdd(st + g.Cout + n0 + tid, a1);
   }
 #pragma unroll
   for (int ms = 0; ms < 2; ++ms)
@@ -349,14 +357,16 @@ __global__ void weight_prep_kernel(const float* __restrict__ w, bf16_t* __restri
 }
 
 static int g_ablate = 0;
+static int g_force_bm = 0;
 extern "C" void iic_debug_set_ablate(int v) { g_ablate = v; }
+extern "C" void iic_debug_force_bm(int v) { g_force_bm = v; }
 
 static int pick_bn(int Cout) { return (Cout % 128 == 0) ? 128 : 64; }
 
 static int geom_gather(const iic_conv_geom* g) { return g->ntaps == 1; }
 
-static long lds_a_bytes_for(const iic_conv_geom* g, int BN) {
-  long a = (long)(geom_gather(g) ? BM : g->NP) * ROWB;
+static long lds_a_bytes_for(const iic_conv_geom* g, int BN, int BM) {
+  long a = (long)(geom_gather(g) ? BM : (BM == 128 ? g->NP : g->NP256)) * ROWB;
   long c = (long)BM * (BN + 8) * 2;
   long m = a > c ? a : c;
   return (m + 15) & ~15L;
@@ -364,9 +374,23 @@ static long lds_a_bytes_for(const iic_conv_geom* g, int BN) {
 
 extern "C" {
 
+static long lds_total(const iic_conv_geom* g, int BN, int BM) {
+  return lds_a_bytes_for(g, BN, BM) + 2L * BN * ROWB + 2L * BM * 4 + (BM / 64) * 2L * BN * 4;
+}
+
+// largest M tile whose LDS footprint fits (256 rows halve the weight-tile traffic per FLOP)
+static int pick_bm(const iic_conv_geom* g, int BN) {
+  if (g_force_bm == 128 || g_force_bm == 256) return g_force_bm;
+  const long M = (long)g->N * g->MY * g->MX;
+  // measured (tools/conv_perf.py --bm): one 8-wave workgroup per CU loses the overlap two
+  // independent 4-wave workgroups give; 256-row tiles stay opt-in (iic_debug_force_bm).
+  (void)M;
+  return 128;
+}
+
 long iic_conv_lds_bytes(const iic_conv_geom* g, int BN) {
   if (BN == 0) BN = pick_bn(g->Cout);
-  return lds_a_bytes_for(g, BN) + 2L * BN * ROWB + 2L * BM * 4 + 4L * BN * 4;
+  return lds_total(g, BN, pick_bm(g, BN));
 }
 
 int iic_conv_igemm(const iic_conv_geom* g, const void* in, const void* w, void* out, float* stats,
@@ -379,29 +403,32 @@ int iic_conv_igemm(const iic_conv_geom* g, const void* in, const void* w, void* 
   const long M = (long)g->N * g->MY * g->MX;
   if (M <= 0 || g->NP <= 0) return IIC_ERR_ARG;
   if (M >= (1L << 31) || (long)g->N * g->in_Hp * g->in_Wp >= (1L << 31)) return IIC_ERR_UNSUPPORTED;
-  const int mt = (int)((M + BM - 1) / BM);
+  const int BMv = pick_bm(g, BN);
+  const int mt = (int)((M + BMv - 1) / BMv);
   const int grid = mt * (g->Cout / BN);
-  const long lds = iic_conv_lds_bytes(g, BN);
+  const long lds = lds_total(g, BN, BMv);
   if (lds > 160 * 1024) return IIC_ERR_UNSUPPORTED;
-  const int la = (int)lds_a_bytes_for(g, BN);
+  const int la = (int)lds_a_bytes_for(g, BN, BMv);
   hipStream_t s = (hipStream_t)stream;
-#define IGEMM_LAUNCH2(BN_, GA_, AB_)                                                              \
+#define IGEMM_LAUNCH3(BN_, GA_, AB_, BM_)                                                         \
   do {                                                                                           \
     static bool attr = false;                                                                    \
     if (!attr) {                                                                                 \
       (void)hipFuncSetAttribute(                                                                 \
-          reinterpret_cast<const void*>(&conv_igemm_kernel<BN_, GA_, AB_>),                      \
+          reinterpret_cast<const void*>(&conv_igemm_kernel<BN_, GA_, AB_, BM_>),                 \
           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                               \
       attr = true;                                                                               \
     }                                                                                            \
-    hipLaunchKernelGGL((conv_igemm_kernel<BN_, GA_, AB_>), dim3(grid), dim3(NTHREADS), lds, s,   \
-                       *g, (const bf16_t*)in, (const bf16_t*)w, (bf16_t*)out, stats,             \
+    hipLaunchKernelGGL((conv_igemm_kernel<BN_, GA_, AB_, BM_>), dim3(grid), dim3(BM_ * 2), lds,  \
+                       s, *g, (const bf16_t*)in, (const bf16_t*)w, (bf16_t*)out, stats,          \
                        (const bf16_t*)res_grad, (const bf16_t*)res_act, accumulate, mt, la,      \
                        g_ablate);                                                                \
   } while (0)
 #define IGEMM_LAUNCH(BN_, GA_)                                                                   \
   do {                                                                                           \
-    if (g_ablate) IGEMM_LAUNCH2(BN_, GA_, true); else IGEMM_LAUNCH2(BN_, GA_, false);            \
+    if (g_ablate) IGEMM_LAUNCH3(BN_, GA_, true, 128);                                            \
+    else if (BMv == 256) IGEMM_LAUNCH3(BN_, GA_, false, 256);                                    \
+    else IGEMM_LAUNCH3(BN_, GA_, false, 128);                                                    \
   } while (0)
   const bool ga = geom_gather(g);
   if (BN == 128) {

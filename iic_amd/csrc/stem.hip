@@ -362,15 +362,23 @@ __global__ __launch_bounds__(512) void stem_bwd_kernel(const float* __restrict__
   }
 }
 
-// dW[co][k] = sum_b part[b][co][k]  (k < K), fp32 OIHW flatten
-__global__ void stem_wgrad_reduce_kernel(const float* __restrict__ part, int nblocks, int LD, int K,
-                                         float* __restrict__ dW) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= 64 * K) return;
+// dW[co][k] = sum_b part[b][co][k]  (k < K), fp32 OIHW flatten.  One block per output
+// element group: 256 threads stride the partial blocks, LDS tree reduction.
+__global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ part,
+                                                                int nblocks, int LD, int K,
+                                                                float* __restrict__ dW) {
+  __shared__ float red[256];
+  const int idx = blockIdx.x;            // output element co*K + k
   const int co = idx / K, k = idx - co * K;
   float t = 0.f;
-  for (int b = 0; b < nblocks; ++b) t += part[((long)b * 64 + co) * LD + k];
-  dW[idx] = t;
+  for (int b = threadIdx.x; b < nblocks; b += 256) t += part[((long)b * 64 + co) * LD + k];
+  red[threadIdx.x] = t;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) dW[idx] = red[0];
 }
 
 // ------------------------------------------------------------------------------------
@@ -511,7 +519,7 @@ int iic_stem_bwd_wgrad(const float* x, const float* w, const float* coef, const 
                        H, W);
   });
   const int K = Cin * 9, LD = ((K + 31) / 32) * 32;
-  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((64 * K + 255) / 256), dim3(256), 0,
+  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(64 * K), dim3(256), 0,
                      (hipStream_t)stream, partials, grid, LD, K, dW);
   return iic_launch_status();
 }

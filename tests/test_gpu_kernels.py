@@ -149,8 +149,27 @@ def _conv_inputs(cin, cout, K, N, H, seed=0):
   return bf16_round(x), w
 
 
+def _force_bm(bm):
+  import ctypes
+  from iic_amd import _lib
+  ctypes.CDLL(_lib.LIB_PATH).iic_debug_force_bm(bm)
+
+
+@pytest.mark.parametrize("bm", [0, 256])
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_forward_and_stats(case):
+def test_conv_forward_and_stats(case, bm):
+  from iic_amd import geom, ops
+  cin, cout, K, s, p, N, H = case
+  if bm == 256 and s != 1:
+    pytest.skip("256-row tiles are used for stride-1 convs only (LDS footprint)")
+  _force_bm(bm)
+  try:
+    _conv_forward_and_stats(case)
+  finally:
+    _force_bm(0)
+
+
+def _conv_forward_and_stats(case):
   from iic_amd import geom, ops
   cin, cout, K, s, p, N, H = case
   x, w = _conv_inputs(cin, cout, K, N, H)
@@ -178,8 +197,19 @@ def test_conv_forward_and_stats(case):
   assert torch.equal(wb.float().cpu(), bf16_round(w).permute(2, 3, 1, 0).reshape(K * K, cin, cout))
 
 
+@pytest.mark.parametrize("bm", [0, 256])
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_backward_data(case):
+def test_conv_backward_data(case, bm):
+  if bm == 256 and case[3] != 1:
+    pytest.skip("256-row tiles are used for stride-1 convs only (LDS footprint)")
+  _force_bm(bm)
+  try:
+    _conv_backward_data(case)
+  finally:
+    _force_bm(0)
+
+
+def _conv_backward_data(case):
   from iic_amd import geom, ops
   cin, cout, K, s, p, N, H = case
   x, w = _conv_inputs(cin, cout, K, N, H, 1)

@@ -40,9 +40,15 @@ def main():
   ap.add_argument("--iters", type=int, default=20)
   ap.add_argument("--only", type=str, default="")
   ap.add_argument("--ablate", type=int, default=0)
+  ap.add_argument("--bm", type=int, default=0)
   a = ap.parse_args()
   dev = torch.device("cuda:0")
   N = a.n
+  if a.bm:
+    import ctypes
+    from iic_amd import _lib
+    ctypes.CDLL(_lib.LIB_PATH).iic_debug_force_bm(a.bm)
+    print('FORCE BM', a.bm)
   if a.ablate:
     import ctypes
     from iic_amd import _lib
