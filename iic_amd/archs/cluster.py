@@ -28,6 +28,24 @@ from .. import ops
 
 __all__ = ["ClusterNet5g", "ClusterNet5gTwoHead"]
 
+import os
+
+# Weight-gradient kernels run on a second HIP stream, concurrently with the dependent
+# backward-data / BatchNorm chain of the same block (they only share inputs): two kernels in
+# flight fill each other's tail waves and barrier stalls.  IIC_DUAL_STREAM=0 disables.
+DUAL_STREAM = [os.environ.get("IIC_DUAL_STREAM", "1") != "0"]
+_SIDE = {}
+
+
+def _side_stream(device):
+  key = str(device)
+  st = _SIDE.get(key)
+  if st is None:
+    st = torch.cuda.Stream(device=device)
+    _SIDE[key] = st
+  return st
+
+
 SHARD_INPUTS = [False]  # set by iic_amd.run under torchrun: forward keeps only this rank's rows
 _WEIGHTS_EPOCH = [0]   # bumped by iic_amd.optim.Adam (raw-pointer updates do not bump _version)
 
@@ -214,11 +232,29 @@ class _BlockFn(torch.autograd.Function):
       dyd = ops.pt_alloc(N, Ho, Wo, planes, 1, dev)
     ops.bn_bwd_apply(dout, out, y2, bc2, dy2, N, Ho, Wo, 1, planes, y2=yd, bcoef2=bcd, dy2=dyd)
 
-    # ---- conv2 backward
+    dual = DUAL_STREAM[0]
+    main = torch.cuda.current_stream()
+    side = _side_stream(dev) if dual else main
+
+    def on_side(fn):
+      """Run fn on the side stream after everything enqueued so far on the main stream."""
+      if not dual:
+        return fn()
+      side.wait_event(main.record_event())
+      with torch.cuda.stream(side):
+        r = fn()
+      r.record_stream(main)
+      return r
+
+    # ---- conv2 backward: weight grad (side stream) || data grad + bn1 backward (main)
+    dW2 = on_side(lambda: ops.conv_wgrad(gf2, a1, dy2, 9, use_tr)).view(planes, planes, 3, 3)
+    dWd = None
+    if hd is not None:
+      gfd, _ = hd.geoms(N, H, W)
+      dWd = on_side(lambda: ops.conv_wgrad(gfd, x, dyd, 1, use_tr)).view(planes, Cin, 1, 1)
     da1 = ops.pt_alloc(N, Ho, Wo, planes, 1, dev)
     for g in gb2:
       ops.conv_igemm(g, dy2, h2.weights()[1], da1)
-    dW2 = ops.conv_wgrad(gf2, a1, dy2, 9, use_tr).view(planes, planes, 3, 3)
 
     # ---- bn1 backward; g1 = da1 * (a1 > 0)
     s1 = h1.stats(dev, "bwd")
@@ -227,7 +263,8 @@ class _BlockFn(torch.autograd.Function):
     dy1 = ops.pt_alloc(N, Ho, Wo, planes, 1, dev)
     ops.bn_bwd_apply(da1, a1, y1, bc1, dy1, N, Ho, Wo, 1, planes)
 
-    # ---- conv1 backward-data (+ residual / downsample gradient), weight grads
+    # ---- conv1 backward: weight grad (side) || data grad (+ residual / downsample gradient)
+    dW1 = on_side(lambda: ops.conv_wgrad(gf1, x, dy1, 9, use_tr)).view(planes, Cin, 3, 3)
     dx = ops.pt_alloc(N, H, W, Cin, 1, dev)
     if hd is None:
       for g in gb1:
@@ -238,11 +275,8 @@ class _BlockFn(torch.autograd.Function):
       _, gbd = hd.geoms(N, H, W)
       for g in gbd:
         ops.conv_igemm(g, dyd, hd.weights()[1], dx, accumulate=True)
-    dW1 = ops.conv_wgrad(gf1, x, dy1, 9, use_tr).view(planes, Cin, 3, 3)
-    dWd = None
-    if hd is not None:
-      gfd, _ = hd.geoms(N, H, W)
-      dWd = ops.conv_wgrad(gfd, x, dyd, 1, use_tr).view(planes, Cin, 1, 1)
+    if dual:   # buffers below are recycled on the main stream: the side stream must be done
+      main.wait_event(side.record_event())
 
     for t in (dout, dy2, dyd, da1, dy1, y1, a1, y2, yd, out):
       ops.POOL.release(t)
