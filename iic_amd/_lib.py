@@ -55,6 +55,11 @@ _SIGNATURES = {
   "iic_stem_bwd_reduce": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
   "iic_stem_wgrad_partial_floats": (c_long, []),
   "iic_stem_bwd_wgrad": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+  "iic_firstconv_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+  "iic_firstconv_wgrad_partial_floats": (c_long, []),
+  "iic_firstconv_wgrad": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+  "iic_maxpool2_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+  "iic_maxpool2_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
   "iic_sobel": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
   "iic_avgpool_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
   "iic_avgpool_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),

@@ -57,8 +57,9 @@ def bump_weights_epoch():
 class _ConvHolder(object):
   """Per-conv caches: bf16 operand copies of the fp32 parameter, geometries, BN stat buffers."""
 
-  def __init__(self, conv):
+  def __init__(self, conv, pad_in=1, pad_out=1):
     self.conv = conv
+    self.pad_in, self.pad_out = pad_in, pad_out
     self.spec = G.ConvSpec(conv.in_channels, conv.out_channels, conv.kernel_size[0],
                            conv.stride[0], conv.padding[0], conv.dilation[0])
     self._wkey = None
@@ -78,7 +79,8 @@ class _ConvHolder(object):
     key = (N, H, W)
     g = self._geoms.get(key)
     if g is None:
-      g = (G.fwd_geom(self.spec, N, H, W, 1, 1), G.bwd_data_geoms(self.spec, N, H, W, 1, 1))
+      g = (G.fwd_geom(self.spec, N, H, W, self.pad_in, self.pad_out),
+           G.bwd_data_geoms(self.spec, N, H, W, self.pad_out, self.pad_in))
       self._geoms[key] = g
     return g
 

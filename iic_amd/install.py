@@ -22,6 +22,10 @@ PATCHES = [
   ("code.archs", "ClusterNet5gTwoHead", "iic_amd.archs", "ClusterNet5gTwoHead"),
   ("code.archs.cluster", "ClusterNet5g", "iic_amd.archs", "ClusterNet5g"),
   ("code.archs.cluster", "ClusterNet5gTwoHead", "iic_amd.archs", "ClusterNet5gTwoHead"),
+  ("code.archs", "ClusterNet6c", "iic_amd.archs", "ClusterNet6c"),
+  ("code.archs", "ClusterNet6cTwoHead", "iic_amd.archs", "ClusterNet6cTwoHead"),
+  ("code.archs.cluster", "ClusterNet6c", "iic_amd.archs", "ClusterNet6c"),
+  ("code.archs.cluster", "ClusterNet6cTwoHead", "iic_amd.archs", "ClusterNet6cTwoHead"),
 ]
 
 

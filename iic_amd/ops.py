@@ -236,3 +236,41 @@ def colsum(A, rows, cols):
   out = torch.empty(cols, dtype=F32, device=A.device)
   check(lib().iic_colsum_f32(ptr(A), ptr(out), rows, cols, 0, stream_ptr()), "iic_colsum_f32")
   return out
+
+
+# ------------------------------------------------------------------------------------
+# VGG-style trunks: first-layer conv from the image, 2x2 max-pool
+# ------------------------------------------------------------------------------------
+def firstconv_fwd(x, w, out_pt, stats, K, pad, P):
+  n, c, h, wd = x.shape
+  check(lib().iic_firstconv_fwd(ptr(x), ptr(w), ptr(out_pt), ptr(stats), n, c, h, wd, K, pad, P,
+                                stream_ptr()), "iic_firstconv_fwd")
+  return out_pt
+
+
+_FC_PART = {}
+
+
+def firstconv_wgrad(x, dy_pt, w_shape, K, pad, P):
+  n, c, h, wd = x.shape
+  key = str(x.device)
+  part = _FC_PART.get(key)
+  if part is None:
+    part = torch.empty(lib().iic_firstconv_wgrad_partial_floats(), dtype=F32, device=x.device)
+    _FC_PART[key] = part
+  dW = torch.empty(w_shape, dtype=F32, device=x.device)
+  check(lib().iic_firstconv_wgrad(ptr(x), ptr(dy_pt), ptr(part), ptr(dW), n, c, h, wd, K, pad, P,
+                                  stream_ptr()), "iic_firstconv_wgrad")
+  return dW
+
+
+def maxpool2_fwd(x_pt, out_pt, N, H, W, Pi, Po, C):
+  check(lib().iic_maxpool2_fwd(ptr(x_pt), ptr(out_pt), N, H, W, Pi, Po, C, stream_ptr()),
+        "iic_maxpool2_fwd")
+  return out_pt
+
+
+def maxpool2_bwd(x_pt, dout_pt, din_pt, N, H, W, Pi, Po, C):
+  check(lib().iic_maxpool2_bwd(ptr(x_pt), ptr(dout_pt), ptr(din_pt), N, H, W, Pi, Po, C,
+                               stream_ptr()), "iic_maxpool2_bwd")
+  return din_pt

@@ -139,6 +139,21 @@ long iic_stem_wgrad_partial_floats(void);
 int iic_stem_bwd_wgrad(const float* x, const float* w, const float* coef, const float* bcoef,
                        const void* dpool_pt, float* partials, float* dW, int N, int Cin, int H,
                        int W, void* stream);
+/* First-layer convolution of the VGG-style trunks from the fp32 NCHW image (Cin*K*K <= 128,
+ * K = 3 (pad 1) or 5 (pad 2), 64 output channels) -- replaces the first nn.Conv2d of
+ * code/archs/cluster/vgg.py:24-26 (net6c.py:16-20, net10a.py:21-25).  Exact fp32 MFMA.
+ * out: PT bf16 [N][H+2P][W+2P][64]; stats as for iic_conv_igemm (nullable).               */
+int iic_firstconv_fwd(const float* x, const float* w, void* out_pt, float* stats, int N, int Cin,
+                      int H, int W, int K, int pad, int P, void* stream);
+long iic_firstconv_wgrad_partial_floats(void);
+int iic_firstconv_wgrad(const float* x, const void* dy_pt, float* partials, float* dW, int N,
+                        int Cin, int H, int W, int K, int pad, int P, void* stream);
+/* nn.MaxPool2d(kernel_size=2, stride=2) (vgg.py:19-20) on PT tensors; backward routes to the
+ * first arg-max in scan order like torch.                                                 */
+int iic_maxpool2_fwd(const void* in_pt, void* out_pt, int N, int H, int W, int Pi, int Po, int C,
+                     void* stream);
+int iic_maxpool2_bwd(const void* in_pt, const void* dout_pt, void* din_pt, int N, int H, int W,
+                     int Pi, int Po, int C, void* stream);
 /* Sobel pre-op -- replaces code/utils/cluster/transforms.py:47-96 (grey channel -> dx,dy;
  * other channels copied through in the reference's order).                              */
 int iic_sobel(const float* imgs, float* out, int N, int C, int H, int W, int include_rgb,

@@ -176,11 +176,11 @@ def gen_nets():
   # ---- ClusterNet6c  (input 24, in_ch 1, k=10, 2 sub-heads, batch 6)
   cfg = types.SimpleNamespace(in_channels=1, input_sz=24, batchnorm_track=True,
                               num_sub_heads=2, output_k=10)
-  params = net_oracle.make_net6c_params(1, 24, 10, 2, True, seed=4, randomize_bn=True)
+  params = net_oracle.make_net6c_params(1, 24, 10, 2, True, seed=4, randomize_bn=True, head_std=0.05)
   net = archs["net6c"].ClusterNet6c(cfg)
   _load(net, params)
   net.train()
-  x6, x6t = net_oracle.make_paired_batch(6, 24, 3, seed=6)
+  x6, x6t = net_oracle.make_paired_batch(24, 24, 3, seed=6)
   xo, xt = net(x6), net(x6t)
   with expand_clones():
     tot = None

@@ -171,7 +171,7 @@ def make_vgg_params(cfg, conv_size, in_channels, batchnorm_track, rng):
 
 def make_net6c_params(in_channels=1, input_sz=24, output_k=10, num_sub_heads=5,
                       batchnorm_track=True, seed=0, heads=("head",), output_ks=None,
-                      randomize_bn=False):
+                      randomize_bn=False, head_std=0.01):
   rng = np.random.default_rng(seed)
   p = make_vgg_params(NET6C_CFG, 5, in_channels, batchnorm_track, rng)
   sp = {24: 3, 64: 8}[input_sz]
@@ -179,7 +179,7 @@ def make_net6c_params(in_channels=1, input_sz=24, output_k=10, num_sub_heads=5,
   for hname, k in zip(heads, ks):
     for i in range(num_sub_heads):
       p["%s.heads.%d.0.weight" % (hname, i)] = torch.from_numpy(
-        (rng.standard_normal((k, 512 * sp * sp)) * 0.01).astype(np.float32))
+        (rng.standard_normal((k, 512 * sp * sp)) * head_std).astype(np.float32))
       p["%s.heads.%d.0.bias" % (hname, i)] = torch.zeros(k)
   if randomize_bn:
     _randomize_bn(p, rng)
@@ -384,3 +384,24 @@ def net5g_forward_bf16emu(params, x, training=True, input_sz=96, head="head", nu
       xcur = block_bf16emu(params, pre, xcur, stride, training)
   feats = F.avg_pool2d(xcur, {96: 7, 64: 5, 32: 3}[input_sz], stride=1).view(xcur.size(0), -1)
   return heads_forward(params, feats, head, num_sub_heads)
+
+
+def vgg_stage_bf16emu(params, idx, x, pad, dil, pool, first, training=True):
+  """One VGG stage (conv -> BN -> ReLU [-> MaxPool2]) with the HIP path's rounding points.
+  First stage: exact fp32 conv of the image; later stages: bf16 operands."""
+  w = params["trunk.features.%d.weight" % idx]
+  y = F.conv2d(x, w if first else _rbf(w), stride=1, padding=pad, dilation=dil)
+  a = _rbf(F.relu(_bn_emu(y, params, "trunk.features.%d" % (idx + 1), training)))
+  return F.max_pool2d(a, 2, 2) if pool else a
+
+
+def net6c_forward_bf16emu(params, x, training=True, head="head", num_sub_heads=5):
+  layers = vgg_feature_index(NET6C_CFG)
+  first = True
+  for li, (kind, idx, c, dil) in enumerate(layers):
+    if kind != "conv":
+      continue
+    pool = li + 1 < len(layers) and layers[li + 1][0] == "pool"
+    x = vgg_stage_bf16emu(params, idx, x, 2, dil, pool, first, training)
+    first = False
+  return heads_forward(params, x.reshape(x.size(0), -1), head, num_sub_heads)

@@ -12,8 +12,8 @@ def test_install_rebinds_reference_names(tmp_path, monkeypatch):
     (root / d / "__init__.py").write_text("")
   (root / "code/utils/cluster/IID_losses.py").write_text("def IID_loss(*a, **k):\n  return 'ref'\n")
   (root / "code/utils/cluster/transforms.py").write_text("def sobel_process(*a, **k):\n  return 'ref'\n")
-  (root / "code/archs/__init__.py").write_text("class ClusterNet5g: pass\nclass ClusterNet5gTwoHead: pass\n")
-  (root / "code/archs/cluster/__init__.py").write_text("class ClusterNet5g: pass\nclass ClusterNet5gTwoHead: pass\n")
+  (root / "code/archs/__init__.py").write_text("class ClusterNet5g: pass\nclass ClusterNet5gTwoHead: pass\nclass ClusterNet6c: pass\nclass ClusterNet6cTwoHead: pass\n")
+  (root / "code/archs/cluster/__init__.py").write_text("class ClusterNet5g: pass\nclass ClusterNet5gTwoHead: pass\nclass ClusterNet6c: pass\nclass ClusterNet6cTwoHead: pass\n")
   monkeypatch.syspath_prepend(str(root))
   for k in [k for k in sys.modules if k == "code" or k.startswith("code.")]:
     monkeypatch.delitem(sys.modules, k)

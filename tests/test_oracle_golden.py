@@ -126,8 +126,8 @@ def test_net5g_oracle_matches_reference(g_nets):
 
 
 def test_net6c_oracle_matches_reference(g_nets):
-  params = _req(net_oracle.make_net6c_params(1, 24, 10, 2, True, seed=4, randomize_bn=True))
-  x6, x6t = net_oracle.make_paired_batch(6, 24, 3, seed=6)
+  params = _req(net_oracle.make_net6c_params(1, 24, 10, 2, True, seed=4, randomize_bn=True, head_std=0.05))
+  x6, x6t = net_oracle.make_paired_batch(24, 24, 3, seed=6)
   xo = net_oracle.net6c_forward(params, x6, True, "head", 2)
   xt = net_oracle.net6c_forward(params, x6t, True, "head", 2)
   assert np.abs(np.stack([o.detach().numpy() for o in xo]) - g_nets["net6c_out"]).max() < 2e-6
