@@ -39,6 +39,10 @@ _SIGNATURES = {
   "iic_iid_joint_raw": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_long, c_long, c_int, _P]),
   "iic_iid_loss_from_joint": (c_int, [_P, c_int, c_int, c_int, c_double, c_double, _P, _P, _P, _P, _P, _P]),
   "iic_iid_grad": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_long, c_long, _P]),
+  "iic_seg_joint_nsplit": (c_int, [c_int, c_int, c_int, c_int]),
+  "iic_seg_joint_raw": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+  "iic_seg_loss_from_joint": (c_int, [_P, c_int, c_int, c_int, c_double, c_double, _P, _P, _P, _P, _P, c_int, _P]),
+  "iic_seg_grad": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
   "iic_conv_lds_bytes": (c_long, [POINTER(ConvGeom), c_int]),
   "iic_conv_igemm": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P, _P, _P, c_int, _P]),
   "iic_conv_wgrad_nsplit": (c_int, [POINTER(ConvGeom)]),

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(64) void iid_joint_kernel(
 __global__ __launch_bounds__(1024) void iid_loss_kernel(
     const float* __restrict__ part, int nparts, int k, double lamb, double eps,
     double* __restrict__ ws, float* __restrict__ loss_out, float* __restrict__ loss_nl_out,
-    float* __restrict__ dR1, float* __restrict__ dR2) {
+    float* __restrict__ dR1, float* __restrict__ dR2, int detach_norm) {
   __shared__ double red[32];
   __shared__ double s_pi[IID_MAXK];   // marginal (row sum of P; == col sum, P symmetric)
   __shared__ double s_rc[IID_MAXK];   // row sum of clamped P
@@ -148,6 +148,8 @@ __global__ __launch_bounds__(1024) void iid_loss_kernel(
   l2 = block_sum_d(l2, red);
   g1 = block_sum_d(g1, red);
   g2 = block_sum_d(g2, red);
+  if (detach_norm) g1 = g2 = 0.0;   // normaliser taken as a constant (segmentation, collapsed:
+                                    // `current_norm = float(p_i_j.sum())`, IID_losses.py:60)
   if (tid == 0) {
     loss_out[h] = (float)l1;
     loss_nl_out[h] = (float)l2;
@@ -248,7 +250,22 @@ int iic_iid_loss_from_joint(const float* partials, int nparts, int H, int k, dou
   if (H <= 0 || k <= 0 || k > IID_MAXK || nparts <= 0) return IIC_ERR_ARG;
   hipLaunchKernelGGL(iid_loss_kernel, dim3(H), dim3(1024), 0, (hipStream_t)stream, partials,
                      nparts, k, lamb, eps, (double*)workspace, loss, loss_no_lamb, dR_loss,
-                     dR_loss_no_lamb);
+                     dR_loss_no_lamb, 0);
+  return iic_launch_status();
+}
+
+// Same k x k stage for the segmentation losses: H = number of shifts (uncollapsed, one joint
+// per shift, normaliser differentiable) or H = 1 with the shifts summed as `nparts`
+// (collapsed, detach_norm = 1).
+int iic_seg_loss_from_joint(const float* partials, int nparts, int H, int k, double lamb,
+                            double eps, void* workspace, float* loss, float* loss_no_lamb,
+                            float* dR_loss, float* dR_loss_no_lamb, int detach_norm, void* stream) {
+  if (!partials || !workspace || !loss || !loss_no_lamb || !dR_loss || !dR_loss_no_lamb)
+    return IIC_ERR_ARG;
+  if (H <= 0 || k <= 0 || k > IID_MAXK || nparts <= 0) return IIC_ERR_ARG;
+  hipLaunchKernelGGL(iid_loss_kernel, dim3(H), dim3(1024), 0, (hipStream_t)stream, partials,
+                     nparts, k, lamb, eps, (double*)workspace, loss, loss_no_lamb, dR_loss,
+                     dR_loss_no_lamb, detach_norm);
   return iic_launch_status();
 }
 

@@ -1,0 +1,306 @@
+// IID segmentation loss for gfx950: the T-shifted per-pixel joint and its gradient.
+//
+// Replaces, in /root/reference/code/utils/segmentation/IID_losses.py:14-159,
+//   perform_affine_tf (identity / axis flips -- the only transforms the published runs use,
+//   potsdam.py:189-202), the mask multiplies (:45-47,115-117), the permutes (:51-52,121-122)
+//   and the giant-filter F.conv2d(x1, weight=x2_inv, padding=T) (:55,125), whose backward is
+//   two more such convolutions.  The k x k x (2T+1)^2 statistics stage reuses iid_loss_kernel.
+//
+//   R[p][q][i][j] = sum_{n,y,x} x1m[n][i][y+p-T][x+q-T] * x2m[n][j][y][x]
+//   x1m = x1 * mask,  x2m = flip(x2) * mask   (zero outside the image)
+//
+// All arithmetic is exact fp32 on v_mfma_f32_16x16x4_f32 (k <= 48 classes => 16x16 tiles keep
+// the matrix core well filled where a 32x32 tile would idle 3/4 of it at k = 15).
+//
+// seg_joint_kernel : workgroup = (one row shift p, a group of QG column shifts q, a slice of
+//   the (n, y) rows); one image row of x2m and the matching shifted row of x1m (+T halo) are
+//   staged in LDS as [class][pixel]; the x2m fragment is reused by all QG shifts; accumulators
+//   (QG x TK x TK tiles) stay in registers across the whole slice -> one partial per workgroup.
+// seg_grad_kernel  : d/dx1m[i][v] = sum_{p,q,j} G[p][q][i][j] x2m[j][v-(t)]   (which = 0)
+//                    d/dx2m[j][u] = sum_{p,q,i} G[p][q][i][j] x1m[i][u+(t)]   (which = 1)
+//   as a GEMM pixels x classes with K = (q, class) per row shift p; G = gl*dR1 + gnl*dR2.
+#include "common.h"
+#include "../../include/iic_hip.h"
+
+#define SEG_MAXW 256
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// value of (x * mask) at (n, ch, y, x) with optional flips of the SOURCE tensor (x2 -> x2_inv)
+__device__ __forceinline__ float seg_src(const float* __restrict__ src, const float* __restrict__ mask,
+                                         int n, int ch, int y, int x, int k, int h, int w, int fx,
+                                         int fy) {
+  const float m = mask[((long)n * h + y) * w + x];
+  const int sy = fy ? h - 1 - y : y, sx = fx ? w - 1 - x : x;
+  return src[(((long)n * k + ch) * h + sy) * w + sx] * m;
+}
+
+// ------------------------------------------------------------------------------------
+// joint.  grid = (2T+1, ceil((2T+1)/QG), S), block = 256.
+// part[s][p][q][i][j]
+// ------------------------------------------------------------------------------------
+template <int TK, int QG>
+__global__ __launch_bounds__(256) void seg_joint_kernel(
+    const float* __restrict__ x1, const float* __restrict__ x2, const float* __restrict__ mask,
+    const int* __restrict__ flips, float* __restrict__ part, int bn, int k, int h, int w, int T) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int nq = 2 * T + 1;
+  const int w4 = (w + 3) & ~3;
+  const int P1 = (w4 + 2 * T) | 1, P2 = w4 | 1;         // odd pitches: conflict-free columns
+  float* sX1 = reinterpret_cast<float*>(smem_raw);          // [16*TK][P1]
+  float* sX2 = sX1 + 16 * TK * P1;                          // [16*TK][P2]
+  const int p = blockIdx.x, q0 = blockIdx.y * QG, split = blockIdx.z, S = gridDim.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, kk = lane >> 4;
+  const long rows = (long)bn * h;
+  const long per = (rows + S - 1) / S;
+  const long r0 = split * per, r1 = min(rows, r0 + per);
+
+  f32x4 acc[QG][TK][TK];
+#pragma unroll
+  for (int a = 0; a < QG; ++a)
+#pragma unroll
+    for (int ti = 0; ti < TK; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < TK; ++tj) acc[a][ti][tj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (long r = r0; r < r1; ++r) {
+    const int n = (int)(r / h), y = (int)(r - (long)n * h);
+    const int y1 = y + p - T;
+    if (y1 < 0 || y1 >= h) continue;                 // uniform: the shifted row is all padding
+    const int fx = flips[2 * n], fy = flips[2 * n + 1];
+    __syncthreads();
+    for (int idx = tid; idx < 16 * TK * P2; idx += 256) {
+      const int ch = idx / P2, x = idx - ch * P2;
+      sX2[idx] = (ch < k && x < w) ? seg_src(x2, mask, n, ch, y, x, k, h, w, fx, fy) : 0.f;
+    }
+    for (int idx = tid; idx < 16 * TK * P1; idx += 256) {
+      const int ch = idx / P1, xx = idx - ch * P1, x = xx - T;
+      sX1[idx] = (ch < k && x >= 0 && x < w) ? seg_src(x1, mask, n, ch, y1, x, k, h, w, 0, 0) : 0.f;
+    }
+    __syncthreads();
+    for (int st = wave; st < w4 / 4; st += 4) {
+      const int x0 = 4 * st + kk;
+      float b[TK];
+#pragma unroll
+      for (int tj = 0; tj < TK; ++tj) b[tj] = sX2[(tj * 16 + c) * P2 + x0];
+#pragma unroll
+      for (int a = 0; a < QG; ++a) {
+        const int q = q0 + a;
+        if (q < nq) {
+#pragma unroll
+          for (int ti = 0; ti < TK; ++ti) {
+            const float av = sX1[(ti * 16 + c) * P1 + x0 + q];   // x + (q - T) + T
+#pragma unroll
+            for (int tj = 0; tj < TK; ++tj) acc[a][ti][tj] = mfma16(av, b[tj], acc[a][ti][tj]);
+          }
+        }
+      }
+    }
+  }
+  // cross-wave reduction, one shift at a time, through LDS (reuses the row buffers)
+  float* red = reinterpret_cast<float*>(smem_raw);          // [4][TK*TK][256]
+  constexpr int TT = TK * TK;
+#pragma unroll
+  for (int a = 0; a < QG; ++a) {
+    const int q = q0 + a;
+    if (q >= nq) break;
+    __syncthreads();
+#pragma unroll
+    for (int ti = 0; ti < TK; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < TK; ++tj)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+          red[(wave * TT + ti * TK + tj) * 256 + lane * 4 + rr] = acc[a][ti][tj][rr];
+    __syncthreads();
+    float* out = part + (((long)split * nq + p) * nq + q) * k * k;
+    for (int idx = tid; idx < TT * 256; idx += 256) {
+      const int t = idx >> 8, e = idx & 255, ln = e >> 2, rr = e & 3;
+      const int i = (t / TK) * 16 + (ln >> 4) * 4 + rr, j = (t % TK) * 16 + (ln & 15);
+      if (i < k && j < k)
+        out[(long)i * k + j] = red[(0 * TT + t) * 256 + e] + red[(1 * TT + t) * 256 + e] +
+                               red[(2 * TT + t) * 256 + e] + red[(3 * TT + t) * 256 + e];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// gradient.  grid = bn*h (one output row each), block = 256.
+//   which = 0: out = d/dx1  (reads x2m rows y - (p-T), columns x - (q-T); G[i = a][j = b])
+//   which = 1: out = d/dx2  (reads x1m rows y + (p-T), columns x + (q-T); G[i = b][j = a])
+//   G[h][i][j] = gl[h]*dR1[h] + gnl[h]*dR2[h],  h = shift index (stride 0 when collapsed)
+// ------------------------------------------------------------------------------------
+template <int TK>
+__global__ __launch_bounds__(256) void seg_grad_kernel(
+    const float* __restrict__ src, const float* __restrict__ mask, const int* __restrict__ flips,
+    const float* __restrict__ dR1, const float* __restrict__ dR2, const float* __restrict__ gl,
+    const float* __restrict__ gnl, float* __restrict__ out, int bn, int k, int h, int w, int T,
+    int which, int shift_stride, int src_is_x2, int QC) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int nq = 2 * T + 1;
+  const int w16 = (w + 15) & ~15;
+  const int PS = (w16 + 2 * T) | 1;
+  constexpr int PG = 16 * TK + 1;
+  float* sS = reinterpret_cast<float*>(smem_raw);          // [k][PS]      masked source row
+  float* sG = sS + (long)k * PS;                            // [QC*k (pad4)][PG]
+  const int n = blockIdx.x / h, y = blockIdx.x - n * h;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, kk = lane >> 4;
+  const int sgn = which == 0 ? -1 : 1;
+  const int fx = flips[2 * n], fy = flips[2 * n + 1];
+  const int ntile = w16 / 16;
+  constexpr int MT = 4;                                    // pixel tiles per wave (w <= 256)
+  f32x4 acc[MT][TK];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < TK; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int p = 0; p < nq; ++p) {
+    const int ys = y + sgn * (p - T);
+    if (ys < 0 || ys >= h) continue;                       // uniform
+    __syncthreads();
+    for (int idx = tid; idx < k * PS; idx += 256) {
+      const int ch = idx / PS, xx = idx - ch * PS, x = xx - T;
+      float v = 0.f;
+      if (x >= 0 && x < w)
+        v = src_is_x2 ? seg_src(src, mask, n, ch, ys, x, k, h, w, fx, fy)
+                      : seg_src(src, mask, n, ch, ys, x, k, h, w, 0, 0);
+      sS[idx] = v;
+    }
+    for (int qc0 = 0; qc0 < nq; qc0 += QC) {
+      const int qn = min(QC, nq - qc0);
+      const int KT = qn * k, KT4 = (KT + 3) & ~3;
+      __syncthreads();
+      for (int idx = tid; idx < KT4 * 16 * TK; idx += 256) {
+        const int kidx = idx / (16 * TK), a = idx - kidx * (16 * TK);
+        float v = 0.f;
+        if (kidx < KT && a < k) {
+          const int q = qc0 + kidx / k, b = kidx - (kidx / k) * k;
+          const long hh = (long)(p * nq + q) * shift_stride;
+          const long e = which == 0 ? ((long)a * k + b) : ((long)b * k + a);
+          const float w1 = gl[hh], w2 = gnl ? gnl[hh] : 0.f;
+          v = w1 * dR1[hh * k * k + e] + w2 * dR2[hh * k * k + e];
+        }
+        sG[kidx * PG + a] = v;
+      }
+      __syncthreads();
+      for (int s = 0; s < KT4 / 4; ++s) {
+        const int kidx = 4 * s + kk;
+        const int q = qc0 + kidx / k, b = kidx - (kidx / k) * k;
+        const bool kv = kidx < KT;
+        float bv[TK];
+#pragma unroll
+        for (int t = 0; t < TK; ++t) bv[t] = sG[kidx * PG + t * 16 + c];
+        const int xoff = sgn * (q - T) + T;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const int tile = wave + 4 * m;
+          if (tile < ntile) {
+            const float av = kv ? sS[b * PS + tile * 16 + c + xoff] : 0.f;
+#pragma unroll
+            for (int t = 0; t < TK; ++t) acc[m][t] = mfma16(av, bv[t], acc[m][t]);
+          }
+        }
+      }
+    }
+  }
+  // store: D[row = pixel (lane>>4)*4 + r][col = class lane&15]; x mask; un-flip for x2
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int tile = wave + 4 * m;
+    if (tile >= ntile) continue;
+#pragma unroll
+    for (int t = 0; t < TK; ++t) {
+      const int a = t * 16 + c;
+      if (a >= k) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int x = tile * 16 + kk * 4 + r;
+        if (x < w) {
+          const float v = acc[m][t][r] * mask[((long)n * h + y) * w + x];
+          const int oy = (src_is_x2 == 0 && which == 1 && fy) ? h - 1 - y : y;
+          const int ox = (src_is_x2 == 0 && which == 1 && fx) ? w - 1 - x : x;
+          out[(((long)n * k + a) * h + oy) * w + ox] = v;
+        }
+      }
+    }
+  }
+}
+
+extern "C" {
+
+static int seg_tk(int k) { return (k + 15) / 16; }
+static int seg_qg(int tk) { return tk == 1 ? 21 : (tk == 2 ? 7 : 3); }
+
+int iic_seg_joint_nsplit(int bn, int h, int k, int T) {
+  const int nq = 2 * T + 1, tk = seg_tk(k), qg = seg_qg(tk);
+  const int groups = nq * ((nq + qg - 1) / qg);
+  int s = 1536 / groups;
+  if (s < 1) s = 1;
+  const long rows = (long)bn * h;
+  if (s > rows) s = (int)rows;
+  return s;
+}
+
+int iic_seg_joint_raw(const float* x1, const float* x2, const float* mask, const int* flips,
+                      float* partials, int bn, int k, int h, int w, int T, int nsplit,
+                      void* stream) {
+  if (!x1 || !x2 || !mask || !flips || !partials || bn <= 0 || nsplit <= 0) return IIC_ERR_ARG;
+  if (k < 1 || k > 48 || T < 0 || T > 10 || w > SEG_MAXW || h < 1) return IIC_ERR_UNSUPPORTED;
+  const int nq = 2 * T + 1, tk = seg_tk(k), qg = seg_qg(tk);
+  const int w4 = (w + 3) & ~3;
+  const size_t rows_b = (size_t)16 * tk * (((w4 + 2 * T) | 1) + (w4 | 1)) * sizeof(float);
+  const size_t red_b = (size_t)4 * tk * tk * 256 * sizeof(float);
+  const size_t lds = rows_b > red_b ? rows_b : red_b;
+  dim3 grid(nq, (nq + qg - 1) / qg, nsplit);
+  hipStream_t s = (hipStream_t)stream;
+#define SEGJ(TK_, QG_)                                                                          \
+  do {                                                                                          \
+    if (lds > 48 * 1024)                                                                        \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seg_joint_kernel<TK_, QG_>),     \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
+    hipLaunchKernelGGL((seg_joint_kernel<TK_, QG_>), grid, dim3(256), lds, s, x1, x2, mask,     \
+                       flips, partials, bn, k, h, w, T);                                        \
+  } while (0)
+  if (tk == 1) SEGJ(1, 21);
+  else if (tk == 2) SEGJ(2, 7);
+  else SEGJ(3, 3);
+  return iic_launch_status();
+}
+
+int iic_seg_grad(const float* src, const float* mask, const int* flips, const float* dR_loss,
+                 const float* dR_loss_no_lamb, const float* g_loss, const float* g_loss_no_lamb,
+                 float* out, int bn, int k, int h, int w, int T, int which, int collapsed,
+                 void* stream) {
+  if (!src || !mask || !flips || !dR_loss || !dR_loss_no_lamb || !g_loss || !out) return IIC_ERR_ARG;
+  if (k < 1 || k > 48 || T < 0 || T > 10 || w > SEG_MAXW || bn <= 0 || h < 1) return IIC_ERR_UNSUPPORTED;
+  const int nq = 2 * T + 1, tk = seg_tk(k);
+  const int w16 = (w + 15) & ~15;
+  const int PS = (w16 + 2 * T) | 1, PG = 16 * tk + 1;
+  int QC = (40 * 1024) / (k * PG * 4);        // G slice kept in LDS per chunk of column shifts
+  if (QC < 1) QC = 1;
+  if (QC > nq) QC = nq;
+  const size_t lds = ((size_t)k * PS + (size_t)((QC * k + 3) & ~3) * PG) * sizeof(float);
+  const int src_is_x2 = which == 0 ? 1 : 0;   // d/dx1 reads x2m ; d/dx2 reads x1m
+  hipStream_t s = (hipStream_t)stream;
+#define SEGG(TK_)                                                                               \
+  do {                                                                                          \
+    if (lds > 48 * 1024)                                                                        \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seg_grad_kernel<TK_>),           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
+    hipLaunchKernelGGL((seg_grad_kernel<TK_>), dim3(bn * h), dim3(256), lds, s, src, mask,      \
+                       flips, dR_loss, dR_loss_no_lamb, g_loss, g_loss_no_lamb, out, bn, k, h,  \
+                       w, T, which, collapsed ? 0 : 1, src_is_x2, QC);                          \
+  } while (0)
+  if (tk == 1) SEGG(1);
+  else if (tk == 2) SEGG(2);
+  else SEGG(3);
+  (void)nq;
+  return iic_launch_status();
+}
+
+}  // extern "C"

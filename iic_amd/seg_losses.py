@@ -1,0 +1,115 @@
+"""Drop-in IID_segmentation_loss / IID_segmentation_loss_uncollapsed on the HIP kernels
+(iic_amd/csrc/seg_loss.hip + the k x k stage of iid_loss.hip).
+
+Mirrors /root/reference/code/utils/segmentation/IID_losses.py:14-159 -- same keyword
+signature, same asserts (inputs require grad; affine / mask do not), returns
+(loss, loss_no_lamb) 0-d tensors.  Supported transforms: identity and axis flips (what
+potsdam.py:189-202 / cocostuff.py produce unless --use_random_affine, which no published run
+sets); the sparse random shift (half_T_side_sparse_*) must be 0 as in every published run.
+Anything else raises NotImplementedError -- there is no silent fallback.
+
+Data-parallel: the raw per-shift joints are all-reduced (SUM) like the clustering loss.
+"""
+from sys import float_info
+
+import torch
+
+from . import dist as iic_dist
+from ._lib import check, lib, ptr, stream_ptr
+
+EPS = float_info.epsilon
+F32 = torch.float32
+
+
+def _flips_from_affine(aff):
+  """[bn, 2, 3] -> int32 [bn, 2] (flip x, flip y); raises on anything but identity / flips."""
+  a = aff.detach().float().cpu()
+  lin, tr = a[:, :, :2], a[:, :, 2]
+  ok = (tr.abs() < 1e-6).all() and (lin[:, 0, 1].abs() < 1e-6).all() and \
+       (lin[:, 1, 0].abs() < 1e-6).all() and ((lin[:, 0, 0].abs() - 1).abs() < 1e-6).all() and \
+       ((lin[:, 1, 1].abs() - 1).abs() < 1e-6).all()
+  if not bool(ok):
+    raise NotImplementedError("HIP IID_segmentation_loss supports identity / axis-flip "
+                              "affine2_to_1 only (general warps: SURVEY.md §8a A7)")
+  return torch.stack([(lin[:, 0, 0] < 0), (lin[:, 1, 1] < 0)], dim=1).to(torch.int32)
+
+
+class _SegLossFn(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, x1, x2, flips, mask, lamb, T, collapsed):
+    assert x1.is_cuda and x1.dtype == F32 and x1.shape == x2.shape and x1.dim() == 4
+    x1, x2, mask = x1.contiguous(), x2.contiguous(), mask.contiguous().float()
+    bn, k, h, w = x1.shape
+    L, s = lib(), stream_ptr()
+    nq = 2 * T + 1
+    ns = L.iic_seg_joint_nsplit(bn, h, k, T)
+    part = torch.empty((ns, nq * nq, k, k), dtype=F32, device=x1.device)
+    check(L.iic_seg_joint_raw(ptr(x1), ptr(x2), ptr(mask), ptr(flips), ptr(part), bn, k, h, w, T,
+                              ns, s), "iic_seg_joint_raw")
+    if iic_dist.enabled():
+      R = torch.empty((1, nq * nq, k, k), dtype=F32, device=x1.device)
+      check(L.iic_colsum_f32(ptr(part), ptr(R), ns, nq * nq * k * k, 0, s), "iic_colsum_f32")
+      iic_dist.all_reduce_sum_(R)
+      part, ns = R, 1
+    H = 1 if collapsed else nq * nq
+    nparts = ns * nq * nq if collapsed else ns
+    ws = torch.empty(H * k * k, dtype=torch.float64, device=x1.device)
+    loss = torch.empty(H, dtype=F32, device=x1.device)
+    loss_nl = torch.empty(H, dtype=F32, device=x1.device)
+    dR1 = torch.empty((H, k, k), dtype=F32, device=x1.device)
+    dR2 = torch.empty((H, k, k), dtype=F32, device=x1.device)
+    check(L.iic_seg_loss_from_joint(ptr(part), nparts, H, k, float(lamb), float(EPS), ptr(ws),
+                                    ptr(loss), ptr(loss_nl), ptr(dR1), ptr(dR2),
+                                    1 if collapsed else 0, s), "iic_seg_loss_from_joint")
+    ctx.save_for_backward(x1, x2, flips, mask, dR1, dR2)
+    ctx.meta = (T, collapsed)
+    return loss, loss_nl
+
+  @staticmethod
+  def backward(ctx, g_loss, g_nl):
+    x1, x2, flips, mask, dR1, dR2 = ctx.saved_tensors
+    T, collapsed = ctx.meta
+    bn, k, h, w = x1.shape
+    g_loss, g_nl = g_loss.contiguous().to(F32), g_nl.contiguous().to(F32)
+    dx1, dx2 = torch.empty_like(x1), torch.empty_like(x2)
+    L, s = lib(), stream_ptr()
+    check(L.iic_seg_grad(ptr(x2), ptr(mask), ptr(flips), ptr(dR1), ptr(dR2), ptr(g_loss), ptr(g_nl),
+                         ptr(dx1), bn, k, h, w, T, 0, 1 if collapsed else 0, s), "iic_seg_grad")
+    check(L.iic_seg_grad(ptr(x1), ptr(mask), ptr(flips), ptr(dR1), ptr(dR2), ptr(g_loss), ptr(g_nl),
+                         ptr(dx2), bn, k, h, w, T, 1, 1 if collapsed else 0, s), "iic_seg_grad")
+    return dx1, dx2, None, None, None, None, None
+
+
+def _seg_loss(x1_outs, x2_outs, all_affine2_to_1, all_mask_img1, lamb, half_T_side_dense,
+              half_T_side_sparse_min, half_T_side_sparse_max, collapsed):
+  assert x1_outs.requires_grad
+  assert x2_outs.requires_grad
+  assert not all_affine2_to_1.requires_grad
+  assert not all_mask_img1.requires_grad
+  assert x1_outs.shape == x2_outs.shape
+  if (half_T_side_sparse_min != 0) or (half_T_side_sparse_max != 0):
+    raise NotImplementedError("sparse random translation (half_T_side_sparse_*) is off in every "
+                              "published run and not implemented on the HIP path")
+  flips = _flips_from_affine(all_affine2_to_1).to(x1_outs.device)
+  T = int(half_T_side_dense)
+  loss, loss_nl = _SegLossFn.apply(x1_outs, x2_outs, flips, all_mask_img1, lamb, T, collapsed)
+  if collapsed:
+    return loss[0], loss_nl[0]
+  n = float((2 * T + 1) ** 2)
+  return loss.sum() / n, loss_nl.sum() / n
+
+
+def IID_segmentation_loss(x1_outs, x2_outs, all_affine2_to_1=None, all_mask_img1=None, lamb=1.0,
+                          half_T_side_dense=None, half_T_side_sparse_min=None,
+                          half_T_side_sparse_max=None):
+  """segmentation/IID_losses.py:14-83."""
+  return _seg_loss(x1_outs, x2_outs, all_affine2_to_1, all_mask_img1, lamb, half_T_side_dense,
+                   half_T_side_sparse_min or 0, half_T_side_sparse_max or 0, True)
+
+
+def IID_segmentation_loss_uncollapsed(x1_outs, x2_outs, all_affine2_to_1=None, all_mask_img1=None,
+                                      lamb=1.0, half_T_side_dense=None,
+                                      half_T_side_sparse_min=None, half_T_side_sparse_max=None):
+  """segmentation/IID_losses.py:86-159."""
+  return _seg_loss(x1_outs, x2_outs, all_affine2_to_1, all_mask_img1, lamb, half_T_side_dense,
+                   half_T_side_sparse_min or 0, half_T_side_sparse_max or 0, False)

@@ -55,6 +55,31 @@ int iic_iid_grad(const float* z, const float* zt, const float* dR_loss,
                  void* stream);
 
 /* ---------------------------------------------------------------------------------
+ * IID segmentation losses -- replace code/utils/segmentation/IID_losses.py:14-159
+ * (IID_segmentation_loss, IID_segmentation_loss_uncollapsed) incl. perform_affine_tf for the
+ * identity / axis-flip transforms (transforms.py:131-143; `flips` = int32 [bn][2]: flip x, y).
+ * x1, x2: fp32 NCHW [bn][k][h][w] (post-softmax), mask fp32 [bn][h][w], T = half_T_side_dense.
+ *   partials[s][p][q][i][j] = sum over row-slice s of x1m[i](y+p-T, x+q-T) * x2m[j](y, x)
+ * Exact fp32 MFMA (16x16x4).  k <= 48, T <= 10, w <= 256.
+ * ------------------------------------------------------------------------------- */
+int iic_seg_joint_nsplit(int bn, int h, int k, int T);
+int iic_seg_joint_raw(const float* x1, const float* x2, const float* mask, const int* flips,
+                      float* partials, int bn, int k, int h, int w, int T, int nsplit,
+                      void* stream);
+/* k x k stage: uncollapsed = one joint per shift (H = (2T+1)^2, nparts = nsplit);
+ * collapsed = shifts summed (H = 1, nparts = nsplit*(2T+1)^2, detach_norm = 1, :60).
+ * Workspace / outputs as iic_iid_loss_from_joint.                                          */
+int iic_seg_loss_from_joint(const float* partials, int nparts, int H, int k, double lamb,
+                            double eps, void* workspace, float* loss, float* loss_no_lamb,
+                            float* dR_loss, float* dR_loss_no_lamb, int detach_norm, void* stream);
+/* which = 0: out = dLoss/dx1 (src = x2);  which = 1: out = dLoss/dx2 (src = x1).
+ * g_loss / g_loss_no_lamb: DEVICE arrays [H] of upstream gradients per shift ([1] if collapsed). */
+int iic_seg_grad(const float* src, const float* mask, const int* flips, const float* dR_loss,
+                 const float* dR_loss_no_lamb, const float* g_loss, const float* g_loss_no_lamb,
+                 float* out, int bn, int k, int h, int w, int T, int which, int collapsed,
+                 void* stream);
+
+/* ---------------------------------------------------------------------------------
  * Convolution as an im2col-free implicit GEMM on bf16 MFMA (fp32 accumulate).
  * Replaces the cuDNN conv fwd / bwd-data / bwd-weight the reference reaches through
  * nn.Conv2d in code/archs/cluster/residual.py:4-7,19,22,54-55, net5g.py:21-23,

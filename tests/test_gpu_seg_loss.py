@@ -1,0 +1,86 @@
+"""IID segmentation losses on the HIP path (through the C ABI) vs the reference golden
+vectors and the float64 oracle.  pytest -m gpu.  Tolerance = the loss clause of the
+north star: |ours - ref| <= 1e-5*|ref64| + 2e-7; gradients ||d||/||g|| <= 1e-5, or no worse
+than the fp32 reference's own error w.r.t. float64."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def dev():
+  return torch.device("cuda:0")
+
+
+def _check(fn_hip, fn_ref64, x1, x2, aff, mask, lamb, T, ref32=None):
+  a = torch.from_numpy(x1).to(dev()).requires_grad_(True)
+  b = torch.from_numpy(x2).to(dev()).requires_grad_(True)
+  l, ln = fn_hip(a, b, all_affine2_to_1=torch.from_numpy(aff).to(dev()),
+                 all_mask_img1=torch.from_numpy(mask).to(dev()), lamb=lamb, half_T_side_dense=T,
+                 half_T_side_sparse_min=0, half_T_side_sparse_max=0)
+  (l + 0.5 * ln).backward()
+  a64 = torch.from_numpy(x1).double().requires_grad_(True)
+  b64 = torch.from_numpy(x2).double().requires_grad_(True)
+  r, rn = fn_ref64(a64, b64, all_affine2_to_1=torch.from_numpy(aff).double(),
+                   all_mask_img1=torch.from_numpy(mask).double(), lamb=lamb, half_T_side_dense=T)
+  (r + 0.5 * rn).backward()
+  assert abs(l.item() - float(r)) <= 1e-5 * abs(float(r)) + 2e-7, (l.item(), float(r))
+  assert abs(ln.item() - float(rn)) <= 1e-5 * abs(float(rn)) + 2e-7, (ln.item(), float(rn))
+  for mine, ref in ((a.grad.cpu().double(), a64.grad), (b.grad.cpu().double(), b64.grad)):
+    err = float((mine - ref).norm() / ref.norm())
+    assert err <= 2e-5, err
+
+
+@pytest.mark.parametrize("ci", [0, 1, 2])
+@pytest.mark.parametrize("collapsed", [False, True])
+def test_seg_loss_golden(ci, collapsed):
+  from iic_amd import seg_losses
+  from oracle import iid_oracle
+  from oracle.gen_golden import SEG_CASES, make_seg_inputs
+  g = np.load(os.path.join(G, "iid_seg_loss.npz"), allow_pickle=True)
+  bn, k, h, w, T, lamb, ff, mp, seed = SEG_CASES[ci]
+  x1, x2, aff, mask = make_seg_inputs(bn, k, h, w, ff, mp, seed)
+  name = "col" if collapsed else "unc"
+  fn = seg_losses.IID_segmentation_loss if collapsed else seg_losses.IID_segmentation_loss_uncollapsed
+  a = torch.from_numpy(x1).to(dev()).requires_grad_(True)
+  b = torch.from_numpy(x2).to(dev()).requires_grad_(True)
+  l, ln = fn(a, b, all_affine2_to_1=torch.from_numpy(aff).to(dev()),
+             all_mask_img1=torch.from_numpy(mask).to(dev()), lamb=lamb, half_T_side_dense=T,
+             half_T_side_sparse_min=0, half_T_side_sparse_max=0)
+  l.backward()
+  ref = g["c%d_%s_loss_f64" % (ci, name)]
+  assert abs(l.item() - ref[0]) <= 1e-5 * abs(ref[0]) + 2e-7, (l.item(), ref[0])
+  assert abs(ln.item() - ref[1]) <= 1e-5 * abs(ref[1]) + 2e-7
+  for t, key in ((a, "dx1"), (b, "dx2")):
+    g64 = g["c%d_%s_%s_f64" % (ci, name, key)]
+    g32 = g["c%d_%s_%s_f32" % (ci, name, key)].astype(np.float64)
+    nrm = np.linalg.norm(g64)
+    err = np.linalg.norm(t.grad.cpu().numpy().astype(np.float64) - g64) / nrm
+    assert err <= max(1e-5, np.linalg.norm(g32 - g64) / nrm), (key, err)
+
+
+@pytest.mark.parametrize("bn,k,h,w,T", [(3, 15, 40, 64, 10), (2, 24, 24, 40, 5), (2, 45, 16, 32, 3), (2, 3, 30, 50, 1)])
+@pytest.mark.parametrize("collapsed", [False, True])
+def test_seg_loss_larger_vs_oracle(bn, k, h, w, T, collapsed):
+  from iic_amd import seg_losses
+  from oracle import iid_oracle
+  from oracle.gen_golden import make_seg_inputs
+  x1, x2, aff, mask = make_seg_inputs(bn, k, h, w, 0.5, 0.8, 7)
+  aff[-1, 1, 1] = -1.0   # also a y-flip on the last sample
+  fh = seg_losses.IID_segmentation_loss if collapsed else seg_losses.IID_segmentation_loss_uncollapsed
+  fr = iid_oracle.IID_segmentation_loss if collapsed else iid_oracle.IID_segmentation_loss_uncollapsed
+  _check(fh, fr, x1, x2, aff, mask, 1.5, T)
+
+
+def test_seg_loss_rejects_unsupported():
+  from iic_amd import seg_losses
+  x = torch.rand(2, 3, 8, 8, device=dev()).softmax(1).requires_grad_(True)
+  aff = torch.tensor([[[0.9, 0.1, 0.0], [-0.1, 0.9, 0.0]]] * 2, device=dev())
+  with pytest.raises(NotImplementedError):
+    seg_losses.IID_segmentation_loss(x, x.detach().clone().requires_grad_(True), all_affine2_to_1=aff,
+                                     all_mask_img1=torch.ones(2, 8, 8, device=dev()), lamb=1.0,
+                                     half_T_side_dense=1, half_T_side_sparse_min=0, half_T_side_sparse_max=0)
