@@ -68,6 +68,11 @@ _SIGNATURES = {
   "iic_avgpool_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
   "iic_avgpool_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
   "iic_gemm_f32": (c_int, [_P, c_long, c_long, _P, c_long, c_long, _P, _P, c_long, c_int, c_int, c_int, c_int, _P]),
+  "iic_gemm_f32_splitk": (c_int, [_P, c_long, c_long, _P, c_long, c_long, _P, c_long, c_int, c_int, c_int, c_int, _P]),
+  "iic_seg_window_gather": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+  "iic_seg_window_scatter": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+  "iic_bilinear_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+  "iic_bilinear_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
   "iic_softmax_fwd": (c_int, [_P, _P, c_int, c_int, _P]),
   "iic_softmax_bwd": (c_int, [_P, _P, _P, c_int, c_int, _P]),
   "iic_colsum_f32": (c_int, [_P, _P, c_int, c_int, c_int, _P]),

@@ -63,7 +63,14 @@ __global__ __launch_bounds__(64) void gemm_f32_kernel(const float* __restrict__ 
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // split-K: blockIdx.z owns an (even-aligned) slice of K and atomically adds into C
+  const int nz = gridDim.z;
   int k = 0;
+  if (nz > 1) {
+    const int per = (((K + nz - 1) / nz) + 1) & ~1;
+    k = blockIdx.z * per;
+    K = min(K, k + per);
+  }
   for (; k + 8 <= K; k += 8) {
     float a[4], b[4];
 #pragma unroll
@@ -87,10 +94,14 @@ __global__ __launch_bounds__(64) void gemm_f32_kernel(const float* __restrict__ 
   for (int r = 0; r < 16; ++r) {
     const int row = m0 + mfma32_row(r, lane);
     if (row < M && col < Nn) {
-      float v = acc[r] + bv;
       float* o = Cm + (long)row * scm + col;
-      if (accumulate) v += *o;
-      *o = v;
+      if (nz > 1) {
+        atomicAdd(o, acc[r] + (blockIdx.z == 0 ? bv : 0.f));
+      } else {
+        float v = acc[r] + bv;
+        if (accumulate) v += *o;
+        *o = v;
+      }
     }
   }
 }
@@ -166,6 +177,17 @@ int iic_gemm_f32(const float* A, long sam, long sak, const float* B, long sbk, l
   dim3 grid((M + 31) / 32, (Nn + 31) / 32);
   hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(64), 0, (hipStream_t)stream, A, sam, sak, B, sbk,
                      sbn, bias, C, scm, M, Nn, K, accumulate);
+  return iic_launch_status();
+}
+
+/* split-K variant: C must be zero-initialised (or hold the value to accumulate onto); the K
+ * range is cut into `splitk` slices whose partial products are added atomically. */
+int iic_gemm_f32_splitk(const float* A, long sam, long sak, const float* B, long sbk, long sbn,
+                        float* C, long scm, int M, int Nn, int K, int splitk, void* stream) {
+  if (!A || !B || !C || M <= 0 || Nn <= 0 || K <= 0 || splitk < 1) return IIC_ERR_ARG;
+  dim3 grid((M + 31) / 32, (Nn + 31) / 32, splitk);
+  hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(64), 0, (hipStream_t)stream, A, sam, sak, B, sbk,
+                     sbn, (const float*)nullptr, C, scm, M, Nn, K, 1);
   return iic_launch_status();
 }
 

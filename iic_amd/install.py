@@ -26,6 +26,13 @@ PATCHES = [
   ("code.archs", "ClusterNet6cTwoHead", "iic_amd.archs", "ClusterNet6cTwoHead"),
   ("code.archs.cluster", "ClusterNet6c", "iic_amd.archs", "ClusterNet6c"),
   ("code.archs.cluster", "ClusterNet6cTwoHead", "iic_amd.archs", "ClusterNet6cTwoHead"),
+  ("code.archs", "SegmentationNet10a", "iic_amd.archs", "SegmentationNet10a"),
+  ("code.archs", "SegmentationNet10aTwoHead", "iic_amd.archs", "SegmentationNet10aTwoHead"),
+  ("code.archs.segmentation", "SegmentationNet10a", "iic_amd.archs", "SegmentationNet10a"),
+  ("code.archs.segmentation", "SegmentationNet10aTwoHead", "iic_amd.archs", "SegmentationNet10aTwoHead"),
+  ("code.utils.segmentation.IID_losses", "IID_segmentation_loss", "iic_amd.seg_losses", "IID_segmentation_loss"),
+  ("code.utils.segmentation.IID_losses", "IID_segmentation_loss_uncollapsed", "iic_amd.seg_losses",
+   "IID_segmentation_loss_uncollapsed"),
 ]
 
 

@@ -196,6 +196,19 @@ int iic_avgpool_bwd(const float* dfeats, void* din_pt, int N, int H, int W, int 
 int iic_gemm_f32(const float* A, long sam, long sak, const float* B, long sbk, long sbn,
                  const float* bias, float* C, long scm, int M, int Nn, int K, int accumulate,
                  void* stream);
+int iic_gemm_f32_splitk(const float* A, long sam, long sak, const float* B, long sbk, long sbn,
+                        float* C, long scm, int M, int Nn, int K, int splitk, void* stream);
+/* SegmentationNet10a head (net10a.py:44-59): PT feature window <-> fp32 matrix for the 1x1
+ * conv (padding 1) GEMM, and bilinear up-sampling (align_corners=False) fwd / bwd between
+ * pixel-major [N][Hl][Wl][k] and NCHW [N][k][S][S].                                        */
+int iic_seg_window_gather(const void* pt, float* out, int N, int Hw, int Ww, int Hp, int Wp, int off,
+                          int C, void* stream);
+int iic_seg_window_scatter(const float* in, void* pt, int N, int Hw, int Ww, int Hp, int Wp, int off,
+                           int C, void* stream);
+int iic_bilinear_fwd(const float* in_nhwc, float* out_nchw, int N, int Hl, int Wl, int k, int S,
+                     void* stream);
+int iic_bilinear_bwd(const float* dout_nchw, float* din_nhwc, int N, int Hl, int Wl, int k, int S,
+                     void* stream);
 int iic_softmax_fwd(const float* logits, float* probs, int rows, int k, void* stream);
 int iic_softmax_bwd(const float* probs, const float* dprobs, float* dlogits, int rows, int k,
                     void* stream);

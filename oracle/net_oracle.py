@@ -405,3 +405,21 @@ def net6c_forward_bf16emu(params, x, training=True, head="head", num_sub_heads=5
     x = vgg_stage_bf16emu(params, idx, x, 2, dil, pool, first, training)
     first = False
   return heads_forward(params, x.reshape(x.size(0), -1), head, num_sub_heads)
+
+
+def net10a_forward_bf16emu(params, x, input_sz, training=True, head="head", num_sub_heads=1):
+  """SegmentationNet10a with the HIP path's rounding points (trunk bf16 storage, fp32 head)."""
+  layers = vgg_feature_index(NET10A_CFG)
+  first = True
+  for li, (kind, idx, c, dil) in enumerate(layers):
+    if kind != "conv":
+      continue
+    pool = li + 1 < len(layers) and layers[li + 1][0] == "pool"
+    x = vgg_stage_bf16emu(params, idx, x, 1, dil, pool, first, training)
+    first = False
+  outs = []
+  for i in range(num_sub_heads):
+    y = F.conv2d(x, params["%s.heads.%d.0.weight" % (head, i)], padding=1)
+    y = F.softmax(y, dim=1)
+    outs.append(F.interpolate(y, size=input_sz, mode="bilinear", align_corners=False))
+  return outs

@@ -7,12 +7,15 @@ import textwrap
 
 def test_install_rebinds_reference_names(tmp_path, monkeypatch):
   root = tmp_path / "ref"
-  for d in ("code", "code/utils", "code/utils/cluster", "code/archs", "code/archs/cluster"):
+  for d in ("code", "code/utils", "code/utils/cluster", "code/utils/segmentation", "code/archs", "code/archs/cluster",
+            "code/archs/segmentation"):
     (root / d).mkdir(parents=True)
     (root / d / "__init__.py").write_text("")
   (root / "code/utils/cluster/IID_losses.py").write_text("def IID_loss(*a, **k):\n  return 'ref'\n")
   (root / "code/utils/cluster/transforms.py").write_text("def sobel_process(*a, **k):\n  return 'ref'\n")
-  (root / "code/archs/__init__.py").write_text("class ClusterNet5g: pass\nclass ClusterNet5gTwoHead: pass\nclass ClusterNet6c: pass\nclass ClusterNet6cTwoHead: pass\n")
+  (root / "code/archs/__init__.py").write_text("class ClusterNet5g: pass\nclass ClusterNet5gTwoHead: pass\nclass ClusterNet6c: pass\nclass ClusterNet6cTwoHead: pass\nclass SegmentationNet10a: pass\nclass SegmentationNet10aTwoHead: pass\n")
+  (root / "code/archs/segmentation/__init__.py").write_text("class SegmentationNet10a: pass\nclass SegmentationNet10aTwoHead: pass\n")
+  (root / "code/utils/segmentation/IID_losses.py").write_text("def IID_segmentation_loss(*a, **k):\n  return 0\ndef IID_segmentation_loss_uncollapsed(*a, **k):\n  return 0\n")
   (root / "code/archs/cluster/__init__.py").write_text("class ClusterNet5g: pass\nclass ClusterNet5gTwoHead: pass\nclass ClusterNet6c: pass\nclass ClusterNet6cTwoHead: pass\n")
   monkeypatch.syspath_prepend(str(root))
   for k in [k for k in sys.modules if k == "code" or k.startswith("code.")]:
