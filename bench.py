@@ -127,12 +127,17 @@ def main():
   rank = int(os.environ.get("RANK", "0"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
   assert torch.cuda.is_available(), "bench.py needs an MI355X"
+  ndev = torch.cuda.device_count()
+  backend = os.environ.get("IIC_DIST_BACKEND", "nccl")   # "gloo": functional check of the N>1
+  if local_rank >= ndev:                                 # path on a 1-GPU box (ranks share cuda:0)
+    assert backend != "nccl", "one GPU per rank is required with RCCL"
+    local_rank = local_rank % ndev
   torch.cuda.set_device(local_rank)
   dev = torch.device("cuda", local_rank)
   if world > 1:
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("nccl", rank=rank, world_size=world)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     from iic_amd import dist as idist
     idist.enable()
   assert args.gpus == world or world == 1, "launch with torchrun --nproc-per-node == --gpus"

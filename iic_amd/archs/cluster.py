@@ -32,8 +32,9 @@ import os
 
 # Weight-gradient kernels run on a second HIP stream, concurrently with the dependent
 # backward-data / BatchNorm chain of the same block (they only share inputs): two kernels in
-# flight fill each other's tail waves and barrier stalls.  IIC_DUAL_STREAM=0 disables.
-DUAL_STREAM = [os.environ.get("IIC_DUAL_STREAM", "1") != "0"]
+# flight could fill each other's tail waves.  Measured neutral on MI355X (two workgroups of either
+# kernel already fill a CU's registers), so it is opt-in: IIC_DUAL_STREAM=1.
+DUAL_STREAM = [os.environ.get("IIC_DUAL_STREAM", "0") == "1"]   # measured: no gain (CUs are register-full), opt-in
 _SIDE = {}
 
 

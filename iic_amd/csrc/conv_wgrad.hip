@@ -286,13 +286,25 @@ __global__ __launch_bounds__(GATHER ? 256 : 768) void conv_wgrad_kernel(
 }
 
 // dW[co][ci][t] (fp32 OIHW) (+)= sum_s partial[s][t][co][ci]
-__global__ void conv_wgrad_reduce_kernel(const float* __restrict__ partials, int nsplit, int T,
-                                         int Co, int Ci, float* __restrict__ dW, int accumulate) {
+// 8 independent accumulators keep 8 loads in flight per thread (the split loop is otherwise a
+// serial latency chain); reads are coalesced over (t, co, ci), the transposing write is small.
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ partials,
+                                                                int nsplit, int T, int Co, int Ci,
+                                                                float* __restrict__ dW,
+                                                                int accumulate) {
   const long per = (long)T * Co * Ci;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per;
        i += (long)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) s += partials[(long)sp * per + i];
+    float a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = 0.f;
+    int sp = 0;
+    for (; sp + 8 <= nsplit; sp += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += partials[(long)(sp + u) * per + i];
+    }
+    for (; sp < nsplit; ++sp) a[0] += partials[(long)sp * per + i];
+    const float s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     const int ci = (int)(i % Ci);
     const long r = i / Ci;
     const int co = (int)(r % Co), t = (int)(r / Co);

@@ -216,6 +216,19 @@ __global__ __launch_bounds__(512) void stem_bwd_kernel(const float* __restrict__
   float* sY = reinterpret_cast<float*>(smem_raw);   // [2][W][64]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int Ho = H / 2 + 1, Wo = W / 2 + 1;
+  // MODE 1: dy as bf16, TRANSPOSED [64 co][2 rows x WP pixels] so that an MFMA A fragment
+  // (8 consecutive pixels of one channel) is one 16-B LDS read; and the 4 input rows the two
+  // conv rows touch, zero padded, as fp32 [CIN][4][WX].
+  const int WP = (W + 15) & ~15;
+  const int PD = 2 * WP + 8;   // = 8 * odd (WP is a multiple of 16): conflict-free 16-B rows
+  const int WX = WP + 10;
+  bf16_t* sDt = reinterpret_cast<bf16_t*>(smem_raw + (size_t)2 * W * STEM_CO * sizeof(float));
+  float* sXr = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(sDt) +
+                                        (((size_t)STEM_CO * PD * 2 + 15) & ~(size_t)15));
+  if (MODE == 1) {
+    for (int i = threadIdx.x; i < STEM_CO * PD / 2; i += blockDim.x)
+      reinterpret_cast<uint32_t*>(sDt)[i] = 0u;      // pad pixels stay zero forever
+  }
   float wr[2][StemK<CIN>::KS];
   stem_load_w<CIN>(w, lane, wr);
   const int ch0 = lane & 31;
@@ -292,34 +305,47 @@ __global__ __launch_bounds__(512) void stem_bwd_kernel(const float* __restrict__
           const float cb1 = s_cf[2][c8 * 8 + i], cb2 = s_cf[3][c8 * 8 + i], cb3 = s_cf[4][c8 * 8 + i];
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            if (valid[q]) sY[lidx[q] + i] = cb1 * (q == am ? g : 0.f) + cb2 * yv[q] + cb3;
+            if (valid[q])
+              sDt[(c8 * 8 + i) * PD + (q >> 1) * WP + (2 * wo - 1 + (q & 1))] =
+                  f32_to_bf16(cb1 * (q == am ? g : 0.f) + cb2 * yv[q] + cb3);
         }
       }
     }
     if (MODE == 1) {
+      // input rows 2ho-2 .. 2ho+1 (zero outside the image), columns -1 .. WP+8
+      for (int idx = threadIdx.x; idx < CIN * 4 * WX; idx += blockDim.x) {
+        const int c = idx / (4 * WX), r = (idx / WX) & 3, xx = idx % WX;
+        const int yy = 2 * ho - 2 + r, xg = xx - 1;
+        sXr[idx] = (yy >= 0 && yy < H && xg >= 0 && xg < W) ? xin[((long)c * H + yy) * W + xg] : 0.f;
+      }
       __syncthreads();
-      // dW[co][k] += sum_pix dy[pix][co] * patch[pix][k];  this wave: its 32 columns, both rows
-      const int i = lane & 31, kk = lane >> 5;
+      // dW[co][k] += sum_pix dy[pix][co] * patch[pix][k] on bf16 MFMA (32x32x16, fp32 accumulate):
+      //   A[i = co][8 pixels] from sDt, B[8 pixels][j = k] built from sXr.  Wave w owns the pixel
+      //   steps {2w, 2w+1} (its 32 columns) of both rows.
+      const int i = lane & 31, g5 = lane >> 5;
 #pragma unroll
       for (int rs = 0; rs < 2; ++rs) {
-        const int y = 2 * ho - 1 + rs;
         if (!rv[rs]) continue;
-        for (int s = 0; s < 16; ++s) {
-          const int px = wave * 32 + 2 * s + kk;     // this lane's k-slot pixel
-          const bool pv = px < W;
-          const float* d = sY + ((long)rs * W + (pv ? px : 0)) * STEM_CO;
-          const float a0 = pv ? d[i] : 0.f, a1 = pv ? d[i + 32] : 0.f;
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx) {
+          const int p0 = (wave * 2 + sidx) * 16 + 8 * g5;      // this lane's 8 pixels start here
+          if ((wave * 2 + sidx) * 16 >= WP) continue;
+          const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(sDt + (long)i * PD + rs * WP + p0);
+          const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(sDt + (long)(i + 32) * PD + rs * WP + p0);
 #pragma unroll
           for (int t = 0; t < NKT; ++t) {
             const int k = t * 32 + i;
-            float b = 0.f;
-            if (pv && k < K) {
-              const int c = k / 9, dy = (k % 9) / 3 - 1, dx = (k % 3) - 1;
-              const int yy = y + dy, xx = px + dx;
-              if (yy >= 0 && yy < H && xx >= 0 && xx < W) b = xin[((long)c * H + yy) * W + xx];
+            union { bf16x8 v; uint32_t u[4]; } bb;
+            bb.u[0] = bb.u[1] = bb.u[2] = bb.u[3] = 0u;
+            if (k < K) {
+              const int c = k / 9, kh = (k % 9) / 3, kw = k % 3;
+              // conv row y = 2ho-1+rs reads input row y+kh-1 = (2ho-2) + rs + kh; column px+kw-1
+              const float* xr = sXr + (c * 4 + rs + kh) * WX + p0 + kw;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) bb.u[e] = pack_bf16x2(xr[2 * e], xr[2 * e + 1]);
             }
-            dacc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, dacc[0][t], 0, 0, 0);
-            dacc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, dacc[1][t], 0, 0, 0);
+            dacc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bb.v, dacc[0][t], 0, 0, 0);
+            dacc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bb.v, dacc[1][t], 0, 0, 0);
           }
         }
       }
@@ -465,6 +491,11 @@ int iic_stem_apply_pool(const float* x, const float* w, const float* coef, void*
 
 static size_t stem_bwd_lds(int Cin, int W, int nseg, int mode) {
   size_t a = (size_t)2 * W * STEM_CO * sizeof(float);
+  if (mode == 1) {
+    const int WP = (W + 15) & ~15;
+    const int PD = 2 * WP + 8;
+    a += (((size_t)STEM_CO * PD * 2 + 15) & ~(size_t)15) + (size_t)Cin * 4 * (WP + 10) * sizeof(float);
+  }
   size_t b = mode == 0 ? (size_t)64 * nseg * 16 * sizeof(float)
                        : (size_t)nseg * 64 * ((Cin * 9 + 31) / 32) * 32 * sizeof(float);
   return a > b ? a : b;

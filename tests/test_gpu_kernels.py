@@ -391,7 +391,8 @@ def test_stem_forward_backward(cin, S):
   torch.cuda.synchronize()
   assert torch.allclose(db.cpu(), bt.grad, rtol=1e-3, atol=1e-3 * bt.grad.abs().max().item())
   assert torch.allclose(dg.cpu(), gt.grad, rtol=1e-3, atol=1e-3 * gt.grad.abs().max().item())
-  assert (dW.cpu() - wt.grad).abs().max() <= 2e-3 * wt.grad.abs().max().item()
+  # dy and the input patch enter the dW GEMM as bf16 MFMA operands (fp32 accumulate)
+  assert (dW.cpu() - wt.grad).abs().max() <= 4e-3 * wt.grad.abs().max().item()
 
 
 # --------------------------------------------------------------------------------------
