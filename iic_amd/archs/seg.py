@@ -57,7 +57,7 @@ class _SegHeadFn(torch.autograd.Function):
           "iic_gemm_f32_splitk")
     dF = torch.empty((M, C), dtype=F32, device=dout.device)
     ops.gemm_f32(dlog, k, 1, W2, C, 1, dF, C, M, C, k)
-    dx = ops.POOL.alloc(shape, dout.device)
+    dx = ops.POOL.alloc(shape, dout.device, P)
     check(L.iic_seg_window_scatter(ptr(dF), ptr(dx), N, Hw, Ww, Hp, Wp, off, C, s), "iic_seg_window_scatter")
     return dx, dW.view(k, C, 1, 1), None, None
 

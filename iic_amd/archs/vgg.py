@@ -129,7 +129,7 @@ class _FlattenFn(torch.autograd.Function):
   def backward(ctx, dfeat):
     shape, P = ctx.meta
     N, Hp, Wp, C = shape
-    dx = ops.POOL.alloc(shape, dfeat.device)
+    dx = ops.POOL.alloc(shape, dfeat.device, P)
     dx[:, P:Hp - P, P:Wp - P, :] = dfeat.contiguous().view(N, Hp - 2 * P, Wp - 2 * P, C).to(torch.bfloat16)
     return dx, None
 

@@ -21,34 +21,43 @@ F32 = torch.float32
 # `release` once every kernel that reads it has been enqueued (stream-ordered reuse).
 # ------------------------------------------------------------------------------------
 class PTPool(object):
+  """Buffers are keyed by (shape, border P, device): a recycled buffer is only valid for a
+  tensor with the SAME interior/border split (its border must still be zero)."""
+
   def __init__(self):
     self.free = {}
+    self.border = {}          # data_ptr -> P of every buffer this pool created
     self.allocated_bytes = 0
 
-  def alloc(self, shape, device):
-    key = (tuple(shape), str(device))
+  def alloc(self, shape, device, P=1):
+    key = (tuple(shape), int(P), str(device))
     lst = self.free.get(key)
     if lst:
       return lst.pop()
     t = torch.zeros(shape, dtype=BF16, device=device)
+    self.border[t.data_ptr()] = int(P)
     self.allocated_bytes += t.numel() * 2
     return t
 
   def release(self, t):
     if t is None:
       return
-    key = (tuple(t.shape), str(t.device))
+    P = self.border.get(t.data_ptr())
+    if P is None:
+      return                  # not one of ours (e.g. a user tensor): never recycle it
+    key = (tuple(t.shape), P, str(t.device))
     self.free.setdefault(key, []).append(t)
 
   def clear(self):
     self.free.clear()
+    self.border.clear()
 
 
 POOL = PTPool()
 
 
 def pt_alloc(N, H, W, C, P, device):
-  return POOL.alloc((N, H + 2 * P, W + 2 * P, C), device)
+  return POOL.alloc((N, H + 2 * P, W + 2 * P, C), device, P)
 
 
 def pt_from_nchw(x, P):
