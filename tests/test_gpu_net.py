@@ -212,6 +212,68 @@ def test_net5g_96_step_runs_and_decreases_loss():
   assert losses[-1] < losses[0], losses
 
 
+def test_north_star_full_size_properties():
+  """BASELINE.json configs[1] at FULL size (660 pairs, 96x96, k=70, 5 sub-heads), checked
+  through size-independent properties of the domain:
+    * every sub-head row is a distribution (sums to 1, >= 0);
+    * all_imgs = 220 base images replicated 3x (cluster_sobel.py:215-226): BN batch statistics
+      are invariant to exact replication and every kernel treats rows independently, so the
+      replicas' softmax rows must be IDENTICAL (bit-exact);
+    * loss_no_lamb == loss at lamb = 1; the loss is invariant to permuting the pairs;
+    * the IID loss evaluated by the float64 oracle on OUR softmax outputs matches OUR loss to
+      the north-star clause (1e-5 relative + 2e-7);
+    * a 2-way split of the batch reproduces the loss through the raw-joint sum (the DP algebra);
+    * one Adam step changes every parameter and keeps everything finite."""
+  from iic_amd import archs
+  from iic_amd.losses import IID_loss_heads
+  from iic_amd.optim import Adam
+  from iic_amd.transforms import sobel_process
+  from oracle import iid_oracle
+  torch.manual_seed(0)
+  H, K, NP = 5, 70, 660
+  net = archs.ClusterNet5g(_cfg(input_sz=96, num_sub_heads=H, output_k=K)).to(dev()).train()
+  with torch.no_grad():   # un-trivial heads so the loss is not ~0
+    for h in net.head.heads:
+      h[0].weight.normal_(0, 0.3)
+  opt = Adam(net.parameters(), lr=1e-4)
+  g = torch.Generator().manual_seed(5)
+  base = torch.rand(NP // 3, 1, 96, 96, generator=g)
+  base = torch.nn.functional.avg_pool2d(torch.nn.functional.pad(base, (2, 2, 2, 2), mode="replicate"), 5, 1)
+  imgs = base.repeat(3, 1, 1, 1)
+  gain = torch.rand(NP, 1, 1, 1, generator=g) * 0.8 + 0.6
+  imgs_tf = torch.clamp(torch.flip(imgs, dims=[3]) * gain + 0.05 * torch.randn(imgs.shape, generator=g), 0, 1)
+  imgs, imgs_tf = imgs.to(dev()), imgs_tf.to(dev())
+  before = [p.detach().clone() for p in net.parameters()]
+  net.zero_grad()
+  xo = net.forward_packed(sobel_process(imgs, False))       # [660, 5*70]
+  xt = net.forward_packed(sobel_process(imgs_tf, False))
+  assert xo.shape == (NP, H * K) and xt.shape == (NP, H * K)
+  rows = xo.detach().view(NP, H, K)
+  assert float(rows.min()) >= 0 and torch.allclose(rows.sum(2), torch.ones(NP, H, device=dev()), atol=1e-5)
+  rep = xo.detach().view(3, NP // 3, H * K)
+  assert torch.equal(rep[0], rep[1]) and torch.equal(rep[0], rep[2])
+  loss_h, loss_nl_h = IID_loss_heads(xo, xt, lamb=1.0)
+  assert torch.equal(loss_h, loss_nl_h)
+  z = xo.detach().view(NP, H, K).double().cpu().numpy()
+  zt = xt.detach().view(NP, H, K).double().cpu().numpy()
+  perm = torch.randperm(NP, generator=g).to(dev())
+  with torch.no_grad():
+    loss_p, _ = IID_loss_heads(xo.detach()[perm].contiguous(), xt.detach()[perm].contiguous(), lamb=1.0)
+  for h in range(H):
+    ref = iid_oracle.iid_loss_np(z[:, h], zt[:, h], 1.0)[0]
+    assert abs(float(loss_h[h]) - ref) <= 1e-5 * abs(ref) + 2e-7, (h, float(loss_h[h]), ref)
+    assert abs(float(loss_p[h]) - ref) <= 1e-5 * abs(ref) + 2e-7
+    R = iid_oracle.raw_joint_np(z[:330, h], zt[:330, h]) + iid_oracle.raw_joint_np(z[330:, h], zt[330:, h])
+    assert abs(iid_oracle.loss_and_grad_from_raw_np(R, 1.0)[0] - ref) < 1e-12
+  loss = loss_h.mean()
+  loss.backward()
+  assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in net.parameters())
+  opt.step()
+  assert np.isfinite(loss.item()) and loss.item() <= 1e-6   # loss = -MI <= 0
+  changed = [bool((p.detach() != b).any()) for p, b in zip(net.parameters(), before)]
+  assert all(changed) and all(bool(torch.isfinite(p).all()) for p in net.parameters())
+
+
 @pytest.mark.parametrize("layer,bidx,cin,planes,stride,H", [
   (1, 0, 64, 64, 1, 17), (2, 0, 64, 128, 2, 17), (3, 1, 256, 256, 1, 5), (4, 0, 256, 512, 2, 13)])
 def test_basic_block_teacher_forced(layer, bidx, cin, planes, stride, H):
