@@ -67,7 +67,11 @@ class ConvTimer(object):
       r = timer._orig(g, x_pt, w_t, out_pt, stats, res_grad, res_act, accumulate)
       e1.record()
       flops = 2.0 * g.N * g.MY * g.MX * g.Cout * g.Cin * g.ntaps
-      timer.records.append((e0, e1, flops))
+      # algorithmic HBM bytes: read the input rows once, write (or read-modify-write) the
+      # output rows, read the weight slice once -- bf16
+      rows = float(g.N * g.MY * g.MX)
+      abytes = 2.0 * (rows * g.Cin + rows * g.Cout + g.ntaps * g.Cout * g.Cin)
+      timer.records.append((e0, e1, flops, abytes))
       return r
     ops.conv_igemm = timed
 
@@ -78,11 +82,21 @@ class ConvTimer(object):
   def summary(self):
     if not self.records:
       return None
-    tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.records)
-    tot_fl = sum(f for _, _, f in self.records)
+    tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in self.records)
+    tot_fl = sum(f for _, _, f, _ in self.records)
     n = len(self.records)
     return {"launches": n, "avg_us": 1e3 * tot_ms / n, "tflops": tot_fl / (tot_ms * 1e-3) / 1e12,
-            "total_ms": tot_ms}
+            "total_ms": tot_ms, "alg_bytes": sum(b for _, _, _, b in self.records) / n}
+
+
+def pmc_traffic():
+  """HBM bytes per conv_igemm launch from the committed rocprofv3 PMC passes of this same
+  command (tools/pmc_traffic.py; PMC cannot be collected from inside the process), or None."""
+  p = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+  try:
+    return float(json.load(open(p))["conv_igemm_hbm_bytes_per_launch"])
+  except Exception:
+    return None
 
 
 def cpu_baseline(n_pairs=96, steps=3, budget_s=90.0):
@@ -222,9 +236,11 @@ def main():
       s = timer.summary()
       if s:
         out["roofline"] = {
-          "bound": "mfma", "kernel": "conv_igemm_kernel (fwd + bwd-data implicit GEMM, bf16 MFMA)",
+          "bound": "mfma", "kernel": "conv_igemm_kernel + conv_igemm_bd_kernel (fwd + bwd-data implicit GEMM, bf16 MFMA)",
           "achieved": s["tflops"], "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-          "frac": s["tflops"] / BF16_PEAK_TFLOPS, "traffic": None,
+          "frac": s["tflops"] / BF16_PEAK_TFLOPS, "traffic": pmc_traffic(),
+          "traffic_unit": "HBM bytes per launch (PMC, profiles/r01_pmc_traffic.json)",
+          "algorithmic_bytes_per_launch": s["alg_bytes"],
           "launches_timed": s["launches"], "avg_launch_us": s["avg_us"],
           "kernel_ms_per_step": s["total_ms"] / args.steps,
           "step_algorithmic_tflops": value / world * FLOP_PER_PAIR / 1e12,

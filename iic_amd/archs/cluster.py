@@ -72,7 +72,7 @@ class _ConvHolder(object):
     w = self.conv.weight
     key = (w.data_ptr(), w._version, _WEIGHTS_EPOCH[0])
     if key != self._wkey:
-      self._w = ops.weight_prep(w.detach(), want_bwd=True)
+      self._w = ops.PreppedWeights(w.detach())
       self._wkey = key
     return self._w
 

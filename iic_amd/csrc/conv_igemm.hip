@@ -21,39 +21,8 @@
 // immediate-offset k-steps.  1-tap convs (1x1 stride-2 downsample) skip the patch and gather
 // the 128 rows' own pixels.
 #include "common.h"
+#include "conv_tile.h"
 #include "../../include/iic_hip.h"
-
-#define ROWB 144   // LDS row pitch in bytes: 128 B of data + 16 B pad.  144*r mod 256 visits all
-                   // sixteen 16-B slots over 16 consecutive rows => the 16-lane groups of
-                   // ds_read_b128 are conflict-free, and every k-step is an IMMEDIATE offset
-                   // (ks*32 B) from one per-tap row address: no address VALU in the MFMA loop.
-
-// Stage the input patch (NP pixels x 64 channels) or, in gather mode (1-tap convs), the 128
-// rows' own pixels.  4 independent 16-B loads in flight per thread.
-template <bool GATHER, int NTHREADS>
-__device__ __forceinline__ void igemm_load_patch(unsigned char* sA, const bf16_t* __restrict__ in,
-                                                 int Cin, int c0, int p_lo, int npix,
-                                                 int in_pixels, const int* s_pin, int tid) {
-  const int n8 = npix * 8;
-  for (int base = 0; base < n8; base += NTHREADS * 4) {
-    u32x4 v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int idx = base + u * NTHREADS + tid;
-      v[u] = (u32x4){0u, 0u, 0u, 0u};
-      if (idx < n8) {
-        const long p = GATHER ? (long)s_pin[idx >> 3] : (long)p_lo + (idx >> 3);
-        if (p < in_pixels) v[u] = *reinterpret_cast<const u32x4*>(in + (p * Cin + c0 + (idx & 7) * 8));
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int idx = base + u * NTHREADS + tid;
-      if (idx < n8) *reinterpret_cast<u32x4*>(sA + (idx >> 3) * ROWB + (idx & 7) * 16) = v[u];
-    }
-  }
-}
-
 
 template <int BN, bool GATHER, bool ABL, int BM>
 __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv_igemm_kernel(
@@ -82,16 +51,8 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv_igemm_kernel(
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, g5 = lane >> 5;
 
-  // XCD-aware tile order: blocks b, b+8, b+16.. share an XCD (observed dispatch); give each
-  // XCD a contiguous range of tiles so neighbouring M-tiles (shared halo, shared weights)
-  // hit the same L2.  Bijective for any grid size.
   const int nt = g.Cout / BN;
-  const int nwg = num_mtiles * nt;
-  int tix;
-  {
-    const int b = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = b & 7, idx = b >> 3;
-    tix = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
+  const int tix = xcd_tile_index(blockIdx.x, num_mtiles * nt);
   const int mtile = tix / nt, ntile = tix - mtile * nt;
   const int n0 = ntile * BN;
   const int M = g.N * g.MY * g.MX;          // < 2^31 (checked on the host)
@@ -302,38 +263,7 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv_igemm_kernel(
         sC[row * CLD + col] = f32_to_bf16(acc[ms][ns][r]);
       }
   __syncthreads();
-  for (int idx = tid; idx < BM * (BN / 8); idx += NTHREADS) {
-    const int row = idx / (BN / 8), ch = idx - row * (BN / 8);
-    const int po = s_pout[row];
-    if (po < 0) continue;
-    uint4 v = *reinterpret_cast<const uint4*>(sC + row * CLD + ch * 8);
-    const long o = (long)po * g.Cout + n0 + ch * 8;
-    if (accumulate || res_grad) {
-      uint32_t vv[4] = {v.x, v.y, v.z, v.w};
-      float f[8];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { f[2 * i] = bf16lo(vv[i]); f[2 * i + 1] = bf16hi(vv[i]); }
-      if (accumulate) {
-        const uint4 ov = *reinterpret_cast<const uint4*>(out + o);
-        const uint32_t oo[4] = {ov.x, ov.y, ov.z, ov.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { f[2 * i] += bf16lo(oo[i]); f[2 * i + 1] += bf16hi(oo[i]); }
-      }
-      if (res_grad) {
-        const uint4 gv = *reinterpret_cast<const uint4*>(res_grad + o);
-        const uint4 av = *reinterpret_cast<const uint4*>(res_act + o);
-        const uint32_t gg[4] = {gv.x, gv.y, gv.z, gv.w}, aa[4] = {av.x, av.y, av.z, av.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (bf16lo(aa[i]) > 0.f) f[2 * i] += bf16lo(gg[i]);
-          if (bf16hi(aa[i]) > 0.f) f[2 * i + 1] += bf16hi(gg[i]);
-        }
-      }
-      v = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]),
-                     pack_bf16x2(f[6], f[7]));
-    }
-    *reinterpret_cast<uint4*>(out + o) = v;
-  }
+  igemm_store_tile<BN, BM, NTHREADS>(sC, s_pout, out, res_grad, res_act, accumulate, g.Cout, n0, tid);
 }
 
 // fp32 OIHW -> bf16 [T][Co][Ci] and [T][Ci][Co]

@@ -1,0 +1,294 @@
+// "Weights-direct" implicit-GEMM convolution for gfx950 (Cout % 128 == 0): the second
+// generation of conv_igemm.hip's kernel for the deep layers.
+//
+// Replaces the cuDNN kernels behind nn.Conv2d in
+//   /root/reference/code/archs/cluster/residual.py:4-7,19,22,54-55  (3x3 s1/s2, 1x1 s2)
+//   /root/reference/code/archs/cluster/vgg.py:24-26                 (5x5, dilated 3x3)
+//
+// What conv_igemm_kernel pays per 16 MFMAs per wave: a 16 KB weight tile written to LDS by
+// ds_write_b128 (13 LDS cycles each), 16 ds_read_b128 and a workgroup barrier.  Here
+//   * the weights never touch LDS: iic_weight_prep_frag stores them in MFMA B-fragment order
+//     ([tap][64-ch chunk][32 couts][k-step][lane][8 bf16]), so one global_load_dwordx4 per lane
+//     IS a B operand and a wave-instruction reads 1 KB contiguous from L2.  A ring of the next
+//     iteration's 8 fragments is kept in flight in registers;
+//   * the input patch (all pixels a 256-row tile touches over all taps, 64 channels) is the only
+//     LDS resident, read-only for a whole chunk => barriers only at chunk boundaries
+//     (every ntaps*4 k-steps) instead of every tap;
+//   * wave tile 128(M) x 64(N): 4 A-fragment reads + 2 B loads feed 8 MFMAs (LDS bytes per FLOP
+//     halved again); workgroup = 256 x 128 tile, 4 waves as 2(M) x 2(N), 2 workgroups per CU.
+// Geometry, PT layout, fused BN statistics / residual-gradient epilogue: as conv_igemm.hip.
+#include "common.h"
+#include "conv_tile.h"
+#include "../../include/iic_hip.h"
+
+#define BD_BM 256
+#define BD_BN 128
+#define BD_THREADS 256
+
+template <bool GATHER>
+__global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
+    const iic_conv_geom g, const bf16_t* __restrict__ in, const unsigned char* __restrict__ wfrag,
+    bf16_t* __restrict__ out, float* __restrict__ stats, const bf16_t* __restrict__ res_grad,
+    const bf16_t* __restrict__ res_act, int accumulate, int num_mtiles, int lds_a_bytes) {
+  constexpr int CLD = BD_BN + 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned char* sA = smem_raw;                                   // [NP256][ROWB]
+  int* s_pin = reinterpret_cast<int*>(smem_raw + lds_a_bytes);     // [256]
+  int* s_pout = s_pin + BD_BM;                                     // [256]
+  float* s_red = reinterpret_cast<float*>(s_pout + BD_BM);         // [2 wm][2][128]
+  bf16_t* sC = reinterpret_cast<bf16_t*>(smem_raw);                // epilogue reuse of sA
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, g5 = lane >> 5;
+
+  const int nt = g.Cout / BD_BN;
+  const int tix = xcd_tile_index(blockIdx.x, num_mtiles * nt);
+  const int mtile = tix / nt, ntile = tix - mtile * nt;
+  const int n0 = ntile * BD_BN;
+  const int M = g.N * g.MY * g.MX;
+  const int m0 = mtile * BD_BM;
+  const int in_pixels = g.N * g.in_Hp * g.in_Wp;
+
+  const int v_tapoff = g.tap_off[lane & (IIC_MAX_TAPS - 1)];
+  const int v_tapw = g.tap_w[lane & (IIC_MAX_TAPS - 1)];
+
+  {
+    int m = m0 + tid;
+    const bool valid = m < M;
+    if (!valid) m = M - 1;
+    const int plane = g.MY * g.MX;
+    const int n = m / plane;
+    const int r = m - n * plane;
+    const int y = r / g.MX, x = r - y * g.MX;
+    s_pin[tid] = (n * g.in_Hp + y * g.sy + g.oy) * g.in_Wp + x * g.sx + g.ox;
+    s_pout[tid] = valid ? (n * g.out_Hp + y * g.ty + g.py) * g.out_Wp + x * g.tx + g.px : -1;
+  }
+  __syncthreads();
+  const int p_lo = s_pin[0];
+  const int npix = GATHER ? BD_BM : g.NP256;
+  int arow[4];
+#pragma unroll
+  for (int ms = 0; ms < 4; ++ms) {
+    const int row = wm * 128 + ms * 32 + l31;
+    arow[ms] = (GATHER ? row : (s_pin[row] - p_lo)) * ROWB + g5 * 16;
+  }
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+    for (int ns = 0; ns < 2; ++ns)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ms][ns][r] = 0.f;
+
+  const int nchunks = g.Cin >> 6;
+  const int ntaps = g.ntaps;
+  const int NIT = nchunks * ntaps;
+  // this wave's B fragments of iteration (tw, chunk): 2 x 4 KB contiguous
+  const long frag_it = (long)(g.Cout >> 5) * 4096;      // bytes per (tap, chunk)
+  const unsigned char* wb0 = wfrag + (long)((n0 + wn * 64) >> 5) * 4096 + lane * 16;
+  auto frag_ptr = [&](int tap, int chunk) {
+    const int tw = __builtin_amdgcn_readlane(v_tapw, tap);
+    return wb0 + ((long)tw * nchunks + chunk) * frag_it;
+  };
+
+  // ---- prologue ------------------------------------------------------------------------
+  u32x4 Bc[4][2];
+  {
+    const unsigned char* p = frag_ptr(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int ns = 0; ns < 2; ++ns)
+        Bc[ks][ns] = *reinterpret_cast<const u32x4*>(p + ns * 4096 + ks * 1024);
+  }
+  igemm_load_patch<GATHER, BD_THREADS>(sA, in, g.Cin, 0, p_lo, npix, in_pixels, s_pin, tid);
+  __syncthreads();
+
+  // ---- main loop: flat (chunk, tap) iterations; barriers only when the chunk changes ------
+  // Software pipeline, explicit so that the register allocator cannot fold it away:
+  //   A fragments double-buffered (a[ks & 1]): k-step ks issues the LDS reads of k-step ks + 1
+  //   (of the NEXT tap when ks == 3) before its own 8 MFMAs;
+  //   B fragments: right after its MFMAs, k-step ks re-fills Bc[ks] for the next iteration, so 6
+  //   newer loads are always in flight behind the one being waited for (vmcnt(6)).
+  // sched_barrier(0) pins each group: without it the scheduler sinks all 8 loads to the end of
+  // the iteration and recycles the B registers as A temporaries (=> vmcnt(0) every iteration).
+  int tap = 0, chunk = 0;
+  bf16x8 a[2][4];
+  int pcur[4];
+#pragma unroll
+  for (int ms = 0; ms < 4; ++ms) {
+    pcur[ms] = arow[ms] + (GATHER ? 0 : __builtin_amdgcn_readlane(v_tapoff, 0) * ROWB);
+    a[0][ms] = *reinterpret_cast<const bf16x8*>(sA + pcur[ms]);
+  }
+  for (int it = 0; it < NIT; ++it) {
+    int tn = tap + 1, cn = chunk;
+    if (tn == ntaps) { tn = 0; ++cn; }
+    const bool more = (it + 1 < NIT);
+    if (!more) { tn = tap; cn = chunk; }   // the ring always reloads: no branch around a load
+    const unsigned char* nb = frag_ptr(tn, cn);
+    const int toffn = GATHER ? 0 : __builtin_amdgcn_readlane(v_tapoff, tn) * ROWB;
+    int pnext[4];
+#pragma unroll
+    for (int ms = 0; ms < 4; ++ms) pnext[ms] = arow[ms] + toffn;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int cur = ks & 1, nxt = cur ^ 1;
+#pragma unroll
+      for (int ms = 0; ms < 4; ++ms)
+        a[nxt][ms] = (ks < 3) ? *reinterpret_cast<const bf16x8*>(sA + pcur[ms] + (ks + 1) * 32)
+                              : *reinterpret_cast<const bf16x8*>(sA + pnext[ms]);
+      __builtin_amdgcn_sched_barrier(0);   // reads of the NEXT k-step issue before these MFMAs
+      const bf16x8 b0 = __builtin_bit_cast(bf16x8, Bc[ks][0]);
+      const bf16x8 b1 = __builtin_bit_cast(bf16x8, Bc[ks][1]);
+#pragma unroll
+      for (int ms = 0; ms < 4; ++ms) {
+        acc[ms][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][ms], b0, acc[ms][0], 0, 0, 0);
+        acc[ms][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][ms], b1, acc[ms][1], 0, 0, 0);
+      }
+      Bc[ks][0] = *reinterpret_cast<const u32x4*>(nb + ks * 1024);
+      Bc[ks][1] = *reinterpret_cast<const u32x4*>(nb + 4096 + ks * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int ms = 0; ms < 4; ++ms) pcur[ms] = pnext[ms];
+    if (more && tn == 0) {       // next iteration starts a new channel chunk
+      __syncthreads();           // everyone is done reading the patch
+      igemm_load_patch<GATHER, BD_THREADS>(sA, in, g.Cin, cn * 64, p_lo, npix, in_pixels, s_pin, tid);
+      __syncthreads();
+#pragma unroll
+      for (int ms = 0; ms < 4; ++ms) a[0][ms] = *reinterpret_cast<const bf16x8*>(sA + pcur[ms]);
+    }
+    tap = tn;
+    chunk = cn;
+  }
+
+  // ---- epilogue ------------------------------------------------------------------------
+  const bool tail = (m0 + BD_BM > M);
+  if (stats) {
+#pragma unroll
+    for (int ns = 0; ns < 2; ++ns) {
+      float s = 0.f, ss = 0.f;
+#pragma unroll
+      for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[ms][ns][r];
+          if (tail && s_pout[wm * 128 + ms * 32 + mfma32_row(r, lane)] < 0) v = 0.f;
+          s += v;
+          ss += v * v;
+        }
+      s += __shfl_xor(s, 32, 64);
+      ss += __shfl_xor(ss, 32, 64);
+      if (lane < 32) {
+        const int col = wn * 64 + ns * 32 + lane;
+        s_red[(wm * 2 + 0) * BD_BN + col] = s;
+        s_red[(wm * 2 + 1) * BD_BN + col] = ss;
+      }
+    }
+  }
+  __syncthreads();   // all waves finished reading sA; s_red complete
+  if (stats && tid < BD_BN) {
+    float* st = stats + (long)(blockIdx.x % IIC_STAT_STRIPES) * 2 * g.Cout;
+    atomicAdd(st + n0 + tid, s_red[0 * BD_BN + tid] + s_red[2 * BD_BN + tid]);
+    atomicAdd(st + g.Cout + n0 + tid, s_red[1 * BD_BN + tid] + s_red[3 * BD_BN + tid]);
+  }
+#pragma unroll
+  for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+    for (int ns = 0; ns < 2; ++ns)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 128 + ms * 32 + mfma32_row(r, lane);
+        const int col = wn * 64 + ns * 32 + l31;
+        sC[row * CLD + col] = f32_to_bf16(acc[ms][ns][r]);
+      }
+  __syncthreads();
+  igemm_store_tile<BD_BN, BD_BM, BD_THREADS>(sC, s_pout, out, res_grad, res_act, accumulate, g.Cout,
+                                             n0, tid);
+}
+
+// fp32 OIHW -> bf16 MFMA-B-fragment order.  mode 0 (forward operand): GEMM N = Cout, K = Cin;
+// mode 1 (backward-data operand): N = Cin, K = Cout.
+//   out[tap][kchunk][n/32][ks][lane][e] = W[n = j*32 + (lane & 31)][k = kchunk*64 + ks*16 + (lane>>5)*8 + e][tap]
+__global__ void weight_prep_frag_kernel(const float* __restrict__ w, bf16_t* __restrict__ o, int Co,
+                                        int Ci, int T, int mode) {
+  const int Nn = mode ? Ci : Co, Kk = mode ? Co : Ci;
+  const int n32 = Nn >> 5, nchunks = Kk >> 6;
+  const long total = (long)T * Co * Ci;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int e = (int)(i & 7), lane = (int)((i >> 3) & 63), ks = (int)((i >> 9) & 3);
+    long r = i >> 11;
+    const int j = (int)(r % n32);
+    r /= n32;
+    const int kc = (int)(r % nchunks), t = (int)(r / nchunks);
+    const int n = j * 32 + (lane & 31), k = kc * 64 + ks * 16 + (lane >> 5) * 8 + e;
+    const int co = mode ? k : n, ci = mode ? n : k;
+    o[i] = f32_to_bf16(w[((long)co * Ci + ci) * T + t]);
+  }
+}
+
+extern "C" {
+
+static long bd_lds_a(const iic_conv_geom* g) {
+  long a = (long)(g->ntaps == 1 ? BD_BM : g->NP256) * ROWB;
+  long c = (long)BD_BM * (BD_BN + 8) * 2;
+  long m = a > c ? a : c;
+  return (m + 15) & ~15L;
+}
+
+/* 1 if iic_conv_igemm_frag can run this geometry (else use iic_conv_igemm). */
+int iic_conv_igemm_frag_supported(const iic_conv_geom* g) {
+  if (!g) return 0;
+  if (g->Cin % 64 != 0 || g->Cout % BD_BN != 0 || g->ntaps < 1 || g->ntaps > IIC_MAX_TAPS) return 0;
+  if (g->ntaps > 1 && g->NP256 <= 0) return 0;
+  const long lds = bd_lds_a(g) + 2L * BD_BM * 4 + 4L * BD_BN * 4;
+  return lds <= 80 * 1024;      // two workgroups per CU
+}
+
+int iic_conv_igemm_frag(const iic_conv_geom* g, const void* in, const void* wfrag, void* out,
+                        float* stats, const void* res_grad, const void* res_act, int accumulate,
+                        void* stream) {
+  if (!g || !in || !wfrag || !out) return IIC_ERR_ARG;
+  if ((res_grad == nullptr) != (res_act == nullptr)) return IIC_ERR_ARG;
+  if (!iic_conv_igemm_frag_supported(g)) return IIC_ERR_UNSUPPORTED;
+  const long M = (long)g->N * g->MY * g->MX;
+  if (M <= 0) return IIC_ERR_ARG;
+  if (M >= (1L << 31) || (long)g->N * g->in_Hp * g->in_Wp >= (1L << 31)) return IIC_ERR_UNSUPPORTED;
+  const int mt = (int)((M + BD_BM - 1) / BD_BM);
+  const int grid = mt * (g->Cout / BD_BN);
+  const int la = (int)bd_lds_a(g);
+  const long lds = la + 2L * BD_BM * 4 + 4L * BD_BN * 4;
+  hipStream_t s = (hipStream_t)stream;
+#define BD_LAUNCH(GA_)                                                                            \
+  do {                                                                                           \
+    static bool attr = false;                                                                    \
+    if (!attr) {                                                                                 \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bd_kernel<GA_>),       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);         \
+      attr = true;                                                                               \
+    }                                                                                            \
+    hipLaunchKernelGGL((conv_igemm_bd_kernel<GA_>), dim3(grid), dim3(BD_THREADS), lds, s, *g,    \
+                       (const bf16_t*)in, (const unsigned char*)wfrag, (bf16_t*)out, stats,      \
+                       (const bf16_t*)res_grad, (const bf16_t*)res_act, accumulate, mt, la);     \
+  } while (0)
+  if (g->ntaps == 1) BD_LAUNCH(true); else BD_LAUNCH(false);
+  return iic_launch_status();
+}
+
+int iic_weight_prep_frag(const float* w_oihw, void* w_frag, int Cout, int Cin, int T, int bwd,
+                         void* stream) {
+  if (!w_oihw || !w_frag || Cout <= 0 || Cin <= 0 || T <= 0) return IIC_ERR_ARG;
+  const int Nn = bwd ? Cin : Cout, Kk = bwd ? Cout : Cin;
+  if (Nn % 32 != 0 || Kk % 64 != 0) return IIC_ERR_UNSUPPORTED;
+  const long total = (long)T * Cout * Cin;
+  int grid = (int)((total + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(weight_prep_frag_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                     w_oihw, (bf16_t*)w_frag, Cout, Cin, T, bwd ? 1 : 0);
+  return iic_launch_status();
+}
+
+}  // extern "C"

@@ -4,6 +4,7 @@ PyTorch is plumbing here: it owns device memory and the HIP stream; every arithm
 the hot path is a kernel of libiic_hip.so.  All wrappers enqueue on torch's current stream.
 """
 import ctypes
+import os
 
 import torch
 
@@ -81,7 +82,7 @@ def new_stats(C, device):
 # conv
 # ------------------------------------------------------------------------------------
 def weight_prep(w, want_bwd=True):
-  """fp32 OIHW parameter -> (bf16 [T][Co][Ci], bf16 [T][Ci][Co])."""
+  """fp32 OIHW parameter -> (bf16 [T][Co][Ci], bf16 [T][Ci][Co])  (row-major operands)."""
   co, ci, kh, kw = w.shape
   T = kh * kw
   wf = torch.empty((T, co, ci), dtype=BF16, device=w.device)
@@ -90,9 +91,65 @@ def weight_prep(w, want_bwd=True):
   return wf, wb
 
 
+def weight_prep_frag(w, bwd):
+  """fp32 OIHW parameter -> bf16 MFMA-B-fragment order (include/iic_hip.h, iic_weight_prep_frag)."""
+  co, ci, kh, kw = w.shape
+  out = torch.empty((kh * kw * co * ci,), dtype=BF16, device=w.device)
+  check(lib().iic_weight_prep_frag(ptr(w), ptr(out), co, ci, kh * kw, 1 if bwd else 0, stream_ptr()),
+        "iic_weight_prep_frag")
+  return out
+
+
+# IIC_CONV_FRAG=0 keeps every conv on the first-generation kernel (row-major weight operand).
+USE_FRAG = [os.environ.get("IIC_CONV_FRAG", "1") != "0"]
+
+
+class PreppedWeights(object):
+  """bf16 operands of one conv parameter, laid out lazily per consumer kernel.  `pw[0]` is the
+  forward operand, `pw[1]` the backward-data operand (handles accepted by conv_igemm)."""
+
+  def __init__(self, w):
+    self.w = w
+    self._rows = None
+    self._frag = [None, None]
+
+  def rows(self, bwd):
+    if self._rows is None:
+      self._rows = weight_prep(self.w, want_bwd=True)
+    return self._rows[1 if bwd else 0]
+
+  def frag(self, bwd):
+    k = 1 if bwd else 0
+    if self._frag[k] is None:
+      self._frag[k] = weight_prep_frag(self.w, bwd)
+    return self._frag[k]
+
+  def __getitem__(self, i):
+    return WOperand(self, bool(i))
+
+
+class WOperand(object):
+  def __init__(self, pw, bwd):
+    self.pw, self.bwd = pw, bwd
+
+
+def frag_supported(g):
+  return USE_FRAG[0] and bool(lib().iic_conv_igemm_frag_supported(ctypes.byref(g)))
+
+
 def conv_igemm(g, x_pt, w_t, out_pt, stats=None, res_grad=None, res_act=None, accumulate=False):
+  """w_t: a row-major bf16 operand tensor (first-generation kernel) or a WOperand handle
+  (second-generation weights-direct kernel wherever the geometry supports it)."""
+  acc = 1 if accumulate else 0
+  if isinstance(w_t, WOperand):
+    if frag_supported(g):
+      check(lib().iic_conv_igemm_frag(ctypes.byref(g), ptr(x_pt), ptr(w_t.pw.frag(w_t.bwd)),
+                                      ptr(out_pt), ptr(stats), ptr(res_grad), ptr(res_act), acc,
+                                      stream_ptr()), "iic_conv_igemm_frag")
+      return out_pt
+    w_t = w_t.pw.rows(w_t.bwd)
   check(lib().iic_conv_igemm(ctypes.byref(g), ptr(x_pt), ptr(w_t), ptr(out_pt), ptr(stats),
-                             ptr(res_grad), ptr(res_act), 1 if accumulate else 0, stream_ptr()),
+                             ptr(res_grad), ptr(res_act), acc, stream_ptr()),
         "iic_conv_igemm")
   return out_pt
 

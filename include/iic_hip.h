@@ -124,6 +124,21 @@ int iic_conv_wgrad_reduce(const float* partials, int nsplit, int T, int Cout, in
 int iic_weight_prep(const float* w_oihw, void* w_fwd, void* w_bwd, int Cout, int Cin, int T,
                     void* stream);
 
+/* Second-generation kernel for Cout % 128 == 0 (same contract as iic_conv_igemm, same
+ * reference call sites): the weight operand is read straight from L2 in MFMA B-fragment order
+ * and never staged in LDS; 256 x 128 workgroup tiles, barriers only per 64-channel chunk.
+ *   w_frag[tap][k/64][n/32][ks][lane][e] = W[n = (n/32)*32 + (lane & 31)]
+ *                                           [k = (k/64)*64 + ks*16 + (lane >> 5)*8 + e][tap]
+ * with (n, k) = (cout, cin) for the forward operand (bwd = 0) and (cin, cout) for the
+ * backward-data operand (bwd = 1).  iic_conv_igemm_frag_supported: 1 if the geometry can run
+ * here (needs NP256), else callers use iic_conv_igemm with the row-major operand.            */
+int iic_conv_igemm_frag_supported(const iic_conv_geom* g);
+int iic_conv_igemm_frag(const iic_conv_geom* g, const void* in, const void* w_frag, void* out,
+                        float* stats, const void* res_grad, const void* res_act, int accumulate,
+                        void* stream);
+int iic_weight_prep_frag(const float* w_oihw, void* w_frag, int Cout, int Cin, int T, int bwd,
+                         void* stream);
+
 /* ---------------------------------------------------------------------------------
  * BatchNorm2d (train / eval), ReLU, residual add -- replaces nn.BatchNorm2d / nn.ReLU /
  * `out += residual` in residual.py:20-41,56-57, vgg.py:28-30.

@@ -139,6 +139,8 @@ CONV_CASES = [  # cin, cout, K, stride, pad, N, H
   (64, 128, 1, 2, 0, 3, 13),    # 1x1 stride-2 downsample
   (256, 512, 3, 2, 1, 2, 13),   # 4 chunks
   (64, 64, 3, 1, 1, 2, 49),     # wide rows (layer1 geometry)
+  (512, 512, 3, 1, 1, 6, 7),    # 8 chunks, 256-row tail tile (layer4 geometry)
+  (128, 128, 3, 1, 1, 20, 25),  # many tiles (layer2 geometry)
 ]
 
 
@@ -155,11 +157,15 @@ def _force_bm(bm):
   ctypes.CDLL(_lib.LIB_PATH).iic_debug_force_bm(bm)
 
 
-@pytest.mark.parametrize("bm", [0, 256])
+@pytest.mark.parametrize("bm", [0, 256, "frag"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_forward_and_stats(case, bm):
+  """bm: 0 / 256 = first-generation kernel with 128- / 256-row tiles (row-major weights);
+  "frag" = second-generation weights-direct kernel (conv_igemm_bd.hip)."""
   from iic_amd import geom, ops
   cin, cout, K, s, p, N, H = case
+  if bm == "frag":
+    return _conv_forward_and_stats(case, frag=True)
   if bm == 256 and s != 1:
     pytest.skip("256-row tiles are used for stride-1 convs only (LDS footprint)")
   _force_bm(bm)
@@ -169,7 +175,7 @@ def test_conv_forward_and_stats(case, bm):
     _force_bm(0)
 
 
-def _conv_forward_and_stats(case):
+def _conv_forward_and_stats(case, frag=False):
   from iic_amd import geom, ops
   cin, cout, K, s, p, N, H = case
   x, w = _conv_inputs(cin, cout, K, N, H)
@@ -178,10 +184,15 @@ def _conv_forward_and_stats(case):
   Ho = spec.out_size(H)
   g = geom.fwd_geom(spec, N, H, H, 1, 1)
   wf, wb = ops.weight_prep(w.to(dev()))
+  wop = wf
+  if frag:
+    if not ops.frag_supported(g):
+      pytest.skip("geometry not served by the weights-direct kernel (Cout % 128 != 0)")
+    wop = ops.PreppedWeights(w.to(dev()))[0]
   xp = ops.pt_from_nchw(x.to(dev()), 1)
   out = torch.zeros((N, Ho + 2, Ho + 2, cout), dtype=torch.bfloat16, device=dev())
   stats = ops.new_stats(cout, dev())
-  ops.conv_igemm(g, xp, wf, out, stats=stats)
+  ops.conv_igemm(g, xp, wop, out, stats=stats)
   torch.cuda.synchronize()
   got = ops.pt_to_nchw(out, 1).cpu()
   scale = ref.abs().max().item()
@@ -197,9 +208,11 @@ def _conv_forward_and_stats(case):
   assert torch.equal(wb.float().cpu(), bf16_round(w).permute(2, 3, 1, 0).reshape(K * K, cin, cout))
 
 
-@pytest.mark.parametrize("bm", [0, 256])
+@pytest.mark.parametrize("bm", [0, 256, "frag"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_backward_data(case, bm):
+  if bm == "frag":
+    return _conv_backward_data(case, frag=True)
   if bm == 256 and case[3] != 1:
     pytest.skip("256-row tiles are used for stride-1 convs only (LDS footprint)")
   _force_bm(bm)
@@ -209,7 +222,7 @@ def test_conv_backward_data(case, bm):
     _force_bm(0)
 
 
-def _conv_backward_data(case):
+def _conv_backward_data(case, frag=False):
   from iic_amd import geom, ops
   cin, cout, K, s, p, N, H = case
   x, w = _conv_inputs(cin, cout, K, N, H, 1)
@@ -222,6 +235,10 @@ def _conv_backward_data(case):
   spec = geom.ConvSpec(cin, cout, K, s, p)
   geoms = geom.bwd_data_geoms(spec, N, H, H, 1, 1)
   _, wb = ops.weight_prep(w.to(dev()))
+  if frag:
+    if not all(ops.frag_supported(g) for g in geoms):
+      pytest.skip("geometry not served by the weights-direct kernel (Cin % 128 != 0)")
+    wb = ops.PreppedWeights(w.to(dev()))[1]
   dyp = ops.pt_from_nchw(dy.to(dev()), 1)
   dx = torch.zeros((N, H + 2, H + 2, cin), dtype=torch.bfloat16, device=dev())
   for g in geoms:

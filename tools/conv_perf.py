@@ -41,6 +41,8 @@ def main():
   ap.add_argument("--only", type=str, default="")
   ap.add_argument("--ablate", type=int, default=0)
   ap.add_argument("--bm", type=int, default=0)
+  ap.add_argument("--frag", type=int, default=1, help="1: weights-direct kernel where supported (A/B column)")
+  ap.add_argument("--no-wgrad", action="store_true")
   a = ap.parse_args()
   dev = torch.device("cuda:0")
   N = a.n
@@ -69,17 +71,31 @@ def main():
     dx = torch.zeros(N, H + 2, H + 2, cin, device=dev, dtype=torch.bfloat16)
     w = torch.randn(cout, cin, K, K, device=dev) * 0.05
     wf, wb = ops.weight_prep(w)
+    pw = ops.PreppedWeights(w)
     st = ops.new_stats(cout, dev)
     flops = 2.0 * N * Ho * Ho * cout * cin * K * K
     t_f = timeit(lambda: ops.conv_igemm(gf, x, wf, y, stats=st), a.iters)
     t_b = timeit(lambda: [ops.conv_igemm(g, dy, wb, dx) for g in gb], a.iters)
-    t_w = timeit(lambda: ops.conv_wgrad(gf, x, dy, K * K, True), a.iters)
+    t_w = 0.0 if a.no_wgrad else timeit(lambda: ops.conv_wgrad(gf, x, dy, K * K, True), a.iters)
+    extra = ""
+    if a.frag:
+      if ops.frag_supported(gf):
+        t2 = timeit(lambda: ops.conv_igemm(gf, x, pw[0], y, stats=st), a.iters)
+        extra += " | frag fwd %7.1f us %7.1f TF/s" % (t2, flops / t2 / 1e6)
+        tot["fwd2"] = tot.get("fwd2", 0.0) + COUNT[li] * (t2 - t_f)
+      if all(ops.frag_supported(g) for g in gb):
+        t2 = timeit(lambda: [ops.conv_igemm(g, dy, pw[1], dx) for g in gb], a.iters)
+        extra += " | frag bwdD %7.1f us %7.1f TF/s" % (t2, flops / t2 / 1e6)
+        tot["bwd2"] = tot.get("bwd2", 0.0) + COUNT[li] * (t2 - t_b)
     c = COUNT[li]
     tot["fwd"] += c * t_f; tot["bwd"] += c * t_b; tot["wg"] += c * t_w
-    print("%-28s %9.1f %8.1f | %9.1f %8.1f | %9.1f %8.1f | %d" % (
-      name, t_f, flops / t_f / 1e6, t_b, flops / t_b / 1e6, t_w, flops / t_w / 1e6, gf.NP))
+    print("%-28s %9.1f %8.1f | %9.1f %8.1f | %9.1f %8.1f | %d%s" % (
+      name, t_f, flops / t_f / 1e6, t_b, flops / t_b / 1e6, t_w, flops / max(t_w, 1e-9) / 1e6, gf.NP, extra))
   print("per pass (x count): fwd %.2f ms, bwd-data %.2f ms, wgrad(+reduce) %.2f ms; x2 passes = %.2f ms/step" % (
-    tot["fwd"] / 1e3, tot["bwd"] / 1e3, tot["wg"] / 1e3, 2 * sum(tot.values()) / 1e3))
+    tot["fwd"] / 1e3, tot["bwd"] / 1e3, tot["wg"] / 1e3, 2 * (tot["fwd"] + tot["bwd"] + tot["wg"]) / 1e3))
+  if "fwd2" in tot or "bwd2" in tot:
+    print("weights-direct kernel delta per step (x2 passes): fwd %+.2f ms, bwd-data %+.2f ms" % (
+      2 * tot.get("fwd2", 0.0) / 1e3, 2 * tot.get("bwd2", 0.0) / 1e3))
 
 
 if __name__ == "__main__":
