@@ -24,8 +24,14 @@
 #define BD_BM 256
 #define BD_BN 128
 #define BD_THREADS 256
+#ifndef BD_RELOAD_NB
+#define BD_RELOAD_NB 4     // 16-B patch pieces in flight per thread at a chunk boundary (8 spills)
+#endif
 
-template <bool GATHER>
+// ABL: timing-ablation build (tools/conv_perf.py --ablate; results are WRONG by design):
+//   1 = no patch reload at chunk boundaries, 2 = B fragments always from the same address
+//   (L2-hot), 4 = no epilogue, 8 = no chunk-boundary barriers either, 16 = no A-fragment LDS reads.
+template <bool GATHER, int ABL>
 __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
     const iic_conv_geom g, const bf16_t* __restrict__ in, const unsigned char* __restrict__ wfrag,
     bf16_t* __restrict__ out, float* __restrict__ stats, const bf16_t* __restrict__ res_grad,
@@ -103,7 +109,8 @@ __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
       for (int ns = 0; ns < 2; ++ns)
         Bc[ks][ns] = *reinterpret_cast<const u32x4*>(p + ns * 4096 + ks * 1024);
   }
-  igemm_load_patch<GATHER, BD_THREADS>(sA, in, g.Cin, 0, p_lo, npix, in_pixels, s_pin, tid);
+  // prologue: the accumulators are not live yet => 16 pieces (64 VGPRs) in flight per thread
+  igemm_load_patch<GATHER, BD_THREADS, 16>(sA, in, g.Cin, 0, p_lo, npix, in_pixels, s_pin, tid);
   __syncthreads();
 
   // ---- main loop: flat (chunk, tap) iterations; barriers only when the chunk changes ------
@@ -127,7 +134,7 @@ __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
     if (tn == ntaps) { tn = 0; ++cn; }
     const bool more = (it + 1 < NIT);
     if (!more) { tn = tap; cn = chunk; }   // the ring always reloads: no branch around a load
-    const unsigned char* nb = frag_ptr(tn, cn);
+    const unsigned char* nb = (ABL & 2) ? frag_ptr(0, 0) : frag_ptr(tn, cn);
     const int toffn = GATHER ? 0 : __builtin_amdgcn_readlane(v_tapoff, tn) * ROWB;
     int pnext[4];
 #pragma unroll
@@ -137,8 +144,11 @@ __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
       const int cur = ks & 1, nxt = cur ^ 1;
 #pragma unroll
       for (int ms = 0; ms < 4; ++ms)
-        a[nxt][ms] = (ks < 3) ? *reinterpret_cast<const bf16x8*>(sA + pcur[ms] + (ks + 1) * 32)
-                              : *reinterpret_cast<const bf16x8*>(sA + pnext[ms]);
+        if (!(ABL & 16))
+          a[nxt][ms] = (ks < 3) ? *reinterpret_cast<const bf16x8*>(sA + pcur[ms] + (ks + 1) * 32)
+                                : *reinterpret_cast<const bf16x8*>(sA + pnext[ms]);
+        else
+          a[nxt][ms] = a[cur][ms];
       __builtin_amdgcn_sched_barrier(0);   // reads of the NEXT k-step issue before these MFMAs
       const bf16x8 b0 = __builtin_bit_cast(bf16x8, Bc[ks][0]);
       const bf16x8 b1 = __builtin_bit_cast(bf16x8, Bc[ks][1]);
@@ -153,9 +163,10 @@ __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
     }
 #pragma unroll
     for (int ms = 0; ms < 4; ++ms) pcur[ms] = pnext[ms];
-    if (more && tn == 0) {       // next iteration starts a new channel chunk
+    if (more && tn == 0 && !(ABL & 8)) {       // next iteration starts a new channel chunk
       __syncthreads();           // everyone is done reading the patch
-      igemm_load_patch<GATHER, BD_THREADS>(sA, in, g.Cin, cn * 64, p_lo, npix, in_pixels, s_pin, tid);
+      if (!(ABL & 1))
+        igemm_load_patch<GATHER, BD_THREADS, BD_RELOAD_NB>(sA, in, g.Cin, cn * 64, p_lo, npix, in_pixels, s_pin, tid);
       __syncthreads();
 #pragma unroll
       for (int ms = 0; ms < 4; ++ms) a[0][ms] = *reinterpret_cast<const bf16x8*>(sA + pcur[ms]);
@@ -165,6 +176,17 @@ __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
   }
 
   // ---- epilogue ------------------------------------------------------------------------
+  if (ABL & 4) {
+    float t = 0.f;   // keep every accumulator live
+#pragma unroll
+    for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+      for (int ns = 0; ns < 2; ++ns)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[ms][ns][r];
+    if (t == 123.f) out[0] = 1;
+    return;
+  }
   const bool tail = (m0 + BD_BM > M);
   if (stats) {
 #pragma unroll
@@ -230,6 +252,14 @@ __global__ void weight_prep_frag_kernel(const float* __restrict__ w, bf16_t* __r
   }
 }
 
+extern "C" int iic_debug_get_ablate(void);
+// conv_igemm_p64.hip: persistent DMA-fed kernel for the 64 -> 64 channel 3x3 layers
+int iic_p64_supported(const iic_conv_geom* g);
+int iic_p64_launch(const iic_conv_geom* g, const void* in, const void* wfrag, void* out, float* stats,
+                   const void* res_grad, const void* res_act, int accumulate, void* stream);
+static int g_p64_enabled = 1;
+extern "C" void iic_debug_enable_p64(int v) { g_p64_enabled = v; }
+
 extern "C" {
 
 static long bd_lds_a(const iic_conv_geom* g) {
@@ -242,6 +272,7 @@ static long bd_lds_a(const iic_conv_geom* g) {
 /* 1 if iic_conv_igemm_frag can run this geometry (else use iic_conv_igemm). */
 int iic_conv_igemm_frag_supported(const iic_conv_geom* g) {
   if (!g) return 0;
+  if (g_p64_enabled && iic_p64_supported(g)) return 1;
   if (g->Cin % 64 != 0 || g->Cout % BD_BN != 0 || g->ntaps < 1 || g->ntaps > IIC_MAX_TAPS) return 0;
   if (g->ntaps > 1 && g->NP256 <= 0) return 0;
   const long lds = bd_lds_a(g) + 2L * BD_BM * 4 + 4L * BD_BN * 4;
@@ -254,6 +285,8 @@ int iic_conv_igemm_frag(const iic_conv_geom* g, const void* in, const void* wfra
   if (!g || !in || !wfrag || !out) return IIC_ERR_ARG;
   if ((res_grad == nullptr) != (res_act == nullptr)) return IIC_ERR_ARG;
   if (!iic_conv_igemm_frag_supported(g)) return IIC_ERR_UNSUPPORTED;
+  if (g_p64_enabled && iic_p64_supported(g))
+    return iic_p64_launch(g, in, wfrag, out, stats, res_grad, res_act, accumulate, stream);
   const long M = (long)g->N * g->MY * g->MX;
   if (M <= 0) return IIC_ERR_ARG;
   if (M >= (1L << 31) || (long)g->N * g->in_Hp * g->in_Wp >= (1L << 31)) return IIC_ERR_UNSUPPORTED;
@@ -262,19 +295,30 @@ int iic_conv_igemm_frag(const iic_conv_geom* g, const void* in, const void* wfra
   const int la = (int)bd_lds_a(g);
   const long lds = la + 2L * BD_BM * 4 + 4L * BD_BN * 4;
   hipStream_t s = (hipStream_t)stream;
-#define BD_LAUNCH(GA_)                                                                            \
+#define BD_LAUNCH(GA_, AB_)                                                                       \
   do {                                                                                           \
     static bool attr = false;                                                                    \
     if (!attr) {                                                                                 \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bd_kernel<GA_>),       \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bd_kernel<GA_, AB_>),  \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);         \
       attr = true;                                                                               \
     }                                                                                            \
-    hipLaunchKernelGGL((conv_igemm_bd_kernel<GA_>), dim3(grid), dim3(BD_THREADS), lds, s, *g,    \
-                       (const bf16_t*)in, (const unsigned char*)wfrag, (bf16_t*)out, stats,      \
+    hipLaunchKernelGGL((conv_igemm_bd_kernel<GA_, AB_>), dim3(grid), dim3(BD_THREADS), lds, s,   \
+                       *g, (const bf16_t*)in, (const unsigned char*)wfrag, (bf16_t*)out, stats,  \
                        (const bf16_t*)res_grad, (const bf16_t*)res_act, accumulate, mt, la);     \
   } while (0)
-  if (g->ntaps == 1) BD_LAUNCH(true); else BD_LAUNCH(false);
+  if (g->ntaps == 1) BD_LAUNCH(true, 0);
+  else switch (iic_debug_get_ablate()) {
+    case 1: BD_LAUNCH(false, 1); break;
+    case 2: BD_LAUNCH(false, 2); break;
+    case 3: BD_LAUNCH(false, 3); break;
+    case 4: BD_LAUNCH(false, 4); break;
+    case 7: BD_LAUNCH(false, 7); break;
+    case 15: BD_LAUNCH(false, 15); break;
+    case 16: BD_LAUNCH(false, 16); break;
+    case 31: BD_LAUNCH(false, 31); break;
+    default: BD_LAUNCH(false, 0); break;
+  }
   return iic_launch_status();
 }
 

@@ -1,0 +1,250 @@
+// Persistent, DMA-fed implicit-GEMM convolution for the 64 -> 64 channel 3x3 layers (ResNet
+// layer1 of ClusterNet5g: /root/reference/code/archs/cluster/residual.py:4-7,19,22 at 64 planes;
+// forward and backward-data).  These layers sit at the HBM/MFMA ridge (AI 288):
+// 0.4 GB of activations move per launch for 117 GFLOP, so the kernel is organised around the
+// memory pipeline instead of around the MFMA loop:
+//   * one persistent workgroup per CU (8 waves) walks a contiguous range of 256-row tiles;
+//   * the input patch of tile t+1 is fetched by LDS-DMA (global_load_lds_dwordx4: no VGPRs, every
+//     piece in flight at once) into the second patch buffer while tile t computes, and the
+//     output rows of tile t-1 are stored while tile t computes => HBM reads, HBM writes and MFMA
+//     overlap inside ONE workgroup; two barriers per tile;
+//   * the whole weight operand of the wave (9 taps x 64 k x 32 couts, MFMA B-fragment order, see
+//     iic_weight_prep_frag) is loaded ONCE into 144 VGPRs and stays there for every tile;
+//   * LDS patch rows are 128 B, unpadded (DMA writes lane-linear), with the 16-byte slot XOR-ed by
+//     (row >> 1) & 7: the DMA applies the swizzle on its SOURCE address, ds_read_b128 of 16
+//     consecutive rows is conflict-free;
+//   * BatchNorm statistics are accumulated in registers across all tiles, one atomic pass at the
+//     end of the kernel.
+#include "common.h"
+#include "conv_tile.h"
+#include "../../include/iic_hip.h"
+
+#define P64_BM 256
+#define P64_BN 64
+#define P64_THREADS 512
+#define P64_NT 9
+#define P64_CLD P64_BN               // unpadded epilogue tile: LDS is the scarce resource here
+#define P64_SC_BYTES (P64_BM * P64_CLD * 2)   // 32768
+#define P64_TAB_BYTES (3 * P64_BM * (4 + 2))  // s_pout[3][256] (int) + s_prow[3][256] (u16)
+
+__device__ __forceinline__ void p64_row_pixels(const iic_conv_geom& g, int m, int M, int& pin,
+                                               int& pout) {
+  const bool valid = m < M;
+  if (!valid) m = M - 1;
+  const int plane = g.MY * g.MX;
+  const int n = m / plane;
+  const int r = m - n * plane;
+  const int y = r / g.MX, x = r - y * g.MX;
+  pin = (n * g.in_Hp + y * g.sy + g.oy) * g.in_Wp + x * g.sx + g.ox;
+  pout = valid ? (n * g.out_Hp + y * g.ty + g.py) * g.out_Wp + x * g.tx + g.px : -1;
+}
+
+__global__ __launch_bounds__(P64_THREADS) void conv_igemm_p64_kernel(
+    const iic_conv_geom g, const bf16_t* __restrict__ in, const unsigned char* __restrict__ wfrag,
+    bf16_t* __restrict__ out, float* __restrict__ stats, const bf16_t* __restrict__ res_grad,
+    const bf16_t* __restrict__ res_act, int accumulate, int num_tiles, int pb_bytes) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned char* const sP0 = smem_raw;                    // patch buffer 0  [rows][128 B]
+  unsigned char* const sP1 = smem_raw + pb_bytes;         // patch buffer 1
+  bf16_t* const sC = reinterpret_cast<bf16_t*>(smem_raw + 2 * pb_bytes);   // [256][64]
+  int* const s_pout = reinterpret_cast<int*>(smem_raw + 2 * pb_bytes + P64_SC_BYTES);  // [3][256]
+  // patch row (input pixel - p_lo of the tile) of every tile row, < NP256 <= 65535
+  unsigned short* const s_prow = reinterpret_cast<unsigned short*>(s_pout + 3 * P64_BM);  // [3][256]
+  float* const s_red = reinterpret_cast<float*>(sC);      // [4 wm][2][64], after the last store
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, g5 = lane >> 5;
+  const int M = g.N * g.MY * g.MX;
+  const int in_pixels = g.N * g.in_Hp * g.in_Wp;
+  const int nblk = pb_bytes >> 10;                        // 1-KB DMA blocks per patch
+
+  // contiguous tile range of this workgroup; workgroups of one XCD own neighbouring ranges
+  const int G = gridDim.x;
+  const int wl = xcd_tile_index(blockIdx.x, G);
+  const int t0 = (int)(((long)wl * num_tiles) / G), t1 = (int)(((long)(wl + 1) * num_tiles) / G);
+  if (t0 >= t1) return;
+
+  const int v_tapoff = g.tap_off[lane & (IIC_MAX_TAPS - 1)];
+
+  auto tile_plo = [&](int t) {
+    int pin, pout;
+    p64_row_pixels(g, t * P64_BM, M, pin, pout);
+    return __builtin_amdgcn_readfirstlane(pin);
+  };
+  auto write_table = [&](int t) {          // threads 0..255: pixel indices of tile t's rows
+    const int plo = tile_plo(t);
+    if (tid < P64_BM) {
+      int pin, pout;
+      p64_row_pixels(g, t * P64_BM + tid, M, pin, pout);
+      s_prow[(t % 3) * P64_BM + tid] = (unsigned short)(pin - plo);
+      s_pout[(t % 3) * P64_BM + tid] = pout;
+    }
+  };
+  // LDS-DMA of tile t's patch: piece q -> LDS byte q*16 (row q>>3, physical slot q&7); the
+  // source is the logical slot (q&7) ^ ((row>>1)&7) of pixel p_lo + row.
+  auto dma_issue = [&](unsigned char* dst, int t) {
+    const int plo = tile_plo(t);
+    for (int blk = wave; blk < nblk; blk += 8) {          // 1-KB blocks, wave-uniform
+      const int q = blk * 64 + lane;
+      const int r = q >> 3;
+      const int ls = (q & 7) ^ ((r >> 1) & 7);
+      int p = plo + r;
+      p = p < in_pixels ? p : in_pixels - 1;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(in + ((long)p * 64 + ls * 8)),
+          (__attribute__((address_space(3))) void*)(dst + blk * 1024), 16, 0, 0);
+    }
+  };
+
+  // ---- prologue: first patch in flight, tables of the first tile, resident weights ----------
+  dma_issue(sP0, t0);
+  write_table(t0);
+  u32x4 Bw[P64_NT][4];
+#pragma unroll
+  for (int tap = 0; tap < P64_NT; ++tap) {
+    const unsigned char* p = wfrag + ((long)g.tap_w[tap] * 2 + wn) * 4096 + lane * 16;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) Bw[tap][ks] = *reinterpret_cast<const u32x4*>(p + ks * 1024);
+  }
+  float st_s = 0.f, st_ss = 0.f;     // BN statistics of column wn*32 + l31 over this lane's rows
+
+  for (int t = t0; t < t1; ++t) {
+    const int par = (t - t0) & 1;
+    unsigned char* const sP = par ? sP1 : sP0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of patch t has landed
+    __syncthreads();                                    // A: patch t + tile t-1 in sC are complete
+    if (t > t0)
+      igemm_store_tile<P64_BN, P64_BM, P64_THREADS, 0>(sC, s_pout + ((t - 1) % 3) * P64_BM, out, res_grad,
+                                                    res_act, accumulate, P64_BN, 0, tid);
+    if (t + 1 < t1) {
+      dma_issue(par ? sP0 : sP1, t + 1);
+      write_table(t + 1);
+    }
+    // ---- tile t: 9 taps x 4 k-steps x (2 A reads, 2 MFMAs) --------------------------------
+    int R0[2];
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) R0[ms] = s_prow[(t % 3) * P64_BM + wm * 64 + ms * 32 + l31];
+    f32x16 acc[2];
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ms][r] = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < P64_NT; ++tap) {
+      const int toff = __builtin_amdgcn_readlane(v_tapoff, tap);
+      bf16x8 a[2][4];
+#pragma unroll
+      for (int ms = 0; ms < 2; ++ms) {
+        const int R = R0[ms] + toff;
+        const int key = (R >> 1) & 7;
+        const int base = R * 128 + (((g5 ^ key) & 1) << 4);
+        const int kk = (key >> 1) << 5;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          a[ms][ks] = *reinterpret_cast<const bf16x8*>(sP + base + ((ks << 5) ^ kk));
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 b = __builtin_bit_cast(bf16x8, Bw[tap][ks]);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][ks], b, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][ks], b, acc[1], 0, 0, 0);
+      }
+    }
+    if (stats) {
+      const bool tail = (t + 1) * P64_BM > M;
+#pragma unroll
+      for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[ms][r];
+          if (tail && t * P64_BM + wm * 64 + ms * 32 + mfma32_row(r, lane) >= M) v = 0.f;
+          st_s += v;
+          st_ss += v * v;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // B: the stores of tile t-1 have read sC
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        sC[(wm * 64 + ms * 32 + mfma32_row(r, lane)) * P64_CLD + wn * 32 + l31] = f32_to_bf16(acc[ms][r]);
+  }
+
+  // ---- drain: last tile's rows, then the statistics -------------------------------------------
+  __syncthreads();
+  igemm_store_tile<P64_BN, P64_BM, P64_THREADS, 0>(sC, s_pout + ((t1 - 1) % 3) * P64_BM, out, res_grad,
+                                                res_act, accumulate, P64_BN, 0, tid);
+  if (stats) {
+    __syncthreads();
+    st_s += __shfl_xor(st_s, 32, 64);
+    st_ss += __shfl_xor(st_ss, 32, 64);
+    if (lane < 32) {
+      s_red[(wm * 2 + 0) * P64_BN + wn * 32 + lane] = st_s;
+      s_red[(wm * 2 + 1) * P64_BN + wn * 32 + lane] = st_ss;
+    }
+    __syncthreads();
+    if (tid < P64_BN) {
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        a0 += s_red[(q * 2 + 0) * P64_BN + tid];
+        a1 += s_red[(q * 2 + 1) * P64_BN + tid];
+      }
+      float* st = stats + (long)(blockIdx.x % IIC_STAT_STRIPES) * 2 * P64_BN;
+      atomicAdd(st + tid, a0);
+      atomicAdd(st + P64_BN + tid, a1);
+    }
+  }
+}
+
+static int g_p64_grid = 0;   // tests: force a small persistent grid (many tiles per workgroup)
+extern "C" void iic_debug_p64_grid(int v) { g_p64_grid = v; }
+
+static int p64_num_cus() {
+  if (g_p64_grid > 0) return g_p64_grid;
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      n = v;
+    else
+      n = 256;
+  }
+  return n;
+}
+
+static long p64_pb_bytes(const iic_conv_geom* g) {
+  return (((long)g->NP256 * 128) + 1023) & ~1023L;
+}
+
+// used by conv_igemm_bd.hip's dispatcher
+int iic_p64_supported(const iic_conv_geom* g) {
+  if (g->Cin != 64 || g->Cout != 64 || g->ntaps != P64_NT || g->NP256 <= 0 || g->NP256 > 65535) return 0;
+  return 2 * p64_pb_bytes(g) + P64_SC_BYTES + P64_TAB_BYTES <= 160 * 1024;
+}
+
+int iic_p64_launch(const iic_conv_geom* g, const void* in, const void* wfrag, void* out, float* stats,
+                   const void* res_grad, const void* res_act, int accumulate, void* stream) {
+  const long M = (long)g->N * g->MY * g->MX;
+  if (M <= 0) return IIC_ERR_ARG;
+  if (M >= (1L << 31) - P64_BM || (long)g->N * g->in_Hp * g->in_Wp >= (1L << 31)) return IIC_ERR_UNSUPPORTED;
+  const int nt = (int)((M + P64_BM - 1) / P64_BM);
+  const int pb = (int)p64_pb_bytes(g);
+  const long lds = 2L * pb + P64_SC_BYTES + P64_TAB_BYTES;
+  const int ncu = p64_num_cus();
+  const int grid = nt < ncu ? nt : ncu;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_p64_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(conv_igemm_p64_kernel, dim3(grid), dim3(P64_THREADS), lds, (hipStream_t)stream,
+                     *g, (const bf16_t*)in, (const unsigned char*)wfrag, (bf16_t*)out, stats,
+                     (const bf16_t*)res_grad, (const bf16_t*)res_act, accumulate, nt, pb);
+  return iic_launch_status();
+}

@@ -18,16 +18,17 @@ __device__ __forceinline__ int xcd_tile_index(int b, int nwg) {
 }
 
 // Stage the input patch (npix pixels x 64 channels) or, in gather mode (1-tap convs), the
-// tile rows' own pixels.  4 independent 16-B loads in flight per thread.
-template <bool GATHER, int NTHREADS>
+// tile rows' own pixels.  NB independent 16-B loads in flight per thread and batch (every batch
+// is exposed to one full memory latency: use the largest NB the live registers allow).
+template <bool GATHER, int NTHREADS, int NB = 4>
 __device__ __forceinline__ void igemm_load_patch(unsigned char* sA, const bf16_t* __restrict__ in,
                                                  int Cin, int c0, int p_lo, int npix,
                                                  int in_pixels, const int* s_pin, int tid) {
   const int n8 = npix * 8;
-  for (int base = 0; base < n8; base += NTHREADS * 4) {
-    u32x4 v[4];
+  for (int base = 0; base < n8; base += NTHREADS * NB) {
+    u32x4 v[NB];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NB; ++u) {
       const int idx = base + u * NTHREADS + tid;
       v[u] = (u32x4){0u, 0u, 0u, 0u};
       if (idx < n8) {
@@ -36,22 +37,22 @@ __device__ __forceinline__ void igemm_load_patch(unsigned char* sA, const bf16_t
       }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NB; ++u) {
       const int idx = base + u * NTHREADS + tid;
       if (idx < n8) *reinterpret_cast<u32x4*>(sA + (idx >> 3) * ROWB + (idx & 7) * 16) = v[u];
     }
   }
 }
 
-// sC [BM][BN + 8] bf16 (LDS) -> out rows s_pout[row] (skipped when < 0), 16-byte stores.
+// sC [BM][BN + PAD] bf16 (LDS) -> out rows s_pout[row] (skipped when < 0), 16-byte stores.
 // accumulate: out += previous contents; res_grad/res_act: out += res_grad where res_act > 0.
-template <int BN, int BM, int NTHREADS>
+template <int BN, int BM, int NTHREADS, int PAD = 8>
 __device__ __forceinline__ void igemm_store_tile(const bf16_t* sC, const int* s_pout,
                                                  bf16_t* __restrict__ out,
                                                  const bf16_t* __restrict__ res_grad,
                                                  const bf16_t* __restrict__ res_act, int accumulate,
                                                  int Cout, int n0, int tid) {
-  constexpr int CLD = BN + 8;
+  constexpr int CLD = BN + PAD;
   for (int idx = tid; idx < BM * (BN / 8); idx += NTHREADS) {
     const int row = idx / (BN / 8), ch = idx - row * (BN / 8);
     const int po = s_pout[row];

@@ -157,6 +157,26 @@ def _force_bm(bm):
   ctypes.CDLL(_lib.LIB_PATH).iic_debug_force_bm(bm)
 
 
+def _p64_grid(n):
+  import ctypes
+  from iic_amd import _lib
+  ctypes.CDLL(_lib.LIB_PATH).iic_debug_p64_grid(n)
+
+
+@pytest.mark.parametrize("grid", [1, 3, 0])
+def test_conv_p64_persistent_tiles(grid):
+  """64 -> 64 3x3 layers run on the persistent DMA-fed kernel (conv_igemm_p64.hip); a forced
+  small grid makes every workgroup walk many tiles (double-buffered patches, deferred stores,
+  statistics carried in registers), grid 0 = one workgroup per CU."""
+  case = (64, 64, 3, 1, 1, 6, 49) if grid else (64, 64, 3, 1, 1, 40, 49)
+  _p64_grid(grid)
+  try:
+    _conv_forward_and_stats(case, frag=True)
+    _conv_backward_data(case, frag=True)
+  finally:
+    _p64_grid(0)
+
+
 @pytest.mark.parametrize("bm", [0, 256, "frag"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_forward_and_stats(case, bm):
@@ -187,6 +207,7 @@ def _conv_forward_and_stats(case, frag=False):
   wop = wf
   if frag:
     if not ops.frag_supported(g):
+      assert not (cin == 64 and cout == 64 and K == 3), "64->64 3x3 must run on the persistent kernel"
       pytest.skip("geometry not served by the weights-direct kernel (Cout % 128 != 0)")
     wop = ops.PreppedWeights(w.to(dev()))[0]
   xp = ops.pt_from_nchw(x.to(dev()), 1)

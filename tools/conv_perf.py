@@ -43,6 +43,7 @@ def main():
   ap.add_argument("--bm", type=int, default=0)
   ap.add_argument("--frag", type=int, default=1, help="1: weights-direct kernel where supported (A/B column)")
   ap.add_argument("--no-wgrad", action="store_true")
+  ap.add_argument("--frag-ablate", type=str, default="", help="comma list of ablation codes for the frag kernel")
   a = ap.parse_args()
   dev = torch.device("cuda:0")
   N = a.n
@@ -82,6 +83,15 @@ def main():
       if ops.frag_supported(gf):
         t2 = timeit(lambda: ops.conv_igemm(gf, x, pw[0], y, stats=st), a.iters)
         extra += " | frag fwd %7.1f us %7.1f TF/s" % (t2, flops / t2 / 1e6)
+        for code in [int(c) for c in a.frag_ablate.split(",") if c]:
+          import ctypes
+          from iic_amd import _lib
+          L = ctypes.CDLL(_lib.LIB_PATH)
+          L.iic_debug_set_ablate(code)
+          # NOTE: only the frag kernel is timed under the flag (the old kernel has its own codes)
+          t3 = timeit(lambda: ops.conv_igemm(gf, x, pw[0], y, stats=st), a.iters)
+          L.iic_debug_set_ablate(0)
+          extra += " | abl%d %6.1f" % (code, t3)
         tot["fwd2"] = tot.get("fwd2", 0.0) + COUNT[li] * (t2 - t_f)
       if all(ops.frag_supported(g) for g in gb):
         t2 = timeit(lambda: [ops.conv_igemm(g, dy, pw[1], dx) for g in gb], a.iters)
