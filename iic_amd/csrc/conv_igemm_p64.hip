@@ -25,31 +25,49 @@
 #define P64_NT 9
 #define P64_CLD P64_BN               // unpadded epilogue tile: LDS is the scarce resource here
 #define P64_SC_BYTES (P64_BM * P64_CLD * 2)   // 32768
-#define P64_TAB_BYTES (3 * P64_BM * (4 + 2))  // s_pout[3][256] (int) + s_prow[3][256] (u16)
+#define P64_NTAB 4                   // row tables are written two tiles ahead of their use
+#define P64_TAB_BYTES (P64_NTAB * P64_BM * (4 + 2))   // s_pout (int) + s_prow (u16)
 
-__device__ __forceinline__ void p64_row_pixels(const iic_conv_geom& g, int m, int M, int& pin,
-                                               int& pout) {
-  const bool valid = m < M;
-  if (!valid) m = M - 1;
+// (n, y, x) of a GEMM row, advanced by one tile (256 rows) at a time: no per-tile divisions.
+struct P64Walk {
+  int n, y, x;
+};
+__device__ __forceinline__ void p64_walk_init(P64Walk& w, const iic_conv_geom& g, int m) {
   const int plane = g.MY * g.MX;
-  const int n = m / plane;
-  const int r = m - n * plane;
-  const int y = r / g.MX, x = r - y * g.MX;
+  w.n = m / plane;
+  const int r = m - w.n * plane;
+  w.y = r / g.MX;
+  w.x = r - w.y * g.MX;
+}
+__device__ __forceinline__ void p64_walk_advance(P64Walk& w, const iic_conv_geom& g, int d_y, int d_x) {
+  w.x += d_x;
+  w.y += d_y;
+  if (w.x >= g.MX) { w.x -= g.MX; ++w.y; }
+  while (w.y >= g.MY) { w.y -= g.MY; ++w.n; }
+}
+// input / output pixel of the row; rows past the end repeat the last row and are never stored
+__device__ __forceinline__ void p64_walk_pixels(const P64Walk& w, const iic_conv_geom& g, int& pin,
+                                                int& pout) {
+  const bool valid = w.n < g.N;
+  const int n = valid ? w.n : g.N - 1, y = valid ? w.y : g.MY - 1, x = valid ? w.x : g.MX - 1;
   pin = (n * g.in_Hp + y * g.sy + g.oy) * g.in_Wp + x * g.sx + g.ox;
   pout = valid ? (n * g.out_Hp + y * g.ty + g.py) * g.out_Wp + x * g.tx + g.px : -1;
 }
 
+// ABL: timing-ablation build (WRONG results): 1 = only the first patch is fetched, 2 = no output
+// stores, 4 = one tap instead of nine.
+template <int ABL>
 __global__ __launch_bounds__(P64_THREADS) void conv_igemm_p64_kernel(
     const iic_conv_geom g, const bf16_t* __restrict__ in, const unsigned char* __restrict__ wfrag,
     bf16_t* __restrict__ out, float* __restrict__ stats, const bf16_t* __restrict__ res_grad,
-    const bf16_t* __restrict__ res_act, int accumulate, int num_tiles, int pb_bytes) {
+    const bf16_t* __restrict__ res_act, int accumulate, int num_tiles, int pb_bytes, int max_tap_off) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned char* const sP0 = smem_raw;                    // patch buffer 0  [rows][128 B]
   unsigned char* const sP1 = smem_raw + pb_bytes;         // patch buffer 1
   bf16_t* const sC = reinterpret_cast<bf16_t*>(smem_raw + 2 * pb_bytes);   // [256][64]
-  int* const s_pout = reinterpret_cast<int*>(smem_raw + 2 * pb_bytes + P64_SC_BYTES);  // [3][256]
-  // patch row (input pixel - p_lo of the tile) of every tile row, < NP256 <= 65535
-  unsigned short* const s_prow = reinterpret_cast<unsigned short*>(s_pout + 3 * P64_BM);  // [3][256]
+  int* const s_pout = reinterpret_cast<int*>(smem_raw + 2 * pb_bytes + P64_SC_BYTES);  // [4][256]
+  // patch row (input pixel - first input pixel of the tile) of every tile row, < NP256 <= 65535
+  unsigned short* const s_prow = reinterpret_cast<unsigned short*>(s_pout + P64_NTAB * P64_BM);
   float* const s_red = reinterpret_cast<float*>(sC);      // [4 wm][2][64], after the last store
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -58,7 +76,6 @@ __global__ __launch_bounds__(P64_THREADS) void conv_igemm_p64_kernel(
   const int l31 = lane & 31, g5 = lane >> 5;
   const int M = g.N * g.MY * g.MX;
   const int in_pixels = g.N * g.in_Hp * g.in_Wp;
-  const int nblk = pb_bytes >> 10;                        // 1-KB DMA blocks per patch
 
   // contiguous tile range of this workgroup; workgroups of one XCD own neighbouring ranges
   const int G = gridDim.x;
@@ -67,25 +84,40 @@ __global__ __launch_bounds__(P64_THREADS) void conv_igemm_p64_kernel(
   if (t0 >= t1) return;
 
   const int v_tapoff = g.tap_off[lane & (IIC_MAX_TAPS - 1)];
+  const int d_y = P64_BM / g.MX, d_x = P64_BM - d_y * g.MX;
 
-  auto tile_plo = [&](int t) {
-    int pin, pout;
-    p64_row_pixels(g, t * P64_BM, M, pin, pout);
-    return __builtin_amdgcn_readfirstlane(pin);
-  };
-  auto write_table = [&](int t) {          // threads 0..255: pixel indices of tile t's rows
-    const int plo = tile_plo(t);
+  // walkers: `wr` = this thread's table row (row tid & 255 of the next tile to tabulate),
+  // `w0` / `wl255` = first / last row of that tile (uniform): p_lo and the span the tile needs
+  P64Walk wr, w0, w255;
+  p64_walk_init(wr, g, t0 * P64_BM + (tid & (P64_BM - 1)));
+  p64_walk_init(w0, g, t0 * P64_BM);
+  p64_walk_init(w255, g, t0 * P64_BM + P64_BM - 1);
+  int plo_q[3], nblk_q[3];      // [0] = tile being tabulated next - 2 ... rotating queue
+  auto tabulate = [&](int t) {  // writes table t (the tile all three walkers point at), advances
+    int pin, pout, p0, p255, dummy;
+    p64_walk_pixels(w0, g, p0, dummy);
+    p64_walk_pixels(w255, g, p255, dummy);
+    p0 = __builtin_amdgcn_readfirstlane(p0);
+    p255 = __builtin_amdgcn_readfirstlane(p255);
     if (tid < P64_BM) {
-      int pin, pout;
-      p64_row_pixels(g, t * P64_BM + tid, M, pin, pout);
-      s_prow[(t % 3) * P64_BM + tid] = (unsigned short)(pin - plo);
-      s_pout[(t % 3) * P64_BM + tid] = pout;
+      p64_walk_pixels(wr, g, pin, pout);
+      s_pout[(t & (P64_NTAB - 1)) * P64_BM + tid] = pout;
+      s_prow[(t & (P64_NTAB - 1)) * P64_BM + tid] = (unsigned short)(pin - p0);
     }
+    p64_walk_advance(wr, g, d_y, d_x);
+    p64_walk_advance(w0, g, d_y, d_x);
+    p64_walk_advance(w255, g, d_y, d_x);
+    plo_q[0] = plo_q[1];
+    nblk_q[0] = nblk_q[1];
+    plo_q[1] = plo_q[2];
+    nblk_q[1] = nblk_q[2];
+    plo_q[2] = p0;
+    // 1-KB blocks covering the rows this tile reads: (p255 + max tap offset - p0 + 1) x 128 B
+    nblk_q[2] = ((p255 + max_tap_off - p0 + 1) * 128 + 1023) >> 10;
   };
-  // LDS-DMA of tile t's patch: piece q -> LDS byte q*16 (row q>>3, physical slot q&7); the
-  // source is the logical slot (q&7) ^ ((row>>1)&7) of pixel p_lo + row.
-  auto dma_issue = [&](unsigned char* dst, int t) {
-    const int plo = tile_plo(t);
+  // LDS-DMA of a patch: piece q -> LDS byte q*16 (row q>>3, physical slot q&7); the source is
+  // the logical slot (q&7) ^ ((row>>1)&7) of pixel plo + row.
+  auto dma_issue = [&](unsigned char* dst, int plo, int nblk) {
     for (int blk = wave; blk < nblk; blk += 8) {          // 1-KB blocks, wave-uniform
       const int q = blk * 64 + lane;
       const int r = q >> 3;
@@ -98,9 +130,11 @@ __global__ __launch_bounds__(P64_THREADS) void conv_igemm_p64_kernel(
     }
   };
 
-  // ---- prologue: first patch in flight, tables of the first tile, resident weights ----------
-  dma_issue(sP0, t0);
-  write_table(t0);
+  // ---- prologue: tables of the first two tiles, first patch in flight, resident weights -------
+  tabulate(t0);
+  tabulate(t0 + 1);
+  // queue now: [1] = tile t0, [2] = tile t0 + 1
+  dma_issue(sP0, plo_q[1], nblk_q[1]);
   u32x4 Bw[P64_NT][4];
 #pragma unroll
   for (int tap = 0; tap < P64_NT; ++tap) {
@@ -108,31 +142,27 @@ __global__ __launch_bounds__(P64_THREADS) void conv_igemm_p64_kernel(
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) Bw[tap][ks] = *reinterpret_cast<const u32x4*>(p + ks * 1024);
   }
-  float st_s = 0.f, st_ss = 0.f;     // BN statistics of column wn*32 + l31 over this lane's rows
+  f32x2 st_s = {0.f, 0.f}, st_ss = {0.f, 0.f};   // BN statistics of column wn*32 + l31
 
   for (int t = t0; t < t1; ++t) {
     const int par = (t - t0) & 1;
     unsigned char* const sP = par ? sP1 : sP0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of patch t has landed
     __syncthreads();                                    // A: patch t + tile t-1 in sC are complete
-    if (t > t0)
-      igemm_store_tile<P64_BN, P64_BM, P64_THREADS, 0>(sC, s_pout + ((t - 1) % 3) * P64_BM, out, res_grad,
-                                                    res_act, accumulate, P64_BN, 0, tid);
-    if (t + 1 < t1) {
-      dma_issue(par ? sP0 : sP1, t + 1);
-      write_table(t + 1);
-    }
+    if (t > t0 && !(ABL & 2))
+      igemm_store_tile<P64_BN, P64_BM, P64_THREADS, 0>(sC, s_pout + ((t - 1) & (P64_NTAB - 1)) * P64_BM, out,
+                                                       res_grad, res_act, accumulate, P64_BN, 0, tid);
+    // queue: [2] = tile t + 1 (tabulated one iteration ago)
+    if (t + 1 < t1 && !(ABL & 1)) dma_issue(par ? sP0 : sP1, plo_q[2], nblk_q[2]);
+    tabulate(t + 2);
     // ---- tile t: 9 taps x 4 k-steps x (2 A reads, 2 MFMAs) --------------------------------
     int R0[2];
 #pragma unroll
-    for (int ms = 0; ms < 2; ++ms) R0[ms] = s_prow[(t % 3) * P64_BM + wm * 64 + ms * 32 + l31];
+    for (int ms = 0; ms < 2; ++ms)
+      R0[ms] = s_prow[(t & (P64_NTAB - 1)) * P64_BM + wm * 64 + ms * 32 + l31];
     f32x16 acc[2];
 #pragma unroll
-    for (int ms = 0; ms < 2; ++ms)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[ms][r] = 0.f;
-#pragma unroll
-    for (int tap = 0; tap < P64_NT; ++tap) {
+    for (int tap = 0; tap < ((ABL & 4) ? 1 : P64_NT); ++tap) {
       const int toff = __builtin_amdgcn_readlane(v_tapoff, tap);
       bf16x8 a[2][4];
 #pragma unroll
@@ -148,18 +178,29 @@ __global__ __launch_bounds__(P64_THREADS) void conv_igemm_p64_kernel(
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const bf16x8 b = __builtin_bit_cast(bf16x8, Bw[tap][ks]);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][ks], b, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][ks], b, acc[1], 0, 0, 0);
+        if (tap == 0 && ks == 0) {          // first MFMA of the tile: C operand = 0 (no zero-fill)
+          const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][ks], b, z, 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][ks], b, z, 0, 0, 0);
+        } else {
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][ks], b, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][ks], b, acc[1], 0, 0, 0);
+        }
       }
     }
     if (stats) {
-      const bool tail = (t + 1) * P64_BM > M;
+      if ((t + 1) * P64_BM > M) {           // last tile: rows past the end do not count
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (t * P64_BM + wm * 64 + ms * 32 + mfma32_row(r, lane) >= M) acc[ms][r] = 0.f;
+      }
 #pragma unroll
       for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v = acc[ms][r];
-          if (tail && t * P64_BM + wm * 64 + ms * 32 + mfma32_row(r, lane) >= M) v = 0.f;
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2 v = {acc[ms][r], acc[ms][r + 1]};
           st_s += v;
           st_ss += v * v;
         }
@@ -175,15 +216,17 @@ __global__ __launch_bounds__(P64_THREADS) void conv_igemm_p64_kernel(
 
   // ---- drain: last tile's rows, then the statistics -------------------------------------------
   __syncthreads();
-  igemm_store_tile<P64_BN, P64_BM, P64_THREADS, 0>(sC, s_pout + ((t1 - 1) % 3) * P64_BM, out, res_grad,
-                                                res_act, accumulate, P64_BN, 0, tid);
+  if (!(ABL & 2))
+    igemm_store_tile<P64_BN, P64_BM, P64_THREADS, 0>(sC, s_pout + ((t1 - 1) & (P64_NTAB - 1)) * P64_BM, out,
+                                                     res_grad, res_act, accumulate, P64_BN, 0, tid);
   if (stats) {
     __syncthreads();
-    st_s += __shfl_xor(st_s, 32, 64);
-    st_ss += __shfl_xor(st_ss, 32, 64);
+    float s1 = st_s[0] + st_s[1], s2 = st_ss[0] + st_ss[1];
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
     if (lane < 32) {
-      s_red[(wm * 2 + 0) * P64_BN + wn * 32 + lane] = st_s;
-      s_red[(wm * 2 + 1) * P64_BN + wn * 32 + lane] = st_ss;
+      s_red[(wm * 2 + 0) * P64_BN + wn * 32 + lane] = s1;
+      s_red[(wm * 2 + 1) * P64_BN + wn * 32 + lane] = s2;
     }
     __syncthreads();
     if (tid < P64_BN) {
@@ -200,6 +243,7 @@ __global__ __launch_bounds__(P64_THREADS) void conv_igemm_p64_kernel(
   }
 }
 
+extern "C" int iic_debug_get_ablate(void);
 static int g_p64_grid = 0;   // tests: force a small persistent grid (many tiles per workgroup)
 extern "C" void iic_debug_p64_grid(int v) { g_p64_grid = v; }
 
@@ -235,16 +279,30 @@ int iic_p64_launch(const iic_conv_geom* g, const void* in, const void* wfrag, vo
   const int nt = (int)((M + P64_BM - 1) / P64_BM);
   const int pb = (int)p64_pb_bytes(g);
   const long lds = 2L * pb + P64_SC_BYTES + P64_TAB_BYTES;
+  int mto = 0;
+  for (int i = 0; i < g->ntaps; ++i) mto = g->tap_off[i] > mto ? g->tap_off[i] : mto;
   const int ncu = p64_num_cus();
   const int grid = nt < ncu ? nt : ncu;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_p64_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
+#define P64_LAUNCH(AB_)                                                                           \
+  do {                                                                                           \
+    static bool attr = false;                                                                    \
+    if (!attr) {                                                                                 \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_p64_kernel<AB_>),      \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);         \
+      attr = true;                                                                               \
+    }                                                                                            \
+    hipLaunchKernelGGL(conv_igemm_p64_kernel<AB_>, dim3(grid), dim3(P64_THREADS), lds,           \
+                       (hipStream_t)stream, *g, (const bf16_t*)in, (const unsigned char*)wfrag,  \
+                       (bf16_t*)out, stats, (const bf16_t*)res_grad, (const bf16_t*)res_act,     \
+                       accumulate, nt, pb, mto);                                                 \
+  } while (0)
+  switch (iic_debug_get_ablate()) {
+    case 1: P64_LAUNCH(1); break;
+    case 2: P64_LAUNCH(2); break;
+    case 3: P64_LAUNCH(3); break;
+    case 4: P64_LAUNCH(4); break;
+    case 7: P64_LAUNCH(7); break;
+    default: P64_LAUNCH(0); break;
   }
-  hipLaunchKernelGGL(conv_igemm_p64_kernel, dim3(grid), dim3(P64_THREADS), lds, (hipStream_t)stream,
-                     *g, (const bf16_t*)in, (const unsigned char*)wfrag, (bf16_t*)out, stats,
-                     (const bf16_t*)res_grad, (const bf16_t*)res_act, accumulate, nt, pb);
   return iic_launch_status();
 }

@@ -245,17 +245,17 @@ def test_north_star_full_size_properties():
   imgs, imgs_tf = imgs.to(dev()), imgs_tf.to(dev())
   before = [p.detach().clone() for p in net.parameters()]
   net.zero_grad()
-  xo = net.forward_packed(sobel_process(imgs, False))       # [660, 5*70]
+  xo = net.forward_packed(sobel_process(imgs, False))       # [660, 5, 70]
   xt = net.forward_packed(sobel_process(imgs_tf, False))
-  assert xo.shape == (NP, H * K) and xt.shape == (NP, H * K)
-  rows = xo.detach().view(NP, H, K)
+  assert xo.shape == (NP, H, K) and xt.shape == (NP, H, K)
+  rows = xo.detach()
   assert float(rows.min()) >= 0 and torch.allclose(rows.sum(2), torch.ones(NP, H, device=dev()), atol=1e-5)
-  rep = xo.detach().view(3, NP // 3, H * K)
+  rep = xo.detach().reshape(3, NP // 3, H * K)
   assert torch.equal(rep[0], rep[1]) and torch.equal(rep[0], rep[2])
   loss_h, loss_nl_h = IID_loss_heads(xo, xt, lamb=1.0)
   assert torch.equal(loss_h, loss_nl_h)
-  z = xo.detach().view(NP, H, K).double().cpu().numpy()
-  zt = xt.detach().view(NP, H, K).double().cpu().numpy()
+  z = xo.detach().double().cpu().numpy()
+  zt = xt.detach().double().cpu().numpy()
   perm = torch.randperm(NP, generator=g).to(dev())
   with torch.no_grad():
     loss_p, _ = IID_loss_heads(xo.detach()[perm].contiguous(), xt.detach()[perm].contiguous(), lamb=1.0)
