@@ -324,6 +324,11 @@ __global__ void probe_tr16_kernel(uint16_t* out) {
   for (int j = 0; j < 4; ++j) out[l * 4 + j] = (uint16_t)v[j];
 }
 
+// conv_wgrad_dma.hip: LDS-DMA double-buffered variant for the stride-1 3x3 layers
+int iic_wgrad_dma_supported(const iic_conv_geom* g);
+int iic_wgrad_dma_launch(const iic_conv_geom* g, const void* x, const void* dy, float* partials,
+                         int nsplit, void* stream);
+
 extern "C" {
 
 static int wgrad_cot(const iic_conv_geom* g) { return (g->Cout % 128 == 0) ? 128 : 64; }
@@ -345,6 +350,7 @@ int iic_conv_wgrad(const iic_conv_geom* g, const void* x, const void* dy, float*
     return IIC_ERR_UNSUPPORTED;
   const long M = (long)g->N * g->MY * g->MX;
   if (M >= (1L << 31) || (long)g->N * g->in_Hp * g->in_Wp >= (1L << 31)) return IIC_ERR_UNSUPPORTED;
+  if (use_tr && iic_wgrad_dma_supported(g)) return iic_wgrad_dma_launch(g, x, dy, partials, nsplit, stream);
   const int kt = (int)((M + BM - 1) / BM);
   const bool ga = g->ntaps == 1;
   const int cot = wgrad_cot(g);

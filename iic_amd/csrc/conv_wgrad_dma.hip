@@ -1,0 +1,270 @@
+// Convolution backward-weight, DMA-fed variant for the stride-1 3x3 layers (the bulk of
+// /root/reference/code/archs/cluster/residual.py:4-7,19,22): same math and work split as
+// conv_wgrad.hip,
+//   dW[t][co][ci] = sum_m dY[pout(m)][co] * X[pin(m) + tap_off[t]][ci],
+// workgroup = COT co x 64 ci x 9 taps over a range of 128-pixel K-tiles, 12 waves
+// (2 co halves x 2 ci halves x 3 tap groups), operands read with ds_read_b64_tr_b16 --
+// but the K-tile pipeline is rebuilt around LDS-DMA:
+//   * the input patch and the dY rows of K-tile kt+1 are fetched by global_load_lds_dwordx4 into
+//     the second LDS buffer while K-tile kt is multiplied: no staging registers, no ds_write
+//     pass, ONE barrier per K-tile (conv_wgrad.hip: register staging, 75 KB of ds_write_b128 and
+//     two barriers per K-tile with the matrix pipe idle in between);
+//   * LDS rows are unpadded (DMA writes lane-linear).  A transposing read covers 4 consecutive
+//     rows x 64 B per LDS cycle, so the 64-byte unit of a row is XOR-swizzled: 128-B rows
+//     (input patch; dY at COT = 64) unit ^= (row >> 1) & 1, 256-B rows (dY at COT = 128)
+//     unit ^= row & 3; the DMA applies the swizzle on its source address;
+//   * rows past the end of the batch take their dY from pixel 0 of the PT tensor (zero border);
+//   * row bookkeeping by (n, y, x) walkers, tables written two K-tiles ahead.
+#include "common.h"
+#include "../../include/iic_hip.h"
+
+#define WD_BM 128
+#define WD_THREADS 768
+#define WD_NTAB 4
+#define WD_TAB_BYTES (WD_NTAB * WD_BM * (4 + 2))
+
+typedef s16x4 __attribute__((address_space(3))) * wd_lds_s16x4_ptr;
+
+__device__ __forceinline__ bf16x8 wd_frag(uint32_t a0, uint32_t a1) {
+  union { bf16x8 v; s16x4 h[2]; } u;
+  u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wd_lds_s16x4_ptr)(uintptr_t)a0);
+  u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wd_lds_s16x4_ptr)(uintptr_t)a1);
+  return u.v;
+}
+
+struct WdWalk {
+  int n, y, x;
+};
+__device__ __forceinline__ void wd_walk_init(WdWalk& w, const iic_conv_geom& g, int m) {
+  const int plane = g.MY * g.MX;
+  w.n = m / plane;
+  const int r = m - w.n * plane;
+  w.y = r / g.MX;
+  w.x = r - w.y * g.MX;
+}
+__device__ __forceinline__ void wd_walk_advance(WdWalk& w, const iic_conv_geom& g, int d_y, int d_x) {
+  w.x += d_x;
+  w.y += d_y;
+  if (w.x >= g.MX) { w.x -= g.MX; ++w.y; }
+  while (w.y >= g.MY) { w.y -= g.MY; ++w.n; }
+}
+__device__ __forceinline__ void wd_walk_pixels(const WdWalk& w, const iic_conv_geom& g, int& pin,
+                                               int& pout) {
+  const bool valid = w.n < g.N;
+  const int n = valid ? w.n : g.N - 1, y = valid ? w.y : g.MY - 1, x = valid ? w.x : g.MX - 1;
+  pin = (n * g.in_Hp + y * g.sy + g.oy) * g.in_Wp + x * g.sx + g.ox;
+  pout = valid ? (n * g.out_Hp + y * g.ty + g.py) * g.out_Wp + x * g.tx + g.px : -1;
+}
+
+template <int COT>
+__global__ __launch_bounds__(WD_THREADS) void conv_wgrad_dma_kernel(
+    const iic_conv_geom g, const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+    float* __restrict__ partials, int nsplit, int num_ktiles, int xb_bytes, int max_tap_off) {
+  constexpr int CS = COT / 64;                  // 32-wide co sub-tiles per wave
+  constexpr int DROW = COT * 2;                 // dY tile row bytes (256 | 128)
+  constexpr int DB = WD_BM * DROW;              // dY tile bytes (32 KB | 16 KB)
+  constexpr int DBLK = DB / 1024;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  typedef unsigned char __attribute__((address_space(3))) * lds_u8_ptr;
+  unsigned char* const sX = smem_raw;                        // [2][xb_bytes]
+  unsigned char* const sD = smem_raw + 2 * xb_bytes;         // [2][DB]
+  int* const s_pout = reinterpret_cast<int*>(sD + 2 * DB);   // [4][128]
+  unsigned short* const s_prow = reinterpret_cast<unsigned short*>(s_pout + WD_NTAB * WD_BM);
+  const uint32_t sXo = (uint32_t)(uintptr_t)(lds_u8_ptr)sX, sDo = (uint32_t)(uintptr_t)(lds_u8_ptr)sD;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tg = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+  const int l31 = lane & 31;
+  const int q = lane >> 4, i16 = lane & 15;
+  const int ncit = g.Cin >> 6;
+  const int cot = blockIdx.x / ncit, cit = blockIdx.x - cot * ncit;
+  const int co0 = cot * COT, ci0 = cit * 64;
+  const int split = blockIdx.y;
+  const int per = (num_ktiles + nsplit - 1) / nsplit;
+  const int kt0 = split * per;
+  const int kt1 = min(num_ktiles, kt0 + per);
+  const int in_pixels = g.N * g.in_Hp * g.in_Wp;
+  const int v_tapoff = g.tap_off[lane & (IIC_MAX_TAPS - 1)];
+  const int tfirst = tg * 3;                     // this wave's taps: tfirst .. tfirst + 2
+
+  // lane constants of the transposing reads (see conv_wgrad.hip::frag_T)
+  const int trow = 8 * (q >> 1) + (i16 >> 2);                         // + 16*ks (+4 for rd=1)
+  const int tsub = (2 * (q & 1) + ((i16 & 3) >> 1)) * 16 + (i16 & 1) * 8;   // byte in the 64-B unit
+  // dY fragment c: logical 64-B unit wm*CS + c of row k; its swizzle key only depends on trow
+  uint32_t aoff[CS];
+#pragma unroll
+  for (int c = 0; c < CS; ++c) {
+    const int unit = (COT == 128) ? ((wm * 2 + c) ^ (trow & 3)) : (wm ^ ((trow >> 1) & 1));
+    aoff[c] = trow * DROW + unit * 64 + tsub;
+  }
+  // X fragment: unit wn of row R, physical unit = wn ^ ((R >> 1) & 1)
+  const uint32_t xoff = tsub + wn * 64;
+  const int xs32 = wn ? -32 : 32;
+
+  f32x16 acc[3][CS];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int c = 0; c < CS; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][c][r] = 0.f;
+
+  if (kt0 < kt1) {
+    const int d_y = WD_BM / g.MX, d_x = WD_BM - d_y * g.MX;
+    WdWalk wr, w0, w1;
+    wd_walk_init(wr, g, kt0 * WD_BM + (tid & (WD_BM - 1)));
+    wd_walk_init(w0, g, kt0 * WD_BM);
+    wd_walk_init(w1, g, kt0 * WD_BM + WD_BM - 1);
+    int plo_q[3], nblk_q[3];
+    auto tabulate = [&](int kt) {   // table of K-tile kt (where the walkers stand), then advance
+      int pin, pout, p0, p1, dummy;
+      wd_walk_pixels(w0, g, p0, dummy);
+      wd_walk_pixels(w1, g, p1, dummy);
+      p0 = __builtin_amdgcn_readfirstlane(p0);
+      p1 = __builtin_amdgcn_readfirstlane(p1);
+      if (tid < WD_BM) {
+        wd_walk_pixels(wr, g, pin, pout);
+        s_pout[(kt & (WD_NTAB - 1)) * WD_BM + tid] = pout;
+        s_prow[(kt & (WD_NTAB - 1)) * WD_BM + tid] = (unsigned short)(pin - p0);
+      }
+      wd_walk_advance(wr, g, d_y, d_x);
+      wd_walk_advance(w0, g, d_y, d_x);
+      wd_walk_advance(w1, g, d_y, d_x);
+      plo_q[0] = plo_q[1];
+      nblk_q[0] = nblk_q[1];
+      plo_q[1] = plo_q[2];
+      nblk_q[1] = nblk_q[2];
+      plo_q[2] = p0;
+      nblk_q[2] = ((p1 + max_tap_off - p0 + 1) * 128 + 1023) >> 10;
+    };
+    // DMA of one K-tile: input patch (nblk 1-KB blocks) + dY rows (DBLK blocks), 12 waves
+    auto dma_issue = [&](int buf, int tab, int plo, int nblk) {
+      unsigned char* const dX = sX + buf * xb_bytes;
+      unsigned char* const dD = sD + buf * DB;
+      for (int b = wave; b < nblk + DBLK; b += WD_THREADS / 64) {
+        if (b < nblk) {
+          const int qq = b * 64 + lane;
+          const int r = qq >> 3, slot = qq & 7;
+          const int ls = slot ^ (((r >> 1) & 1) << 2);
+          int p = plo + r;
+          p = p < in_pixels ? p : in_pixels - 1;
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void*)(x + ((long)p * g.Cin + ci0 + ls * 8)),
+              (__attribute__((address_space(3))) void*)(dX + b * 1024), 16, 0, 0);
+        } else {
+          const int bd = b - nblk;
+          int row, ls;
+          if (COT == 128) {
+            row = bd * 4 + (lane >> 4);
+            ls = (lane & 15) ^ ((row & 3) << 2);
+          } else {
+            row = bd * 8 + (lane >> 3);
+            ls = (lane & 7) ^ (((row >> 1) & 1) << 2);
+          }
+          int po = s_pout[tab * WD_BM + row];
+          po = po < 0 ? 0 : po;                       // pixel 0 = zero border of the PT tensor
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void*)(dy + ((long)po * g.Cout + co0 + ls * 8)),
+              (__attribute__((address_space(3))) void*)(dD + bd * 1024), 16, 0, 0);
+        }
+      }
+    };
+
+    tabulate(kt0);
+    tabulate(kt0 + 1);
+    __syncthreads();                                   // table kt0 visible to the dY gather
+    dma_issue(0, kt0 & (WD_NTAB - 1), plo_q[1], nblk_q[1]);
+
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const int b = (kt - kt0) & 1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of K-tile kt landed
+      __syncthreads();                                    // everyone's did; tile kt-1 is consumed
+      if (kt + 1 < kt1) dma_issue(b ^ 1, (kt + 1) & (WD_NTAB - 1), plo_q[2], nblk_q[2]);
+      tabulate(kt + 2);
+      const unsigned short* prow = s_prow + (kt & (WD_NTAB - 1)) * WD_BM;
+      const uint32_t xb = sXo + b * xb_bytes + xoff;
+      const uint32_t db = sDo + b * DB;
+      // this lane's patch rows of all 8 k-steps up front (one LDS round trip per K-tile)
+      int rr0[WD_BM / 16], rr1[WD_BM / 16];
+#pragma unroll
+      for (int ks = 0; ks < WD_BM / 16; ++ks) {
+        rr0[ks] = prow[ks * 16 + trow];
+        rr1[ks] = prow[ks * 16 + trow + 4];
+      }
+#pragma unroll
+      for (int ks = 0; ks < WD_BM / 16; ++ks) {
+        bf16x8 a[CS], bfr[3];
+#pragma unroll
+        for (int c = 0; c < CS; ++c)
+          a[c] = wd_frag(db + ks * 16 * DROW + aoff[c], db + (ks * 16 + 4) * DROW + aoff[c]);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const int toff = __builtin_amdgcn_readlane(v_tapoff, tfirst + t);
+          const int R0 = rr0[ks] + toff, R1 = rr1[ks] + toff;
+          bfr[t] = wd_frag(xb + (R0 << 7) + (R0 & 2) * xs32, xb + (R1 << 7) + (R1 & 2) * xs32);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // all 10 transposing reads of the k-step in flight
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int c = 0; c < CS; ++c)
+            acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[c], bfr[t], acc[t][c], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  // partial[split][t][co][ci]
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    float* dst = partials + (((long)split * g.ntaps + (tfirst + t)) * g.Cout + co0) * g.Cin + ci0;
+#pragma unroll
+    for (int c = 0; c < CS; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * (COT / 2) + c * 32 + mfma32_row(r, lane);
+        const int col = wn * 32 + l31;
+        dst[(long)row * g.Cin + col] = acc[t][c][r];
+      }
+  }
+}
+
+static long wd_xb_bytes(const iic_conv_geom* g) { return (((long)g->NP * 128) + 1023) & ~1023L; }
+
+static int g_wd_enabled = 1;
+extern "C" void iic_debug_enable_wgrad_dma(int v) { g_wd_enabled = v; }
+
+// used by conv_wgrad.hip's dispatcher
+int iic_wgrad_dma_supported(const iic_conv_geom* g) {
+  if (!g_wd_enabled) return 0;
+  if (g->ntaps != 9 || g->Cin % 64 != 0 || g->Cout % 64 != 0 || g->NP <= 0 || g->NP > 65535) return 0;
+  const int cot = (g->Cout % 128 == 0) ? 128 : 64;
+  const long lds = 2 * wd_xb_bytes(g) + 2L * WD_BM * cot * 2 + WD_TAB_BYTES;
+  return lds <= 160 * 1024;
+}
+
+int iic_wgrad_dma_launch(const iic_conv_geom* g, const void* x, const void* dy, float* partials,
+                         int nsplit, void* stream) {
+  const long M = (long)g->N * g->MY * g->MX;
+  const int kt = (int)((M + WD_BM - 1) / WD_BM);
+  const int cot = (g->Cout % 128 == 0) ? 128 : 64;
+  const int xb = (int)wd_xb_bytes(g);
+  const long lds = 2L * xb + 2L * WD_BM * cot * 2 + WD_TAB_BYTES;
+  int mto = 0;
+  for (int i = 0; i < g->ntaps; ++i) mto = g->tap_off[i] > mto ? g->tap_off[i] : mto;
+  dim3 grid((g->Cout / cot) * (g->Cin / 64), nsplit);
+  hipStream_t s = (hipStream_t)stream;
+#define WD_LAUNCH(COT_)                                                                          \
+  do {                                                                                          \
+    static bool attr = false;                                                                   \
+    if (!attr) {                                                                                \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_dma_kernel<COT_>),    \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);        \
+      attr = true;                                                                              \
+    }                                                                                           \
+    hipLaunchKernelGGL((conv_wgrad_dma_kernel<COT_>), grid, dim3(WD_THREADS), lds, s, *g,       \
+                       (const bf16_t*)x, (const bf16_t*)dy, partials, nsplit, kt, xb, mto);     \
+  } while (0)
+  if (cot == 128) WD_LAUNCH(128); else WD_LAUNCH(64);
+  return iic_launch_status();
+}

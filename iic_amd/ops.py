@@ -157,9 +157,10 @@ def conv_igemm(g, x_pt, w_t, out_pt, stats=None, res_grad=None, res_act=None, ac
 _WG_PART = {}
 
 
-def conv_wgrad(g, x_pt, dy_pt, wtaps, use_tr=True, out=None, accumulate=False):
-  """Returns dW fp32 [Co][Ci][kh][kw] flattened as [Co, Ci, wtaps]."""
-  ns = lib().iic_conv_wgrad_nsplit(ctypes.byref(g))
+def conv_wgrad(g, x_pt, dy_pt, wtaps, use_tr=True, out=None, accumulate=False, nsplit=None):
+  """Returns dW fp32 [Co][Ci][kh][kw] flattened as [Co, Ci, wtaps].  nsplit: override of the
+  split-K factor (tests: few splits = many K-tiles per workgroup)."""
+  ns = int(nsplit) if nsplit else lib().iic_conv_wgrad_nsplit(ctypes.byref(g))
   need = ns * g.ntaps * g.Cout * g.Cin
   key = str(x_pt.device)
   part = _WG_PART.get(key)

@@ -288,6 +288,29 @@ def _conv_backward_data(case, frag=False):
 @pytest.mark.parametrize("use_tr", [False, True])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_backward_weight(case, use_tr):
+  _conv_backward_weight(case, use_tr)
+
+
+def _wgrad_dma(on):
+  import ctypes
+  from iic_amd import _lib
+  ctypes.CDLL(_lib.LIB_PATH).iic_debug_enable_wgrad_dma(1 if on else 0)
+
+
+@pytest.mark.parametrize("dma", [True, False])
+@pytest.mark.parametrize("case,nsplit", [((64, 64, 3, 1, 1, 2, 49), 2), ((128, 128, 3, 1, 1, 20, 25), 3),
+                                         ((512, 512, 3, 1, 1, 6, 7), 1), ((64, 64, 3, 1, 1, 5, 13), 1)])
+def test_conv_backward_weight_long_k_ranges(case, nsplit, dma):
+  """Few splits => every workgroup walks many 128-pixel K-tiles: the double-buffered LDS-DMA
+  pipeline of conv_wgrad_dma.hip (dma=True) and the register-staged one of conv_wgrad.hip."""
+  _wgrad_dma(dma)
+  try:
+    _conv_backward_weight(case, True, nsplit=nsplit)
+  finally:
+    _wgrad_dma(True)
+
+
+def _conv_backward_weight(case, use_tr, nsplit=None):
   from iic_amd import geom, ops
   cin, cout, K, s, p, N, H = case
   x, w = _conv_inputs(cin, cout, K, N, H, 4)
@@ -299,7 +322,7 @@ def test_conv_backward_weight(case, use_tr):
   spec = geom.ConvSpec(cin, cout, K, s, p)
   g = geom.fwd_geom(spec, N, H, H, 1, 1)
   dW = ops.conv_wgrad(g, ops.pt_from_nchw(x.to(dev()), 1), ops.pt_from_nchw(dy.to(dev()), 1), K * K,
-                      use_tr=use_tr)
+                      use_tr=use_tr, nsplit=nsplit)
   torch.cuda.synchronize()
   got = dW.view(cout, cin, K, K).cpu()
   scale = ref.abs().max().item()

@@ -78,7 +78,15 @@ def main():
     t_f = timeit(lambda: ops.conv_igemm(gf, x, wf, y, stats=st), a.iters)
     t_b = timeit(lambda: [ops.conv_igemm(g, dy, wb, dx) for g in gb], a.iters)
     t_w = 0.0 if a.no_wgrad else timeit(lambda: ops.conv_wgrad(gf, x, dy, K * K, True), a.iters)
-    extra = ""
+    t_w0 = 0.0
+    if not a.no_wgrad:    # A/B: register-staged kernel
+      import ctypes
+      from iic_amd import _lib
+      L = ctypes.CDLL(_lib.LIB_PATH)
+      L.iic_debug_enable_wgrad_dma(0)
+      t_w0 = timeit(lambda: ops.conv_wgrad(gf, x, dy, K * K, True), a.iters)
+      L.iic_debug_enable_wgrad_dma(1)
+    extra = "" if a.no_wgrad else " | wgrad(reg-staged) %7.1f us" % t_w0
     if a.frag:
       if ops.frag_supported(gf):
         t2 = timeit(lambda: ops.conv_igemm(gf, x, pw[0], y, stats=st), a.iters)
