@@ -108,6 +108,9 @@ def _bn_training(bn):
 # ------------------------------------------------------------------------------------
 # Stem
 # ------------------------------------------------------------------------------------
+STEM_FUSED_BWD = [True]    # tests flip this to cross-check against the two-pass backward
+
+
 class _StemFn(torch.autograd.Function):
   @staticmethod
   def forward(ctx, x, w, gamma, beta, mod):
@@ -142,9 +145,15 @@ class _StemFn(torch.autograd.Function):
     N, C, H, W = x.shape
     dpool = dpool.contiguous()
     sums = ctx.mod._h_conv1.stats(x.device, "bwd")
-    ops.stem_bwd_reduce(x, w.detach(), coef, dpool, sums)
-    bcoef, dgamma, dbeta = ops.bn_bwd_finalize(sums, gamma.detach(), coef, 64, N * H * W)
-    dW = ops.stem_bwd_wgrad(x, w.detach(), coef, bcoef, dpool)
+    if STEM_FUSED_BWD[0] and ops.stem_bwd_fused_ok(C):
+      # one recompute pass: BN-backward sums + coefficient-free dW GEMMs, coefficients applied after
+      h = ops.stem_bwd_fused(x, w.detach(), coef, dpool, sums)
+      bcoef, dgamma, dbeta = ops.bn_bwd_finalize(sums, gamma.detach(), coef, 64, N * H * W)
+      dW = ops.stem_wgrad_combine(h, bcoef, w.detach())
+    else:
+      ops.stem_bwd_reduce(x, w.detach(), coef, dpool, sums)
+      bcoef, dgamma, dbeta = ops.bn_bwd_finalize(sums, gamma.detach(), coef, 64, N * H * W)
+      dW = ops.stem_bwd_wgrad(x, w.detach(), coef, bcoef, dpool)
     ops.POOL.release(dpool)
     ops.POOL.release(out)
     return None, dW, dgamma, dbeta, None

@@ -203,13 +203,18 @@ __device__ __forceinline__ int window_argmax(const float yv[4], const bool valid
 // ------------------------------------------------------------------------------------
 // 3/4. backward.  persistent over (n, ho) items; LDS: conv outputs y [2][W][64] fp32.
 //   MODE 0: sums[stripe][0][64] += sum g ; [1] += sum g*y
-//   MODE 1: dy = c1*g + c2*y + c3 (in LDS), dWpart[block][64][K] += dy^T . patch  (fp32 MFMA)
+//   MODE 1: dy = c1*g + c2*y + c3 (in LDS), dWpart[block][64][K] += dy^T . patch  (bf16 MFMA)
+//   MODE 2 (the product path): BOTH in one recompute pass.  dy is affine in (g, y) with
+//     per-channel coefficients, so dW[co][k] = c1[co]*G1 + c2[co]*G2 + c3[co]*G3[k] with
+//     G1 = sum g*patch, G2 = sum y*patch, G3 = sum patch over valid pixels: the three GEMMs
+//     need no coefficient and run next to the sum g / sum g*y reduction; the coefficients are
+//     applied to the 64 x K results afterwards (stem_wgrad_combine_kernel).
 // ------------------------------------------------------------------------------------
 template <int CIN, int MODE>
 __global__ __launch_bounds__(512) void stem_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                 const float* __restrict__ coef, const float* __restrict__ bcoef,
-                                const bf16_t* __restrict__ dpool, float* __restrict__ outbuf, int N,
-                                int H, int W) {
+                                const bf16_t* __restrict__ dpool, float* __restrict__ outbuf,
+                                float* __restrict__ sums2, int N, int H, int W) {
   constexpr int K = StemK<CIN>::K;
   constexpr int NKT = StemK<CIN>::NKT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(512) void stem_bwd_kernel(const float* __restrict__
   bf16_t* sDt = reinterpret_cast<bf16_t*>(smem_raw + (size_t)2 * W * STEM_CO * sizeof(float));
   float* sXr = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(sDt) +
                                         (((size_t)STEM_CO * PD * 2 + 15) & ~(size_t)15));
-  if (MODE == 1) {
+  if (MODE >= 1) {
     for (int i = threadIdx.x; i < STEM_CO * PD / 2; i += blockDim.x)
       reinterpret_cast<uint32_t*>(sDt)[i] = 0u;      // pad pixels stay zero forever
   }
@@ -245,13 +250,19 @@ __global__ __launch_bounds__(512) void stem_bwd_kernel(const float* __restrict__
   float sg[8], sgy[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) sg[i] = sgy[i] = 0.f;
-  f32x16 dacc[2][NKT];
+  f32x16 dacc[2][NKT];                      // MODE 1: dW;  MODE 2: G1 (g . patch)
+  f32x16 daccy[MODE == 2 ? 2 : 1][NKT];     // MODE 2: G2 (y . patch)
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+  for (int t = 0; t < NKT; ++t) {
 #pragma unroll
-    for (int t = 0; t < NKT; ++t)
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int r = 0; r < 16; ++r) dacc[h][t][r] = 0.f;
+#pragma unroll
+    for (int h = 0; h < (MODE == 2 ? 2 : 1); ++h)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) daccy[h][t][r] = 0.f;
+  }
 
   const long items = (long)N * Ho;
   for (long it = blockIdx.x; it < items; it += gridDim.x) {
@@ -296,12 +307,20 @@ __global__ __launch_bounds__(512) void stem_bwd_kernel(const float* __restrict__
         for (int q = 0; q < 4; ++q) yv[q] = valid[q] ? sY[lidx[q] + i] : 0.f;
         const int am = window_argmax(yv, valid, s_cf[0][c8 * 8 + i], s_cf[1][c8 * 8 + i]);
         const float g = (i & 1) ? bf16hi(gg[i >> 1]) : bf16lo(gg[i >> 1]);
-        if (MODE == 0) {
+        if (MODE == 0 || MODE == 2) {
           if (am >= 0) {
             sg[i] += g;
             sgy[i] += g * yv[am];
           }
-        } else {
+        }
+        if (MODE == 2) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (valid[q])
+              sDt[(c8 * 8 + i) * PD + (q >> 1) * WP + (2 * wo - 1 + (q & 1))] =
+                  f32_to_bf16(q == am ? g : 0.f);
+        }
+        if (MODE == 1) {
           const float cb1 = s_cf[2][c8 * 8 + i], cb2 = s_cf[3][c8 * 8 + i], cb3 = s_cf[4][c8 * 8 + i];
 #pragma unroll
           for (int q = 0; q < 4; ++q)
@@ -311,7 +330,7 @@ __global__ __launch_bounds__(512) void stem_bwd_kernel(const float* __restrict__
         }
       }
     }
-    if (MODE == 1) {
+    if (MODE >= 1) {
       // input rows 2ho-2 .. 2ho+1 (zero outside the image), columns -1 .. WP+8
       for (int idx = threadIdx.x; idx < CIN * 4 * WX; idx += blockDim.x) {
         const int c = idx / (4 * WX), r = (idx / WX) & 3, xx = idx % WX;
@@ -332,6 +351,20 @@ __global__ __launch_bounds__(512) void stem_bwd_kernel(const float* __restrict__
           if ((wave * 2 + sidx) * 16 >= WP) continue;
           const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(sDt + (long)i * PD + rs * WP + p0);
           const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(sDt + (long)(i + 32) * PD + rs * WP + p0);
+          bf16x8 ay0, ay1;
+          if (MODE == 2) {      // y operand straight from the fp32 conv rows (pixel-strided reads)
+            union { bf16x8 v; uint32_t u[4]; } y0, y1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int pa = p0 + 2 * e, pb = pa + 1;
+              const float* ya = sY + ((long)rs * W + (pa < W ? pa : 0)) * STEM_CO;
+              const float* yb = sY + ((long)rs * W + (pb < W ? pb : 0)) * STEM_CO;
+              y0.u[e] = pack_bf16x2(pa < W ? ya[i] : 0.f, pb < W ? yb[i] : 0.f);
+              y1.u[e] = pack_bf16x2(pa < W ? ya[i + 32] : 0.f, pb < W ? yb[i + 32] : 0.f);
+            }
+            ay0 = y0.v;
+            ay1 = y1.v;
+          }
 #pragma unroll
           for (int t = 0; t < NKT; ++t) {
             const int k = t * 32 + i;
@@ -346,6 +379,10 @@ __global__ __launch_bounds__(512) void stem_bwd_kernel(const float* __restrict__
             }
             dacc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bb.v, dacc[0][t], 0, 0, 0);
             dacc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bb.v, dacc[1][t], 0, 0, 0);
+            if (MODE == 2) {
+              daccy[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ay0, bb.v, daccy[0][t], 0, 0, 0);
+              daccy[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ay1, bb.v, daccy[1][t], 0, 0, 0);
+            }
           }
         }
       }
@@ -353,7 +390,7 @@ __global__ __launch_bounds__(512) void stem_bwd_kernel(const float* __restrict__
   }
 
   __syncthreads();
-  if (MODE == 0) {
+  if (MODE == 0 || MODE == 2) {
     float* red = sY;   // [blockDim][16]
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -361,31 +398,109 @@ __global__ __launch_bounds__(512) void stem_bwd_kernel(const float* __restrict__
       red[threadIdx.x * 16 + 8 + i] = sgy[i];
     }
     __syncthreads();
+    float* sums = MODE == 2 ? sums2 : outbuf;
     for (int o = threadIdx.x; o < 128; o += blockDim.x) {   // blockDim may be a single wave
       const int which = o >> 6, ch = o & 63;
       float t = 0.f;
       for (int th = (ch >> 3); th < (int)blockDim.x; th += 8) t += red[th * 16 + which * 8 + (ch & 7)];
-      atomicAdd(outbuf + (long)(blockIdx.x % IIC_STAT_STRIPES) * 2 * STEM_CO + which * STEM_CO + ch, t);
+      atomicAdd(sums + (long)(blockIdx.x % IIC_STAT_STRIPES) * 2 * STEM_CO + which * STEM_CO + ch, t);
     }
-  } else {
-    // reduce the waves' accumulators through LDS, then one partial [64][NKT*32] per block
+    __syncthreads();
+  }
+  if (MODE >= 1) {
+    // reduce the waves' accumulators through LDS, then one partial per block:
+    //   MODE 1: [64][LD];  MODE 2: [128][LD] = G1 rows 0..63, G2 rows 64..127
     float* red = sY;   // [nwaves][64][NKT*32]
     constexpr int LD = NKT * 32;
+    constexpr int ROWS = MODE == 2 ? 128 : 64;
+    float* pout = outbuf + (long)blockIdx.x * ROWS * LD;
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int pass = 0; pass < (MODE == 2 ? 2 : 1); ++pass) {
 #pragma unroll
-      for (int t = 0; t < NKT; ++t)
+      for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          red[((long)wave * 64 + h * 32 + mfma32_row(r, lane)) * LD + t * 32 + (lane & 31)] =
-              dacc[h][t][r];
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < 64 * LD; idx += blockDim.x) {
-      float t = 0.f;
-      for (int wv = 0; wv < nwaves; ++wv) t += red[(long)wv * 64 * LD + idx];
-      outbuf[(long)blockIdx.x * 64 * LD + idx] = t;
+        for (int t = 0; t < NKT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            red[((long)wave * 64 + h * 32 + mfma32_row(r, lane)) * LD + t * 32 + (lane & 31)] =
+                pass == 0 ? dacc[h][t][r] : daccy[MODE == 2 ? h : 0][t][r];
+      __syncthreads();
+      for (int idx = threadIdx.x; idx < 64 * LD; idx += blockDim.x) {
+        float t = 0.f;
+        for (int wv = 0; wv < nwaves; ++wv) t += red[(long)wv * 64 * LD + idx];
+        pout[(long)pass * 64 * LD + idx] = t;
+      }
+      __syncthreads();
     }
   }
+}
+
+// G3[k = (c, kh, kw)] = sum over images and valid conv positions (y, x) of the zero-padded input
+// x[c][y+kh-1][x+kw-1]: every input pixel (yy, xx) counts for tap (kh, kw) iff the conv position
+// (yy-kh+1, xx-kw+1) lies inside the image.  out[k] += ... (zero-initialised by the caller).
+__global__ __launch_bounds__(256) void stem_patch_sums_kernel(const float* __restrict__ x,
+                                                              float* __restrict__ out, int N, int CIN,
+                                                              int H, int W) {
+  __shared__ float red[9][256];
+  const int c = blockIdx.y;
+  float s[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) s[t] = 0.f;
+  const long per = (long)H * W, total = (long)N * per;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long n = i / per;
+    const int r = (int)(i - n * per);
+    const int yy = r / W, xx = r - yy * W;
+    const float v = x[(n * CIN + c) * per + r];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int y = yy - kh + 1, xq = xx - kw + 1;
+        if (y >= 0 && y < H && xq >= 0 && xq < W) s[kh * 3 + kw] += v;
+      }
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) red[t][threadIdx.x] = s[t];
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) red[t][threadIdx.x] += red[t][threadIdx.x + st];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 9) atomicAdd(out + c * 9 + threadIdx.x, red[threadIdx.x][0]);
+}
+
+// MODE 2 epilogue: dW[co][k] = c1[co]*sum_b G1 + c2[co]*sum_b G2 + c3[co]*sum_b G3[k]
+// (bcoef = [3][64] from bn_bwd_finalize: dy = c1*g + c2*y + c3).
+__global__ __launch_bounds__(256) void stem_wgrad_combine_kernel(const float* __restrict__ part,
+                                                                 int nblocks, int LD, int K,
+                                                                 const float* __restrict__ bcoef,
+                                                                 const float* __restrict__ g3,
+                                                                 float* __restrict__ dW) {
+  __shared__ float red[2][256];
+  const int idx = blockIdx.x;            // output element co*K + k
+  const int co = idx / K, k = idx - co * K;
+  float t1 = 0.f, t2 = 0.f;
+  for (int b = threadIdx.x; b < nblocks; b += 256) {
+    const float* pb = part + (long)b * 128 * LD;
+    t1 += pb[(long)co * LD + k];
+    t2 += pb[(long)(64 + co) * LD + k];
+  }
+  red[0][threadIdx.x] = t1;
+  red[1][threadIdx.x] = t2;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + s];
+      red[1][threadIdx.x] += red[1][threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+    dW[idx] = bcoef[co] * red[0][0] + bcoef[STEM_CO + co] * red[1][0] + bcoef[2 * STEM_CO + co] * g3[k];
 }
 
 // dW[co][k] = sum_b part[b][co][k]  (k < K), fp32 OIHW flatten.  One block per output
@@ -491,13 +606,15 @@ int iic_stem_apply_pool(const float* x, const float* w, const float* coef, void*
 
 static size_t stem_bwd_lds(int Cin, int W, int nseg, int mode) {
   size_t a = (size_t)2 * W * STEM_CO * sizeof(float);
-  if (mode == 1) {
+  if (mode >= 1) {
     const int WP = (W + 15) & ~15;
     const int PD = 2 * WP + 8;
-    a += (((size_t)STEM_CO * PD * 2 + 15) & ~(size_t)15) + (size_t)Cin * 4 * (WP + 10) * sizeof(float);
+    a += (((size_t)STEM_CO * PD * 2 + 15) & ~(size_t)15) +
+         (((size_t)Cin * 4 * (WP + 10) * sizeof(float) + 15) & ~(size_t)15);
   }
-  size_t b = mode == 0 ? (size_t)64 * nseg * 16 * sizeof(float)
-                       : (size_t)nseg * 64 * ((Cin * 9 + 31) / 32) * 32 * sizeof(float);
+  size_t b0 = (size_t)64 * nseg * 16 * sizeof(float);
+  size_t b1 = (size_t)nseg * 64 * ((Cin * 9 + 31) / 32) * 32 * sizeof(float);
+  size_t b = mode == 0 ? b0 : (b1 > b0 ? b1 : b0);
   return a > b ? a : b;
 }
 
@@ -520,12 +637,56 @@ int iic_stem_bwd_reduce(const float* x, const float* w, const float* coef, const
     }
     hipLaunchKernelGGL((stem_bwd_kernel<CI, 0>), dim3(grid), dim3(64 * nseg), lds,
                        (hipStream_t)stream, x, w, coef, (const float*)nullptr,
-                       (const bf16_t*)dpool_pt, sums, N, H, W);
+                       (const bf16_t*)dpool_pt, sums, (float*)nullptr, N, H, W);
   });
   return iic_launch_status();
 }
 
-long iic_stem_wgrad_partial_floats(void) { return (long)STEM_PERSIST_BLOCKS * 64 * 64; }
+long iic_stem_wgrad_partial_floats(void) { return (long)STEM_PERSIST_BLOCKS * 128 * 64 + 64; }
+
+/* One recompute pass: sums (as iic_stem_bwd_reduce) AND the coefficient-free weight-gradient
+ * GEMMs G1 = sum g*patch, G2 = sum y*patch into partials [blocks][128][LD] (+ G3 = sum patch in
+ * the last 64 floats of the partials buffer); *nblocks_out = blocks written. */
+int iic_stem_bwd_fused(const float* x, const float* w, const float* coef, const void* dpool_pt,
+                       float* sums, float* partials, int* nblocks_out, int N, int Cin, int H, int W,
+                       void* stream) {
+  int rc = stem_check(x, w, N, Cin, H, W);
+  if (rc) return rc;
+  if (!coef || !dpool_pt || !sums || !partials || !nblocks_out) return IIC_ERR_ARG;
+  const int nseg = (W + 31) / 32, Ho = H / 2 + 1;
+  long items = (long)N * Ho;
+  int grid = (int)(items < STEM_PERSIST_BLOCKS ? items : STEM_PERSIST_BLOCKS);
+  *nblocks_out = grid;
+  float* g3 = partials + (long)STEM_PERSIST_BLOCKS * 128 * 64;
+  if (hipMemsetAsync(g3, 0, 64 * sizeof(float), (hipStream_t)stream) != hipSuccess) return IIC_ERR_LAUNCH;
+  hipLaunchKernelGGL(stem_patch_sums_kernel, dim3(256, Cin), dim3(256), 0, (hipStream_t)stream, x, g3, N,
+                     Cin, H, W);
+  const size_t lds = stem_bwd_lds(Cin, W, nseg, 2);
+  STEM_DISPATCH(Cin, {
+    if (lds > 48 * 1024) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_bwd_kernel<CI, 2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        (void)hipGetLastError();
+        return IIC_ERR_UNSUPPORTED;
+      }
+    }
+    hipLaunchKernelGGL((stem_bwd_kernel<CI, 2>), dim3(grid), dim3(64 * nseg), lds,
+                       (hipStream_t)stream, x, w, coef, (const float*)nullptr,
+                       (const bf16_t*)dpool_pt, partials, sums, N, H, W);
+  });
+  return iic_launch_status();
+}
+
+/* dW (fp32 OIHW [64][Cin][3][3]) from the partials of iic_stem_bwd_fused and the BatchNorm
+ * backward coefficients bcoef = [3][64] (iic_bn_bwd_finalize). */
+int iic_stem_wgrad_combine(const float* partials, int nblocks, const float* bcoef, float* dW, int Cin,
+                           void* stream) {
+  if (!partials || !bcoef || !dW || nblocks <= 0 || Cin < 1 || Cin > 5) return IIC_ERR_ARG;
+  const int K = Cin * 9, LD = ((K + 31) / 32) * 32;
+  hipLaunchKernelGGL(stem_wgrad_combine_kernel, dim3(64 * K), dim3(256), 0, (hipStream_t)stream,
+                     partials, nblocks, LD, K, bcoef, partials + (long)STEM_PERSIST_BLOCKS * 128 * 64, dW);
+  return iic_launch_status();
+}
 
 int iic_stem_bwd_wgrad(const float* x, const float* w, const float* coef, const float* bcoef,
                        const void* dpool_pt, float* partials, float* dW, int N, int Cin, int H,
@@ -546,8 +707,8 @@ int iic_stem_bwd_wgrad(const float* x, const float* w, const float* coef, const 
       }
     }
     hipLaunchKernelGGL((stem_bwd_kernel<CI, 1>), dim3(grid), dim3(64 * nseg), lds,
-                       (hipStream_t)stream, x, w, coef, bcoef, (const bf16_t*)dpool_pt, partials, N,
-                       H, W);
+                       (hipStream_t)stream, x, w, coef, bcoef, (const bf16_t*)dpool_pt, partials,
+                       (float*)nullptr, N, H, W);
   });
   const int K = Cin * 9, LD = ((K + 31) / 32) * 32;
   hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(64 * K), dim3(256), 0,

@@ -254,14 +254,43 @@ _STEM_PART = {}
 
 def stem_bwd_wgrad(x, w, coef, bcoef, dpool):
   n, c, h, wd = x.shape
-  key = str(x.device)
-  part = _STEM_PART.get(key)
-  if part is None:
-    part = torch.empty(lib().iic_stem_wgrad_partial_floats(), dtype=F32, device=x.device)
-    _STEM_PART[key] = part
+  part = _stem_partials(x.device)
   dW = torch.empty_like(w)
   check(lib().iic_stem_bwd_wgrad(ptr(x), ptr(w), ptr(coef), ptr(bcoef), ptr(dpool), ptr(part),
                                  ptr(dW), n, c, h, wd, stream_ptr()), "iic_stem_bwd_wgrad")
+  return dW
+
+
+def _stem_partials(device):
+  key = str(device)
+  part = _STEM_PART.get(key)
+  if part is None:
+    part = torch.empty(lib().iic_stem_wgrad_partial_floats(), dtype=F32, device=device)
+    _STEM_PART[key] = part
+  return part
+
+
+def stem_bwd_fused_ok(cin):
+  """One-pass stem backward: K = 9*Cin must fit one 32-wide MFMA column tile."""
+  return 9 * cin <= 32
+
+
+def stem_bwd_fused(x, w, coef, dpool, sums):
+  """sums += (sum g, sum g*y) AND the coefficient-free dW GEMMs; returns the handle for
+  stem_wgrad_combine."""
+  n, c, h, wd = x.shape
+  part = _stem_partials(x.device)
+  nb = ctypes.c_int(0)
+  check(lib().iic_stem_bwd_fused(ptr(x), ptr(w), ptr(coef), ptr(dpool), ptr(sums), ptr(part),
+                                 ctypes.byref(nb), n, c, h, wd, stream_ptr()), "iic_stem_bwd_fused")
+  return part, nb.value
+
+
+def stem_wgrad_combine(handle, bcoef, w):
+  part, nb = handle
+  dW = torch.empty_like(w)
+  check(lib().iic_stem_wgrad_combine(ptr(part), nb, ptr(bcoef), ptr(dW), w.shape[1], stream_ptr()),
+        "iic_stem_wgrad_combine")
   return dW
 
 

@@ -179,6 +179,16 @@ long iic_stem_wgrad_partial_floats(void);
 int iic_stem_bwd_wgrad(const float* x, const float* w, const float* coef, const float* bcoef,
                        const void* dpool_pt, float* partials, float* dW, int N, int Cin, int H,
                        int W, void* stream);
+/* Fused stem backward (one recompute pass instead of two): `sums` as iic_stem_bwd_reduce AND the
+ * coefficient-free weight-gradient GEMMs G1 = sum g*patch, G2 = sum y*patch (+ G3 = sum patch)
+ * into `partials` (iic_stem_wgrad_partial_floats() floats).  dy = c1*g + c2*y + c3 is affine
+ * with per-channel coefficients, so after iic_bn_bwd_finalize
+ *   dW[co][k] = c1[co]*G1[co][k] + c2[co]*G2[co][k] + c3[co]*G3[k]   (iic_stem_wgrad_combine). */
+int iic_stem_bwd_fused(const float* x, const float* w, const float* coef, const void* dpool_pt,
+                       float* sums, float* partials, int* nblocks_out, int N, int Cin, int H, int W,
+                       void* stream);
+int iic_stem_wgrad_combine(const float* partials, int nblocks, const float* bcoef, float* dW, int Cin,
+                           void* stream);
 /* First-layer convolution of the VGG-style trunks from the fp32 NCHW image (Cin*K*K <= 128,
  * K = 3 (pad 1) or 5 (pad 2), 64 output channels) -- replaces the first nn.Conv2d of
  * code/archs/cluster/vgg.py:24-26 (net6c.py:16-20, net10a.py:21-25).  Exact fp32 MFMA.

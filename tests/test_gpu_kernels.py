@@ -454,6 +454,18 @@ def test_stem_forward_backward(cin, S):
   assert torch.allclose(dg.cpu(), gt.grad, rtol=1e-3, atol=1e-3 * gt.grad.abs().max().item())
   # dy and the input patch enter the dW GEMM as bf16 MFMA operands (fp32 accumulate)
   assert (dW.cpu() - wt.grad).abs().max() <= 4e-3 * wt.grad.abs().max().item()
+  # one-pass backward (the product path when 9*Cin <= 32): sums identical, dW from the
+  # coefficient-free GEMMs G1 (g), G2 (y), G3 (valid patch sums)
+  if ops.stem_bwd_fused_ok(cin):
+    sums2 = ops.new_stats(64, d)
+    h = ops.stem_bwd_fused(xd, wd, coef, dpp, sums2)
+    bcoef2, dg2, db2 = ops.bn_bwd_finalize(sums2, gamma.to(d), coef, 64, cnt)
+    dW2 = ops.stem_wgrad_combine(h, bcoef2, wd)
+    torch.cuda.synchronize()
+    assert torch.allclose(db2.cpu(), bt.grad, rtol=1e-3, atol=1e-3 * bt.grad.abs().max().item())
+    assert torch.allclose(dg2.cpu(), gt.grad, rtol=1e-3, atol=1e-3 * gt.grad.abs().max().item())
+    assert (dW2.cpu() - wt.grad).abs().max() <= 4e-3 * wt.grad.abs().max().item(), \
+        (dW2.cpu() - wt.grad).abs().max().item() / wt.grad.abs().max().item()
 
 
 # --------------------------------------------------------------------------------------
