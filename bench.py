@@ -200,18 +200,26 @@ def main():
 
   for _ in range(args.warmup):
     last = step()
-  timer = None
-  if not args.no_roofline and rank == 0:
-    timer = ConvTimer()
-    timer.install()
   fence()
   t0 = time.perf_counter()
   for _ in range(args.steps):
     last = step()
+  t_enq = time.perf_counter() - t0      # host time to enqueue the K steps (no sync inside)
   fence()
   dt = time.perf_counter() - t0
-  if timer is not None:
-    timer.uninstall()
+  # Roofline of the conv kernels: HIP events around every conv launch, on the launch stream, in
+  # extra steps run right AFTER the timed region.  (Inside the timed region the 316 event pairs
+  # per step cost ~6 ms/step of GPU bubbles -- measured -- and would distort `value`.)
+  timer = None
+  if not args.no_roofline:          # every rank runs the extra steps (they contain collectives)
+    if rank == 0:
+      timer = ConvTimer()
+      timer.install()
+    for _ in range(min(args.steps, 3)):
+      step()
+    fence()
+    if timer is not None:
+      timer.uninstall()
   loss_val = float(last)
   if world > 1:
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -230,7 +238,8 @@ def main():
                              "batch %d pairs/GPU, 5 sub-heads, k=70, bf16 MFMA convs / fp32 "
                              "stem+heads+loss, fused HIP Adam" % args.pairs,
                  "global_batch_pairs": args.pairs * world, "input": "96x96x1 grey -> sobel 2ch",
-                 "parallelism": "dp%d" % world, "final_loss": loss_val},
+                 "parallelism": "dp%d" % world, "final_loss": loss_val,
+                 "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps},
     }
     if timer is not None:
       s = timer.summary()
@@ -242,7 +251,8 @@ def main():
           "traffic_unit": "HBM bytes per launch (PMC, profiles/r01_pmc_traffic.json)",
           "algorithmic_bytes_per_launch": s["alg_bytes"],
           "launches_timed": s["launches"], "avg_launch_us": s["avg_us"],
-          "kernel_ms_per_step": s["total_ms"] / args.steps,
+          "timed_in": "%d instrumented steps run after the timed region (same batch, same state)" % min(args.steps, 3),
+          "kernel_ms_per_step": s["total_ms"] / min(args.steps, 3),
           "step_algorithmic_tflops": value / world * FLOP_PER_PAIR / 1e12,
           "step_frac_of_peak": value / world * FLOP_PER_PAIR / 1e12 / BF16_PEAK_TFLOPS,
         }

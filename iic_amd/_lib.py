@@ -129,6 +129,17 @@ def ptr(t):
   return None if t is None else t.data_ptr()
 
 
+_RAW_STREAM = None
+
+
 def stream_ptr():
+  """hipStream_t of torch's current stream on the current device.  Uses torch's raw-stream
+  accessor (0.2 us) instead of building a torch.cuda.Stream object per launch (several us: at
+  ~1100 launches per step the host was close to becoming the bottleneck)."""
+  global _RAW_STREAM
   import torch
+  if _RAW_STREAM is None:
+    _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", False)
+  if _RAW_STREAM:
+    return _RAW_STREAM(torch.cuda.current_device())
   return torch.cuda.current_stream().cuda_stream

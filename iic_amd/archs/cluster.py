@@ -108,7 +108,7 @@ def _bn_training(bn):
 # ------------------------------------------------------------------------------------
 # Stem
 # ------------------------------------------------------------------------------------
-STEM_FUSED_BWD = [True]    # tests flip this to cross-check against the two-pass backward
+STEM_FUSED_BWD = [os.environ.get("IIC_STEM_FUSED", "1") != "0"]   # 0: two-pass backward (cross-check)
 
 
 class _StemFn(torch.autograd.Function):

@@ -134,7 +134,13 @@ class WOperand(object):
 
 
 def frag_supported(g):
-  return USE_FRAG[0] and bool(lib().iic_conv_igemm_frag_supported(ctypes.byref(g)))
+  if not USE_FRAG[0]:
+    return False
+  ok = getattr(g, "_frag_ok", None)     # geometry objects are cached per (layer, shape)
+  if ok is None:
+    ok = bool(lib().iic_conv_igemm_frag_supported(ctypes.byref(g)))
+    g._frag_ok = ok
+  return ok
 
 
 def conv_igemm(g, x_pt, w_t, out_pt, stats=None, res_grad=None, res_act=None, accumulate=False):
