@@ -78,9 +78,19 @@ __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_dma_kernel(
   const int l31 = lane & 31;
   const int q = lane >> 4, i16 = lane & 15;
   const int ncit = g.Cin >> 6;
-  const int cot = blockIdx.x / ncit, cit = blockIdx.x - cot * ncit;
+  // XCD-aware work mapping: workgroups are dealt to the 8 XCDs round-robin by linear id.  All
+  // (co, ci) tiles of one K-split read the same input patch / dY rows, so they should share an
+  // L2: when the split count divides by 8, linear ids L, L+8, L+16, ... (one XCD) walk the tiles
+  // of one split before moving to the next split.
+  int tile = blockIdx.x, split = blockIdx.y;
+  if ((gridDim.y & 7) == 0) {
+    const int L = blockIdx.y * gridDim.x + blockIdx.x;
+    const int xcd = L & 7, j = L >> 3;
+    tile = j % (int)gridDim.x;
+    split = xcd + 8 * (j / (int)gridDim.x);
+  }
+  const int cot = tile / ncit, cit = tile - cot * ncit;
   const int co0 = cot * COT, ci0 = cit * 64;
-  const int split = blockIdx.y;
   const int per = (num_ktiles + nsplit - 1) / nsplit;
   const int kt0 = split * per;
   const int kt1 = min(num_ktiles, kt0 + per);
