@@ -108,6 +108,7 @@ def _bn_training(bn):
 # ------------------------------------------------------------------------------------
 # Stem
 # ------------------------------------------------------------------------------------
+BN_MASK_FROM_Y = [os.environ.get("IIC_BN_MASK_FROM_Y", "1") != "0"]
 STEM_FUSED_BWD = [os.environ.get("IIC_STEM_FUSED", "1") != "0"]   # 0: two-pass backward (cross-check)
 
 
@@ -270,10 +271,12 @@ class _BlockFn(torch.autograd.Function):
 
     # ---- bn1 backward; g1 = da1 * (a1 > 0)
     s1 = h1.stats(dev, "bwd")
-    ops.bn_bwd_reduce(da1, a1, y1, s1, N, Ho, Wo, 1, planes)
+    # a1 = relu(bn1(y1)) exactly: the ReLU mask comes from (y1, coef1), a1 is not read
+    m_act, m_coef = (None, coef1) if BN_MASK_FROM_Y[0] else (a1, None)
+    ops.bn_bwd_reduce(da1, m_act, y1, s1, N, Ho, Wo, 1, planes, mask_coef=m_coef)
     bc1, dg1, db1 = ops.bn_bwd_finalize(s1, g1.detach(), coef1, planes, cnt)
     dy1 = ops.pt_alloc(N, Ho, Wo, planes, 1, dev)
-    ops.bn_bwd_apply(da1, a1, y1, bc1, dy1, N, Ho, Wo, 1, planes)
+    ops.bn_bwd_apply(da1, m_act, y1, bc1, dy1, N, Ho, Wo, 1, planes, mask_coef=m_coef)
 
     # ---- conv1 backward: weight grad (side) || data grad (+ residual / downsample gradient)
     dW1 = on_side(lambda: ops.conv_wgrad(gf1, x, dy1, 9, use_tr)).view(planes, Cin, 3, 3)

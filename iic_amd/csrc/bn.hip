@@ -109,18 +109,34 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
 
 // sums[stripe][0][C] += sum g ; sums[stripe][1][C] += sum g*y   (g = dout * (act > 0))
 // block = 256 threads: channel chunk = tid % (C/8), pixel lane = tid / (C/8); grid-stride over rows.
+// MASK: 0 = g = dout, 1 = g = dout * (act > 0), 2 = g = dout * (scale*y + shift > 0) with the
+// forward coefficients mcoef: act = relu(scale*y + shift) was produced by bn_apply with exactly
+// this expression, so the mask is identical and the activation tensor is not read (one tensor
+// less).  HAS2: second BatchNorm (downsample branch) sharing g.
+template <int MASK, bool HAS2>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const bf16_t* __restrict__ dout, const bf16_t* __restrict__ act, const bf16_t* __restrict__ y,
-    const bf16_t* __restrict__ y2, float* __restrict__ sums, float* __restrict__ sums2, int N, int H,
-    int W, int P, int C) {
+    const bf16_t* __restrict__ y2, float* __restrict__ sums, float* __restrict__ sums2,
+    const float* __restrict__ mcoef, int N, int H, int W, int P, int C) {
   __shared__ float s_acc[256 * 8];
   const int c8n = C >> 3;
   const int PL = 256 / c8n;
   const int c8 = threadIdx.x % c8n, pl = threadIdx.x / c8n;
   const int Hp = H + 2 * P, Wp = W + 2 * P;
-  float sg[8], sgy[8], sgy2[8];
+  float sg[8], sgy[8], sgy2[HAS2 ? 8 : 1], msc[MASK == 2 ? 8 : 1], msh[MASK == 2 ? 8 : 1];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) sg[i] = sgy[i] = sgy2[i] = 0.f;
+  for (int i = 0; i < 8; ++i) sg[i] = sgy[i] = 0.f;
+  if (HAS2) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sgy2[HAS2 ? i : 0] = 0.f;
+  }
+  if (MASK == 2) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      msc[MASK == 2 ? i : 0] = mcoef[c8 * 8 + i];
+      msh[MASK == 2 ? i : 0] = mcoef[C + c8 * 8 + i];
+    }
+  }
   const long rows = (long)N * H;
   for (long row = blockIdx.x; row < rows; row += gridDim.x) {
     const int n = (int)(row / H), yy = (int)(row - (long)n * H);
@@ -129,26 +145,31 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
       const long off = rbase + (long)xq * C;
       float g[8], v[8];
       unpack8(*reinterpret_cast<const uint4*>(dout + off), g);
-      if (act) {
+      if (MASK == 1) {
         float a[8];
         unpack8(*reinterpret_cast<const uint4*>(act + off), a);
 #pragma unroll
         for (int i = 0; i < 8; ++i) g[i] = a[i] > 0.f ? g[i] : 0.f;
       }
       unpack8(*reinterpret_cast<const uint4*>(y + off), v);
+      if (MASK == 2) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          g[i] = (v[i] * msc[MASK == 2 ? i : 0] + msh[MASK == 2 ? i : 0]) > 0.f ? g[i] : 0.f;
+      }
 #pragma unroll
       for (int i = 0; i < 8; ++i) { sg[i] += g[i]; sgy[i] += g[i] * v[i]; }
-      if (y2) {
+      if (HAS2) {
         unpack8(*reinterpret_cast<const uint4*>(y2 + off), v);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) sgy2[i] += g[i] * v[i];
+        for (int i = 0; i < 8; ++i) sgy2[HAS2 ? i : 0] += g[i] * v[i];
       }
     }
   }
   const int stripe = blockIdx.x % IIC_STAT_STRIPES;
   // three LDS reductions over the pixel lanes (sum g, sum g*y, sum g*y2)
-  for (int which = 0; which < (y2 ? 3 : 2); ++which) {
-    const float* src = which == 0 ? sg : (which == 1 ? sgy : sgy2);
+  for (int which = 0; which < (HAS2 ? 3 : 2); ++which) {
+    const float* src = which == 0 ? sg : (which == 1 || !HAS2 ? sgy : sgy2);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 8; ++i) s_acc[(pl * c8n + c8) * 8 + i] = src[i];
@@ -158,7 +179,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
       for (int p = 0; p < PL; ++p) t += s_acc[(p * c8n + (c >> 3)) * 8 + (c & 7)];
       if (which == 0) {
         atomicAdd(sums + (long)stripe * 2 * C + c, t);
-        if (y2) atomicAdd(sums2 + (long)stripe * 2 * C + c, t);
+        if (HAS2) atomicAdd(sums2 + (long)stripe * 2 * C + c, t);
       } else if (which == 1) {
         atomicAdd(sums + (long)stripe * 2 * C + C + c, t);
       } else {
@@ -198,7 +219,8 @@ __global__ void bn_bwd_finalize_kernel(float* __restrict__ sums, const float* __
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const bf16_t* __restrict__ dout, const bf16_t* __restrict__ act, const bf16_t* __restrict__ y,
     const float* __restrict__ bcoef, bf16_t* __restrict__ dy, const bf16_t* __restrict__ y2,
-    const float* __restrict__ bcoef2, bf16_t* __restrict__ dy2, int H, int W, int P, int C) {
+    const float* __restrict__ bcoef2, bf16_t* __restrict__ dy2, const float* __restrict__ mcoef,
+    int H, int W, int P, int C) {
   const int c8n = C >> 3;
   const int item = blockIdx.y * blockDim.x + threadIdx.x;
   if (item >= W * c8n) return;
@@ -206,28 +228,37 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
   const int n = blockIdx.x / H, yy = blockIdx.x - n * H;
   const int Hp = H + 2 * P, Wp = W + 2 * P;
   const long off = (((long)n * Hp + yy + P) * Wp + xq + P) * C + c8 * 8;
-  float g[8], v[8], o[8];
+  float g[8], v[8], o[8], k1[8], k2[8], k3[8];
+  auto ld8 = [](const float* p, float (&d)[8]) {
+    *reinterpret_cast<float4*>(d) = *reinterpret_cast<const float4*>(p);
+    *reinterpret_cast<float4*>(d + 4) = *reinterpret_cast<const float4*>(p + 4);
+  };
   unpack8(*reinterpret_cast<const uint4*>(dout + off), g);
+  unpack8(*reinterpret_cast<const uint4*>(y + off), v);
   if (act) {
     float a[8];
     unpack8(*reinterpret_cast<const uint4*>(act + off), a);
 #pragma unroll
     for (int i = 0; i < 8; ++i) g[i] = a[i] > 0.f ? g[i] : 0.f;
-  }
-  unpack8(*reinterpret_cast<const uint4*>(y + off), v);
+  } else if (mcoef) {      // mask from y (see bn_bwd_reduce_kernel)
+    ld8(mcoef + c8 * 8, k1);
+    ld8(mcoef + C + c8 * 8, k2);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int c = c8 * 8 + i;
-    o[i] = bcoef[c] * g[i] + bcoef[C + c] * v[i] + bcoef[2 * C + c];
+    for (int i = 0; i < 8; ++i) g[i] = (v[i] * k1[i] + k2[i]) > 0.f ? g[i] : 0.f;
   }
+  ld8(bcoef + c8 * 8, k1);
+  ld8(bcoef + C + c8 * 8, k2);
+  ld8(bcoef + 2 * C + c8 * 8, k3);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = k1[i] * g[i] + k2[i] * v[i] + k3[i];
   *reinterpret_cast<uint4*>(dy + off) = pack8(o);
   if (y2) {
     unpack8(*reinterpret_cast<const uint4*>(y2 + off), v);
+    ld8(bcoef2 + c8 * 8, k1);
+    ld8(bcoef2 + C + c8 * 8, k2);
+    ld8(bcoef2 + 2 * C + c8 * 8, k3);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int c = c8 * 8 + i;
-      o[i] = bcoef2[c] * g[i] + bcoef2[C + c] * v[i] + bcoef2[2 * C + c];
-    }
+    for (int i = 0; i < 8; ++i) o[i] = k1[i] * g[i] + k2[i] * v[i] + k3[i];
     *reinterpret_cast<uint4*>(dy2 + off) = pack8(o);
   }
 }
@@ -262,15 +293,23 @@ int iic_bn_apply(const void* y, const float* coef, const void* res, const void* 
 }
 
 int iic_bn_bwd_reduce(const void* dout, const void* act, const void* y, const void* y2, float* sums,
-                      float* sums2, int N, int H, int W, int P, int C, void* stream) {
-  if (!dout || !y || !sums || N <= 0) return IIC_ERR_ARG;
+                      float* sums2, const float* mask_coef, int N, int H, int W, int P, int C,
+                      void* stream) {
+  if (!dout || !y || !sums || N <= 0 || (act && mask_coef)) return IIC_ERR_ARG;
   if (check_c(C)) return IIC_ERR_UNSUPPORTED;
   if ((y2 == nullptr) != (sums2 == nullptr)) return IIC_ERR_ARG;
   long rows = (long)N * H;
   int grid = (int)(rows < 2048 ? rows : 2048);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)dout, (const bf16_t*)act, (const bf16_t*)y, (const bf16_t*)y2,
-                     sums, sums2, N, H, W, P, C);
+#define BN_RED_LAUNCH(M_, H2_)                                                                  \
+  hipLaunchKernelGGL((bn_bwd_reduce_kernel<M_, H2_>), dim3(grid), dim3(256), 0,                 \
+                     (hipStream_t)stream, (const bf16_t*)dout, (const bf16_t*)act,              \
+                     (const bf16_t*)y, (const bf16_t*)y2, sums, sums2, mask_coef, N, H, W, P, C)
+  const int mode = act ? 1 : (mask_coef ? 2 : 0);
+  if (y2) {
+    if (mode == 1) BN_RED_LAUNCH(1, true); else if (mode == 2) BN_RED_LAUNCH(2, true); else BN_RED_LAUNCH(0, true);
+  } else {
+    if (mode == 1) BN_RED_LAUNCH(1, false); else if (mode == 2) BN_RED_LAUNCH(2, false); else BN_RED_LAUNCH(0, false);
+  }
   return iic_launch_status();
 }
 
@@ -283,16 +322,16 @@ int iic_bn_bwd_finalize(float* sums, const float* gamma, const float* coef, floa
 }
 
 int iic_bn_bwd_apply(const void* dout, const void* act, const void* y, const float* bcoef, void* dy,
-                     const void* y2, const float* bcoef2, void* dy2, int N, int H, int W, int P,
-                     int C, void* stream) {
-  if (!dout || !y || !bcoef || !dy || N <= 0) return IIC_ERR_ARG;
+                     const void* y2, const float* bcoef2, void* dy2, const float* mask_coef, int N,
+                     int H, int W, int P, int C, void* stream) {
+  if (!dout || !y || !bcoef || !dy || N <= 0 || (act && mask_coef)) return IIC_ERR_ARG;
   if (C % 8 != 0) return IIC_ERR_UNSUPPORTED;
   if ((y2 == nullptr) != (bcoef2 == nullptr) || (y2 == nullptr) != (dy2 == nullptr))
     return IIC_ERR_ARG;
   dim3 grid(N * H, (W * (C / 8) + 255) / 256);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)dout, (const bf16_t*)act, (const bf16_t*)y, bcoef, (bf16_t*)dy,
-                     (const bf16_t*)y2, bcoef2, (bf16_t*)dy2, H, W, P, C);
+                     (const bf16_t*)y2, bcoef2, (bf16_t*)dy2, mask_coef, H, W, P, C);
   return iic_launch_status();
 }
 

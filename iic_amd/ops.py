@@ -204,9 +204,11 @@ def bn_apply(y, coef, out, N, H, W, P, C, res=None, y2=None, coef2=None, relu=Tr
   return out
 
 
-def bn_bwd_reduce(dout, act, y, sums, N, H, W, P, C, y2=None, sums2=None):
-  check(lib().iic_bn_bwd_reduce(ptr(dout), ptr(act), ptr(y), ptr(y2), ptr(sums), ptr(sums2), N, H,
-                                W, P, C, stream_ptr()), "iic_bn_bwd_reduce")
+def bn_bwd_reduce(dout, act, y, sums, N, H, W, P, C, y2=None, sums2=None, mask_coef=None):
+  """mask_coef: forward coef of this BN when act = relu(bn(y)) exactly (pass act=None): the ReLU
+  mask is recomputed from y instead of reading the activation tensor."""
+  check(lib().iic_bn_bwd_reduce(ptr(dout), ptr(act), ptr(y), ptr(y2), ptr(sums), ptr(sums2),
+                                ptr(mask_coef), N, H, W, P, C, stream_ptr()), "iic_bn_bwd_reduce")
 
 
 def bn_bwd_finalize(sums, gamma, coef, C, count):
@@ -218,9 +220,10 @@ def bn_bwd_finalize(sums, gamma, coef, C, count):
   return bcoef, dgamma, dbeta
 
 
-def bn_bwd_apply(dout, act, y, bcoef, dy, N, H, W, P, C, y2=None, bcoef2=None, dy2=None):
+def bn_bwd_apply(dout, act, y, bcoef, dy, N, H, W, P, C, y2=None, bcoef2=None, dy2=None,
+                 mask_coef=None):
   check(lib().iic_bn_bwd_apply(ptr(dout), ptr(act), ptr(y), ptr(bcoef), ptr(dy), ptr(y2),
-                               ptr(bcoef2), ptr(dy2), N, H, W, P, C, stream_ptr()),
+                               ptr(bcoef2), ptr(dy2), ptr(mask_coef), N, H, W, P, C, stream_ptr()),
         "iic_bn_bwd_apply")
 
 

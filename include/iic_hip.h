@@ -154,15 +154,19 @@ int iic_bn_apply(const void* y, const float* coef, const void* res, const void* 
                  const float* coef2, void* out, int N, int H, int W, int P, int C, int relu,
                  void* stream);
 /* sums[stripe][2][C] += sum g, sum g*y  with g = dout * (act > 0) (act nullable => g = dout);
- * second BN (y2/sums2) optional (downsample branch shares g).                           */
+ * second BN (y2/sums2) optional (downsample branch shares g).
+ * mask_coef (nullable, exclusive with act): the forward coef of THIS BatchNorm when its
+ * activation was act = relu(scale*y + shift) with nothing added: the mask is then recomputed
+ * as (scale*y + shift > 0) and the activation tensor is not read at all.                  */
 int iic_bn_bwd_reduce(const void* dout, const void* act, const void* y, const void* y2,
-                      float* sums, float* sums2, int N, int H, int W, int P, int C, void* stream);
+                      float* sums, float* sums2, const float* mask_coef, int N, int H, int W, int P,
+                      int C, void* stream);
 /* from sums -> bcoef[0..2][C] = c1,c2,c3 (dy = c1*g + c2*y + c3), dgamma, dbeta. Re-zeroes sums. */
 int iic_bn_bwd_finalize(float* sums, const float* gamma, const float* coef, float* bcoef,
                         float* dgamma, float* dbeta, int C, long count, void* stream);
 int iic_bn_bwd_apply(const void* dout, const void* act, const void* y, const float* bcoef,
-                     void* dy, const void* y2, const float* bcoef2, void* dy2, int N, int H, int W,
-                     int P, int C, void* stream);
+                     void* dy, const void* y2, const float* bcoef2, void* dy2,
+                     const float* mask_coef, int N, int H, int W, int P, int C, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * Stem: conv3x3(Cin<=5 -> 64, pad 1, no bias) + BN + ReLU + MaxPool(k2,s2,p1), computed

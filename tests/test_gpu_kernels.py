@@ -397,6 +397,20 @@ def test_bn_forward_backward_kernels():
   assert torch.allclose(dg.cpu(), gt.grad, rtol=2e-3, atol=2e-3 * gt.grad.abs().max().item())
   assert torch.allclose(db.cpu(), bt.grad, rtol=2e-3, atol=2e-3 * bt.grad.abs().max().item())
   assert (ops.pt_to_nchw(dy, 1).cpu() - yt.grad).abs().max() <= 1e-2 * yt.grad.abs().max()
+  # mask recomputed from y (act = relu(bn(y)) with nothing added): identical to reading act
+  a_plain = torch.zeros_like(yp)
+  ops.bn_apply(yp, coef, a_plain, N, H, H, 1, C, relu=True)
+  s_a, s_m = ops.new_stats(C, d), ops.new_stats(C, d)
+  ops.bn_bwd_reduce(dp, a_plain, yp, s_a, N, H, H, 1, C)
+  ops.bn_bwd_reduce(dp, None, yp, s_m, N, H, H, 1, C, mask_coef=coef)
+  torch.cuda.synchronize()
+  assert torch.allclose(s_a.sum(0), s_m.sum(0), rtol=1e-5, atol=1e-4)
+  bc_a, _, _ = ops.bn_bwd_finalize(s_a, gamma.to(d), coef, C, cnt)
+  dy_a, dy_m = torch.zeros_like(yp), torch.zeros_like(yp)
+  ops.bn_bwd_apply(dp, a_plain, yp, bc_a, dy_a, N, H, H, 1, C)
+  ops.bn_bwd_apply(dp, None, yp, bc_a, dy_m, N, H, H, 1, C, mask_coef=coef)
+  torch.cuda.synchronize()
+  assert torch.equal(dy_a, dy_m)
 
 
 # --------------------------------------------------------------------------------------
