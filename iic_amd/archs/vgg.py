@@ -90,10 +90,11 @@ class _StageFn(torch.autograd.Function):
     else:
       da = dout
     sums = st.holder.stats(dev, "bwd")
-    ops.bn_bwd_reduce(da, a, y, sums, N, Ho, Wo, P, C)
+    # a = relu(bn(y)) exactly: the ReLU mask is recomputed from (y, coef), a is not read here
+    ops.bn_bwd_reduce(da, None, y, sums, N, Ho, Wo, P, C, mask_coef=coef)
     bcoef, dgamma, dbeta = ops.bn_bwd_finalize(sums, gamma.detach(), coef, C, cnt)
     dy = ops.pt_alloc(N, Ho, Wo, C, P, dev)
-    ops.bn_bwd_apply(da, a, y, bcoef, dy, N, Ho, Wo, P, C)
+    ops.bn_bwd_apply(da, None, y, bcoef, dy, N, Ho, Wo, P, C, mask_coef=coef)
     dx = None
     if st.first:
       dW = ops.firstconv_wgrad(x, dy, tuple(w.shape), st.K, st.pad, P)

@@ -20,27 +20,7 @@
 #include "common.h"
 #include "../../include/iic_hip.h"
 
-#define STEM_CO 64
-#define STEM_PERSIST_BLOCKS 1024
-
-template <int CIN> struct StemK {
-  static constexpr int K = CIN * 9;
-  static constexpr int KS = (K + 1) / 2;       // MFMA k-steps (2 k per step)
-  static constexpr int NKT = (K + 31) / 32;    // 32-wide column tiles of the dW GEMM
-};
-
-template <int CIN>
-__device__ __forceinline__ void stem_load_w(const float* __restrict__ w, int lane,
-                                            float (&wr)[2][StemK<CIN>::KS]) {
-  constexpr int K = StemK<CIN>::K;
-  const int j = lane & 31, kk = lane >> 5;
-#pragma unroll
-  for (int s = 0; s < StemK<CIN>::KS; ++s) {
-    const int k = 2 * s + kk;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) wr[h][s] = k < K ? w[(j + 32 * h) * K + k] : 0.f;
-  }
-}
+#include "stem_common.h"
 
 // conv outputs for 32 pixels (row y, cols x0..x0+31) x 64 couts of one image.
 template <int CIN>
@@ -182,22 +162,6 @@ __global__ __launch_bounds__(512) void stem_apply_pool_kernel(const float* __res
         make_uint4(pack_bf16x2(m[0], m[1]), pack_bf16x2(m[2], m[3]), pack_bf16x2(m[4], m[5]),
                    pack_bf16x2(m[6], m[7]));
   }
-}
-
-// Routing of the pooled gradient to the conv grid for one (window, channel): returns the
-// LDS index (0..3 -> (rs,cs)) of the arg-max of relu(bn(y)) in scan order (first max wins,
-// as torch's max_pool2d), or -1 when the max is not positive (ReLU kills the gradient).
-__device__ __forceinline__ int window_argmax(const float yv[4], const bool valid[4], float sc,
-                                             float sh) {
-  float best = -1.f;
-  int bi = -1;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    if (!valid[q]) continue;
-    const float a = fmaxf(yv[q] * sc + sh, 0.f);   // fp32 compare, like the fp32 reference
-    if (a > best) { best = a; bi = q; }
-  }
-  return best > 0.f ? bi : -1;
 }
 
 // ------------------------------------------------------------------------------------
@@ -441,36 +405,58 @@ __global__ __launch_bounds__(512) void stem_bwd_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void stem_patch_sums_kernel(const float* __restrict__ x,
                                                               float* __restrict__ out, int N, int CIN,
                                                               int H, int W) {
+  // Inclusion-exclusion instead of 9 predicated sums per pixel: tap (kh, kw) covers every input
+  // pixel except the last / no / the first row (kh = 0 / 1 / 2) and column (kw likewise), so
+  //   G3 = T - R[kh] - C[kw] + X[kh][kw]
+  // with T = total, R = excluded-row sum, C = excluded-column sum, X = excluded corner.
+  // Block = one (image, channel) plane slice: rows strided over blocks, no divisions per pixel.
   __shared__ float red[9][256];
   const int c = blockIdx.y;
-  float s[9];
-#pragma unroll
-  for (int t = 0; t < 9; ++t) s[t] = 0.f;
-  const long per = (long)H * W, total = (long)N * per;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long n = i / per;
-    const int r = (int)(i - n * per);
-    const int yy = r / W, xx = r - yy * W;
-    const float v = x[(n * CIN + c) * per + r];
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const int y = yy - kh + 1, xq = xx - kw + 1;
-        if (y >= 0 && y < H && xq >= 0 && xq < W) s[kh * 3 + kw] += v;
-      }
+  float T = 0.f, r0 = 0.f, r1 = 0.f, c0 = 0.f, c1 = 0.f, x00 = 0.f, x01 = 0.f, x10 = 0.f, x11 = 0.f;
+  // 256 threads = 8 rows in flight x 32 column lanes (latency-bound otherwise: one dependent
+  // load per row per block)
+  const long rows = (long)N * H;
+  const int rl = threadIdx.x >> 5, cl = threadIdx.x & 31;
+  for (long row = (long)blockIdx.x * 8 + rl; row < rows; row += (long)gridDim.x * 8) {
+    const long n = row / H;
+    const int yy = (int)(row - n * H);
+    const float* p = x + ((n * CIN + c) * H + yy) * (long)W;
+    float t = 0.f;
+    for (int xx = cl; xx < W; xx += 32) t += p[xx];
+    T += t;
+    if (yy == 0) r0 += t;
+    if (yy == H - 1) r1 += t;
+    if (cl == 0) {
+      const float a = p[0], b = p[W - 1];
+      c0 += a;
+      c1 += b;
+      if (yy == 0) { x00 += a; x01 += b; }
+      if (yy == H - 1) { x10 += a; x11 += b; }
+    }
   }
+  const float v[9] = {T, r0, r1, c0, c1, x00, x01, x10, x11};
 #pragma unroll
-  for (int t = 0; t < 9; ++t) red[t][threadIdx.x] = s[t];
+  for (int t = 0; t < 9; ++t) red[t][threadIdx.x] = v[t];
   __syncthreads();
-  for (int st = 128; st > 0; st >>= 1) {
+  for (int st = blockDim.x >> 1; st > 0; st >>= 1) {
     if (threadIdx.x < st) {
 #pragma unroll
       for (int t = 0; t < 9; ++t) red[t][threadIdx.x] += red[t][threadIdx.x + st];
     }
     __syncthreads();
   }
-  if (threadIdx.x < 9) atomicAdd(out + c * 9 + threadIdx.x, red[threadIdx.x][0]);
+  if (threadIdx.x < 9) {
+    const int kh = threadIdx.x / 3, kw = threadIdx.x % 3;
+    // excluded row: kh = 0 -> last row (H-1), kh = 2 -> first row (0); same for columns
+    const float R = kh == 0 ? red[2][0] : (kh == 2 ? red[1][0] : 0.f);
+    const float C = kw == 0 ? red[4][0] : (kw == 2 ? red[3][0] : 0.f);
+    float X = 0.f;
+    if (kh == 0 && kw == 0) X = red[8][0];   // row H-1, col W-1
+    if (kh == 0 && kw == 2) X = red[7][0];   // row H-1, col 0
+    if (kh == 2 && kw == 0) X = red[6][0];   // row 0,   col W-1
+    if (kh == 2 && kw == 2) X = red[5][0];   // row 0,   col 0
+    atomicAdd(out + c * 9 + threadIdx.x, red[0][0] - R - C + X);
+  }
 }
 
 // MODE 2 epilogue: dW[co][k] = c1[co]*sum_b G1 + c2[co]*sum_b G2 + c3[co]*sum_b G3[k]
@@ -576,6 +562,14 @@ static int stem_check(const void* x, const void* w, int N, int Cin, int H, int W
   return IIC_OK;
 }
 
+// stem_bwd2.hip
+int iic_stem_bwd2_supported(int Cin, int W);
+int iic_stem_bwd2_launch(const float* x, const float* w, const float* coef, const void* dpool_pt,
+                         float* sums, float* partials, int* nblocks_out, int N, int Cin, int H, int W,
+                         void* stream);
+static int g_stem_bwd2 = 1;
+extern "C" void iic_debug_enable_stem_bwd2(int v) { g_stem_bwd2 = v; }
+
 extern "C" {
 
 int iic_stem_stats(const float* x, const float* w, float* stats, int N, int Cin, int H, int W,
@@ -659,8 +653,10 @@ int iic_stem_bwd_fused(const float* x, const float* w, const float* coef, const 
   *nblocks_out = grid;
   float* g3 = partials + (long)STEM_PERSIST_BLOCKS * 128 * 64;
   if (hipMemsetAsync(g3, 0, 64 * sizeof(float), (hipStream_t)stream) != hipSuccess) return IIC_ERR_LAUNCH;
-  hipLaunchKernelGGL(stem_patch_sums_kernel, dim3(256, Cin), dim3(256), 0, (hipStream_t)stream, x, g3, N,
+  hipLaunchKernelGGL(stem_patch_sums_kernel, dim3(512, Cin), dim3(256), 0, (hipStream_t)stream, x, g3, N,
                      Cin, H, W);
+  if (g_stem_bwd2 && iic_stem_bwd2_supported(Cin, W))      // register-resident routing (stem_bwd2.hip)
+    return iic_stem_bwd2_launch(x, w, coef, dpool_pt, sums, partials, nblocks_out, N, Cin, H, W, stream);
   const size_t lds = stem_bwd_lds(Cin, W, nseg, 2);
   STEM_DISPATCH(Cin, {
     if (lds > 48 * 1024) {
