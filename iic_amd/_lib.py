@@ -28,6 +28,7 @@ class ConvGeom(Structure):
     ("tap_w", c_int32 * IIC_MAX_TAPS),
     ("NP", c_int32),
     ("NP256", c_int32),
+    ("NP64", c_int32),
   ]
 
 

@@ -14,14 +14,48 @@
 //     (input patch; dY at COT = 64) unit ^= (row >> 1) & 1, 256-B rows (dY at COT = 128)
 //     unit ^= row & 3; the DMA applies the swizzle on its source address;
 //   * rows past the end of the batch take their dY from pixel 0 of the PT tensor (zero border);
-//   * row bookkeeping by (n, y, x) walkers, tables written two K-tiles ahead.
+//   * row bookkeeping by (n, y, x) walkers, tables written ahead of their use;
+//   * the DMA ring is NBUF deep (K-tiles of BMK = 64 pixels, 4 buffers, where LDS allows): with
+//     one K-tile of prefetch the ~2-4 us HBM latency exceeded the ~1-2 us of MFMA work per tile
+//     and every tile waited for its data; each wave issues a FIXED number of DMA instructions per
+//     tile so that a counted s_waitcnt vmcnt(N) retires exactly tile kt.
 #include "common.h"
 #include "../../include/iic_hip.h"
 
-#define WD_BM 128
 #define WD_THREADS 768
-#define WD_NTAB 4
-#define WD_TAB_BYTES (WD_NTAB * WD_BM * (4 + 2))
+#define WD_NTAB 8                               // table ring (>= NBUF + 2, power of two)
+#define WD_TAB_BYTES(BMK_) (WD_NTAB * (BMK_) * (4 + 2))
+
+__device__ __forceinline__ void wd_wait_vmcnt(int n) {   // counted wait, n uniform
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+    case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+    case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+    case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+    case 21: asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); break;
+    case 22: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
+    case 23: asm volatile("s_waitcnt vmcnt(23)" ::: "memory"); break;
+    case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // over-waiting is always safe
+  }
+}
 
 typedef s16x4 __attribute__((address_space(3))) * wd_lds_s16x4_ptr;
 
@@ -56,19 +90,19 @@ __device__ __forceinline__ void wd_walk_pixels(const WdWalk& w, const iic_conv_g
   pout = valid ? (n * g.out_Hp + y * g.ty + g.py) * g.out_Wp + x * g.tx + g.px : -1;
 }
 
-template <int COT>
+template <int COT, int WD_BM, int NBUF>
 __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_dma_kernel(
     const iic_conv_geom g, const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
     float* __restrict__ partials, int nsplit, int num_ktiles, int xb_bytes, int max_tap_off) {
   constexpr int CS = COT / 64;                  // 32-wide co sub-tiles per wave
   constexpr int DROW = COT * 2;                 // dY tile row bytes (256 | 128)
-  constexpr int DB = WD_BM * DROW;              // dY tile bytes (32 KB | 16 KB)
+  constexpr int DB = WD_BM * DROW;              // dY tile bytes
   constexpr int DBLK = DB / 1024;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   typedef unsigned char __attribute__((address_space(3))) * lds_u8_ptr;
-  unsigned char* const sX = smem_raw;                        // [2][xb_bytes]
-  unsigned char* const sD = smem_raw + 2 * xb_bytes;         // [2][DB]
-  int* const s_pout = reinterpret_cast<int*>(sD + 2 * DB);   // [4][128]
+  unsigned char* const sX = smem_raw;                        // [NBUF][xb_bytes]
+  unsigned char* const sD = smem_raw + NBUF * xb_bytes;      // [NBUF][DB]
+  int* const s_pout = reinterpret_cast<int*>(sD + NBUF * DB);   // [NTAB][BMK]
   unsigned short* const s_prow = reinterpret_cast<unsigned short*>(s_pout + WD_NTAB * WD_BM);
   const uint32_t sXo = (uint32_t)(uintptr_t)(lds_u8_ptr)sX, sDo = (uint32_t)(uintptr_t)(lds_u8_ptr)sD;
 
@@ -126,7 +160,8 @@ __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_dma_kernel(
     wd_walk_init(wr, g, kt0 * WD_BM + (tid & (WD_BM - 1)));
     wd_walk_init(w0, g, kt0 * WD_BM);
     wd_walk_init(w1, g, kt0 * WD_BM + WD_BM - 1);
-    int plo_q[3], nblk_q[3];
+    // first input pixel / block count of the tabulated tiles (uniform), ring in LDS
+    int* const s_plo = reinterpret_cast<int*>(s_prow + WD_NTAB * WD_BM);   // [NTAB][2]
     auto tabulate = [&](int kt) {   // table of K-tile kt (where the walkers stand), then advance
       int pin, pout, p0, p1, dummy;
       wd_walk_pixels(w0, g, p0, dummy);
@@ -141,18 +176,24 @@ __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_dma_kernel(
       wd_walk_advance(wr, g, d_y, d_x);
       wd_walk_advance(w0, g, d_y, d_x);
       wd_walk_advance(w1, g, d_y, d_x);
-      plo_q[0] = plo_q[1];
-      nblk_q[0] = nblk_q[1];
-      plo_q[1] = plo_q[2];
-      nblk_q[1] = nblk_q[2];
-      plo_q[2] = p0;
-      nblk_q[2] = ((p1 + max_tap_off - p0 + 1) * 128 + 1023) >> 10;
+      if (tid == 0) {
+        s_plo[(kt & (WD_NTAB - 1)) * 2] = p0;
+        s_plo[(kt & (WD_NTAB - 1)) * 2 + 1] = ((p1 + max_tap_off - p0 + 1) * 128 + 1023) >> 10;
+      }
     };
-    // DMA of one K-tile: input patch (nblk 1-KB blocks) + dY rows (DBLK blocks), 12 waves
-    auto dma_issue = [&](int buf, int tab, int plo, int nblk) {
+    // DMA of one K-tile: input patch (nblk 1-KB blocks) + dY rows (DBLK blocks) over 12 waves.
+    // Every wave issues exactly NI instructions per tile (surplus ones re-fetch the tile's last
+    // block: same data to the same address) so that vmcnt counts tiles.
+    const int NI = ((xb_bytes >> 10) + DBLK + WD_THREADS / 64 - 1) / (WD_THREADS / 64);
+    auto dma_issue = [&](int buf, int kt) {
+      const int tab = kt & (WD_NTAB - 1);
+      const int plo = __builtin_amdgcn_readfirstlane(s_plo[tab * 2]);
+      const int nblk = __builtin_amdgcn_readfirstlane(s_plo[tab * 2 + 1]);
       unsigned char* const dX = sX + buf * xb_bytes;
       unsigned char* const dD = sD + buf * DB;
-      for (int b = wave; b < nblk + DBLK; b += WD_THREADS / 64) {
+      for (int i = 0; i < NI; ++i) {
+        int b = wave + i * (WD_THREADS / 64);
+        b = b < nblk + DBLK ? b : nblk + DBLK - 1;
         if (b < nblk) {
           const int qq = b * 64 + lane;
           const int r = qq >> 3, slot = qq & 7;
@@ -181,17 +222,22 @@ __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_dma_kernel(
       }
     };
 
-    tabulate(kt0);
-    tabulate(kt0 + 1);
-    __syncthreads();                                   // table kt0 visible to the dY gather
-    dma_issue(0, kt0 & (WD_NTAB - 1), plo_q[1], nblk_q[1]);
+    // prologue: tables of the first NBUF tiles, DMA of the first NBUF-1
+#pragma unroll
+    for (int i = 0; i < NBUF; ++i) tabulate(kt0 + i);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NBUF - 1; ++i)
+      if (kt0 + i < kt1) dma_issue(i, kt0 + i);
 
     for (int kt = kt0; kt < kt1; ++kt) {
-      const int b = (kt - kt0) & 1;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of K-tile kt landed
-      __syncthreads();                                    // everyone's did; tile kt-1 is consumed
-      if (kt + 1 < kt1) dma_issue(b ^ 1, (kt + 1) & (WD_NTAB - 1), plo_q[2], nblk_q[2]);
-      tabulate(kt + 2);
+      const int b = (kt - kt0) % NBUF;
+      // tiles kt+1 .. kt+NBUF-2 may stay in flight; tile kt must have landed
+      const int ahead = min(NBUF - 2, kt1 - 1 - kt);
+      wd_wait_vmcnt(ahead * NI);
+      __syncthreads();                                    // everyone's share landed; tile kt-1 consumed
+      if (kt + NBUF - 1 < kt1) dma_issue((b + NBUF - 1) % NBUF, kt + NBUF - 1);
+      tabulate(kt + NBUF);
       const unsigned short* prow = s_prow + (kt & (WD_NTAB - 1)) * WD_BM;
       const uint32_t xb = sXo + b * xb_bytes + xoff;
       const uint32_t db = sDo + b * DB;
@@ -239,42 +285,77 @@ __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_dma_kernel(
   }
 }
 
-static long wd_xb_bytes(const iic_conv_geom* g) { return (((long)g->NP * 128) + 1023) & ~1023L; }
+static long wd_xb_bytes(int np) { return (((long)np * 128) + 1023) & ~1023L; }
+static long wd_lds(int np, int cot, int bmk, int nbuf) {
+  return nbuf * (wd_xb_bytes(np) + (long)bmk * cot * 2) + WD_TAB_BYTES(bmk) + 64;
+}
 
-static int g_wd_enabled = 1;
+static int g_wd_enabled = 1;     // 0: register-staged kernel, 1: DMA kernel, 3: force 64-pixel K-tiles
 extern "C" void iic_debug_enable_wgrad_dma(int v) { g_wd_enabled = v; }
+
+// K-tile size / ring depth.  Measured at the ClusterNet5g shapes (tools/conv_perf.py): 128-pixel
+// tiles with 2 buffers beat 64-pixel tiles with 3-4 buffers by 10-20 % -- the halo makes a 64-row
+// patch 44 % larger per row (NP64/64 vs NP/128) and the tile barrier comes twice as often, which
+// costs more than the deeper prefetch hides.  The 64-pixel ring serves geometries whose 128-row
+// patch does not fit twice in LDS (wide images).  g_wd_enabled = 3 forces it (tests).
+static int wd_config(const iic_conv_geom* g, int* bmk, int* nbuf) {
+  if (g->ntaps != 9 || g->Cin % 64 != 0 || g->Cout % 64 != 0 || g->NP <= 0 || g->NP > 65535) return 0;
+  const int cot = (g->Cout % 128 == 0) ? 128 : 64;
+  if (g_wd_enabled != 3 && wd_lds(g->NP, cot, 128, 2) <= 160 * 1024) {
+    *bmk = 128;
+    *nbuf = 2;
+    return 1;
+  }
+  if (g->NP64 > 0) {
+    for (int nb = 4; nb >= 3; --nb)
+      if (wd_lds(g->NP64, cot, 64, nb) <= 160 * 1024) {
+        *bmk = 64;
+        *nbuf = nb;
+        return 1;
+      }
+  }
+  return 0;
+}
 
 // used by conv_wgrad.hip's dispatcher
 int iic_wgrad_dma_supported(const iic_conv_geom* g) {
-  if (!g_wd_enabled) return 0;
-  if (g->ntaps != 9 || g->Cin % 64 != 0 || g->Cout % 64 != 0 || g->NP <= 0 || g->NP > 65535) return 0;
-  const int cot = (g->Cout % 128 == 0) ? 128 : 64;
-  const long lds = 2 * wd_xb_bytes(g) + 2L * WD_BM * cot * 2 + WD_TAB_BYTES;
-  return lds <= 160 * 1024;
+  int bmk, nbuf;
+  return g_wd_enabled && wd_config(g, &bmk, &nbuf);
 }
 
 int iic_wgrad_dma_launch(const iic_conv_geom* g, const void* x, const void* dy, float* partials,
                          int nsplit, void* stream) {
+  int bmk = 0, nbuf = 0;
+  if (!wd_config(g, &bmk, &nbuf)) return IIC_ERR_UNSUPPORTED;
   const long M = (long)g->N * g->MY * g->MX;
-  const int kt = (int)((M + WD_BM - 1) / WD_BM);
+  const int kt = (int)((M + bmk - 1) / bmk);
   const int cot = (g->Cout % 128 == 0) ? 128 : 64;
-  const int xb = (int)wd_xb_bytes(g);
-  const long lds = 2L * xb + 2L * WD_BM * cot * 2 + WD_TAB_BYTES;
+  const int np = bmk == 64 ? g->NP64 : g->NP;
+  const int xb = (int)wd_xb_bytes(np);
+  const long lds = wd_lds(np, cot, bmk, nbuf);
   int mto = 0;
   for (int i = 0; i < g->ntaps; ++i) mto = g->tap_off[i] > mto ? g->tap_off[i] : mto;
   dim3 grid((g->Cout / cot) * (g->Cin / 64), nsplit);
   hipStream_t s = (hipStream_t)stream;
-#define WD_LAUNCH(COT_)                                                                          \
+#define WD_LAUNCH(COT_, BMK_, NBUF_)                                                             \
   do {                                                                                          \
     static bool attr = false;                                                                   \
     if (!attr) {                                                                                \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_dma_kernel<COT_>),    \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);        \
+      (void)hipFuncSetAttribute(                                                                \
+          reinterpret_cast<const void*>(&conv_wgrad_dma_kernel<COT_, BMK_, NBUF_>),             \
+          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                              \
       attr = true;                                                                              \
     }                                                                                           \
-    hipLaunchKernelGGL((conv_wgrad_dma_kernel<COT_>), grid, dim3(WD_THREADS), lds, s, *g,       \
-                       (const bf16_t*)x, (const bf16_t*)dy, partials, nsplit, kt, xb, mto);     \
+    hipLaunchKernelGGL((conv_wgrad_dma_kernel<COT_, BMK_, NBUF_>), grid, dim3(WD_THREADS), lds, \
+                       s, *g, (const bf16_t*)x, (const bf16_t*)dy, partials, nsplit, kt, xb,    \
+                       mto);                                                                    \
   } while (0)
-  if (cot == 128) WD_LAUNCH(128); else WD_LAUNCH(64);
+  if (bmk == 64 && nbuf == 4) {
+    if (cot == 128) WD_LAUNCH(128, 64, 4); else WD_LAUNCH(64, 64, 4);
+  } else if (bmk == 64) {
+    if (cot == 128) WD_LAUNCH(128, 64, 3); else WD_LAUNCH(64, 64, 3);
+  } else {
+    if (cot == 128) WD_LAUNCH(128, 128, 2); else WD_LAUNCH(64, 128, 2);
+  }
   return iic_launch_status();
 }

@@ -57,7 +57,7 @@ def _finish(g, taps):
     g.tap_off[i] = off
     g.tap_w[i] = tw
   M = g.N * g.MY * g.MX
-  for bm, field in ((BM, "NP"), (2 * BM, "NP256")):
+  for bm, field in ((BM, "NP"), (2 * BM, "NP256"), (BM // 2, "NP64")):
     m0 = np.arange(0, M, bm, dtype=np.int64)
     m1 = np.minimum(m0 + bm, M) - 1
     span = int((_pin(g, m1) - _pin(g, m0)).max())
@@ -133,7 +133,7 @@ def bwd_data_covers_all(spec):
 def geom_key(g):
   return (g.N, g.MY, g.MX, g.in_Hp, g.in_Wp, g.Cin, g.sy, g.sx, g.oy, g.ox, g.out_Hp, g.out_Wp,
           g.Cout, g.ty, g.tx, g.py, g.px, g.ntaps, tuple(g.tap_off[:g.ntaps]),
-          tuple(g.tap_w[:g.ntaps]), g.NP, g.NP256)
+          tuple(g.tap_w[:g.ntaps]), g.NP, g.NP256, g.NP64)
 
 
 # ---------------------------------------------------------------------------------------

@@ -99,6 +99,7 @@ typedef struct {
   int32_t tap_w[IIC_MAX_TAPS];  /* which [Cout][Cin] slice of the weight tensor the tap uses   */
   int32_t NP;                   /* LDS patch pixels per 128-row tile (max input span + 1)      */
   int32_t NP256;                /* same for 256-row tiles (0 = unknown: 128-row tiles only)    */
+  int32_t NP64;                 /* same for 64-row tiles  (0 = unknown)                         */
 } iic_conv_geom;
 
 long iic_conv_lds_bytes(const iic_conv_geom* g, int BN);
