@@ -29,6 +29,7 @@ class ConvGeom(Structure):
     ("NP", c_int32),
     ("NP256", c_int32),
     ("NP64", c_int32),
+    ("MP", c_int32),
   ]
 
 

@@ -55,7 +55,6 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv_igemm_kernel(
   const int tix = xcd_tile_index(blockIdx.x, num_mtiles * nt);
   const int mtile = tix / nt, ntile = tix - mtile * nt;
   const int n0 = ntile * BN;
-  const int M = g.N * g.MY * g.MX;          // < 2^31 (checked on the host)
   const int m0 = mtile * BM;
   const int in_pixels = g.N * g.in_Hp * g.in_Wp;
 
@@ -66,15 +65,10 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv_igemm_kernel(
 
   // ---- per-row pixel indices --------------------------------------------------------
   if (tid < BM) {
-    int m = m0 + tid;
-    const bool valid = m < M;
-    if (!valid) m = M - 1;
-    const int plane = g.MY * g.MX;
-    const int n = m / plane;
-    const int r = m - n * plane;
-    const int y = r / g.MX, x = r - y * g.MX;
-    s_pin[tid] = (n * g.in_Hp + y * g.sy + g.oy) * g.in_Wp + x * g.sx + g.ox;
-    s_pout[tid] = valid ? (n * g.out_Hp + y * g.ty + g.py) * g.out_Wp + x * g.tx + g.px : -1;
+    int pin, pout;
+    igemm_row_pixels(g, m0 + tid, pin, pout);
+    s_pin[tid] = pin;
+    s_pout[tid] = pout;
   }
   __syncthreads();
   const int p_lo = s_pin[0];
@@ -217,7 +211,7 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv_igemm_kernel(
 
   // ---- epilogue ------------------------------------------------------------------------
   if (ABL && (ablate & 32)) return;
-  const bool tail = (m0 + BM > M);
+  const bool tail = igemm_tile_has_invalid(g, m0, BM);
   if (stats) {
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) {
@@ -313,7 +307,7 @@ static long lds_total(const iic_conv_geom* g, int BN, int BM) {
 // largest M tile whose LDS footprint fits (256 rows halve the weight-tile traffic per FLOP)
 static int pick_bm(const iic_conv_geom* g, int BN) {
   if (g_force_bm == 128 || g_force_bm == 256) return g_force_bm;
-  const long M = (long)g->N * g->MY * g->MX;
+  const long M = igemm_rows_host(g);
   // measured (tools/conv_perf.py --bm): one 8-wave workgroup per CU loses the overlap two
   // independent 4-wave workgroups give; 256-row tiles stay opt-in (iic_debug_force_bm).
   (void)M;
@@ -332,7 +326,7 @@ int iic_conv_igemm(const iic_conv_geom* g, const void* in, const void* w, void* 
     return IIC_ERR_UNSUPPORTED;
   if ((res_grad == nullptr) != (res_act == nullptr)) return IIC_ERR_ARG;
   const int BN = pick_bn(g->Cout);
-  const long M = (long)g->N * g->MY * g->MX;
+  const long M = igemm_rows_host(g);
   if (M <= 0 || g->NP <= 0) return IIC_ERR_ARG;
   if (M >= (1L << 31) || (long)g->N * g->in_Hp * g->in_Wp >= (1L << 31)) return IIC_ERR_UNSUPPORTED;
   const int BMv = pick_bm(g, BN);

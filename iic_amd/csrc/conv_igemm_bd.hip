@@ -52,7 +52,6 @@ __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
   const int tix = xcd_tile_index(blockIdx.x, num_mtiles * nt);
   const int mtile = tix / nt, ntile = tix - mtile * nt;
   const int n0 = ntile * BD_BN;
-  const int M = g.N * g.MY * g.MX;
   const int m0 = mtile * BD_BM;
   const int in_pixels = g.N * g.in_Hp * g.in_Wp;
 
@@ -60,15 +59,10 @@ __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
   const int v_tapw = g.tap_w[lane & (IIC_MAX_TAPS - 1)];
 
   {
-    int m = m0 + tid;
-    const bool valid = m < M;
-    if (!valid) m = M - 1;
-    const int plane = g.MY * g.MX;
-    const int n = m / plane;
-    const int r = m - n * plane;
-    const int y = r / g.MX, x = r - y * g.MX;
-    s_pin[tid] = (n * g.in_Hp + y * g.sy + g.oy) * g.in_Wp + x * g.sx + g.ox;
-    s_pout[tid] = valid ? (n * g.out_Hp + y * g.ty + g.py) * g.out_Wp + x * g.tx + g.px : -1;
+    int pin, pout;
+    igemm_row_pixels(g, m0 + tid, pin, pout);
+    s_pin[tid] = pin;
+    s_pout[tid] = pout;
   }
   __syncthreads();
   const int p_lo = s_pin[0];
@@ -187,7 +181,7 @@ __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
     if (t == 123.f) out[0] = 1;
     return;
   }
-  const bool tail = (m0 + BD_BM > M);
+  const bool tail = igemm_tile_has_invalid(g, m0, BD_BM);
   if (stats) {
 #pragma unroll
     for (int ns = 0; ns < 2; ++ns) {
@@ -287,7 +281,7 @@ int iic_conv_igemm_frag(const iic_conv_geom* g, const void* in, const void* wfra
   if (!iic_conv_igemm_frag_supported(g)) return IIC_ERR_UNSUPPORTED;
   if (g_p64_enabled && iic_p64_supported(g))
     return iic_p64_launch(g, in, wfrag, out, stats, res_grad, res_act, accumulate, stream);
-  const long M = (long)g->N * g->MY * g->MX;
+  const long M = igemm_rows_host(g);
   if (M <= 0) return IIC_ERR_ARG;
   if (M >= (1L << 31) || (long)g->N * g->in_Hp * g->in_Wp >= (1L << 31)) return IIC_ERR_UNSUPPORTED;
   const int mt = (int)((M + BD_BM - 1) / BD_BM);

@@ -268,6 +268,7 @@ static long p64_pb_bytes(const iic_conv_geom* g) {
 // used by conv_igemm_bd.hip's dispatcher
 int iic_p64_supported(const iic_conv_geom* g) {
   if (g->Cin != 64 || g->Cout != 64 || g->ntaps != P64_NT || g->NP256 <= 0 || g->NP256 > 65535) return 0;
+  if (!igemm_dense_host(g)) return 0;       // the row walkers assume the dense row numbering
   return 2 * p64_pb_bytes(g) + P64_SC_BYTES + P64_TAB_BYTES <= 160 * 1024;
 }
 

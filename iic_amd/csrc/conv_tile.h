@@ -3,6 +3,36 @@
 // accumulate / ReLU-masked residual-gradient epilogue.
 #pragma once
 #include "common.h"
+#include "../../include/iic_hip.h"
+
+// GEMM row -> pixel indices.  Rows are numbered per image with g.MP rows each (0 = the dense
+// plane MY*MX); rows >= plane of an image, and rows of images >= N, are invalid: they read the
+// image's last pixel (stays inside the tile's patch span) and get pout = -1.
+__device__ __forceinline__ void igemm_row_pixels(const iic_conv_geom& g, int m, int& pin, int& pout) {
+  const int plane = g.MY * g.MX;
+  const int mp = g.MP > 0 ? g.MP : plane;
+  int n = m / mp;
+  int r = m - n * mp;
+  const bool valid = n < g.N && r < plane;
+  if (n >= g.N) { n = g.N - 1; r = plane - 1; }
+  r = r < plane ? r : plane - 1;
+  const int y = r / g.MX, x = r - y * g.MX;
+  pin = (n * g.in_Hp + y * g.sy + g.oy) * g.in_Wp + x * g.sx + g.ox;
+  pout = valid ? (n * g.out_Hp + y * g.ty + g.py) * g.out_Wp + x * g.tx + g.px : -1;
+}
+__device__ __forceinline__ int igemm_rows(const iic_conv_geom& g) {
+  return g.N * (g.MP > 0 ? g.MP : g.MY * g.MX);
+}
+// does the tile [m0, m0 + bm) contain invalid rows?
+__device__ __forceinline__ bool igemm_tile_has_invalid(const iic_conv_geom& g, int m0, int bm) {
+  const int plane = g.MY * g.MX;
+  if (m0 + bm > igemm_rows(g)) return true;
+  return g.MP > 0 && g.MP != plane && (m0 % g.MP) + bm > plane;
+}
+static inline long igemm_rows_host(const iic_conv_geom* g) {
+  return (long)g->N * (g->MP > 0 ? g->MP : g->MY * g->MX);
+}
+static inline bool igemm_dense_host(const iic_conv_geom* g) { return g->MP <= 0 || g->MP == g->MY * g->MX; }
 
 #define ROWB 144   // LDS row pitch in bytes: 128 B of data + 16 B pad.  144*r mod 256 visits all
                    // sixteen 16-B slots over 16 consecutive rows => the 16-lane groups of

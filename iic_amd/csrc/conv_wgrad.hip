@@ -21,10 +21,10 @@
 // across workgroups, partial sums go to [split][tap][co][ci] fp32 and are reduced (and
 // transposed to the OIHW parameter layout) by conv_wgrad_reduce_kernel.
 #include "common.h"
+#include "conv_tile.h"
 #include "../../include/iic_hip.h"
 
 #define BM 128      // K-tile: 128 output pixels
-#define ROWB 144    // LDS row pitch of the input patch: 128 B of data + 16 B pad
 #define TPG 3       // taps per wave (tap group)
 #define NTG 3       // tap groups per pass => 9 taps per pass
 #define PFX 4       // patch 16-B pieces per thread prefetched in registers (NP <= 384 at 768 threads)
@@ -87,7 +87,6 @@ __global__ __launch_bounds__(GATHER ? 256 : 768) void conv_wgrad_kernel(
   const int per = (num_ktiles + nsplit - 1) / nsplit;
   const int kt0 = split * per;
   const int kt1 = min(num_ktiles, kt0 + per);
-  const int M = g.N * g.MY * g.MX;
   const int in_pixels = g.N * g.in_Hp * g.in_Wp;
   const int npix = GATHER ? BM : g.NP;
   const int n8 = npix * 8;
@@ -104,16 +103,10 @@ __global__ __launch_bounds__(GATHER ? 256 : 768) void conv_wgrad_kernel(
 
   auto rowinfo = [&](int kt, int b) {
     if (tid < BM) {
-      int m = kt * BM + tid;
-      const bool valid = m < M;
-      if (!valid) m = M - 1;
-      const int plane = g.MY * g.MX;
-      const int n = m / plane;
-      const int r = m - n * plane;
-      const int y = r / g.MX, xx = r - y * g.MX;
-      s_pin[b * BM + tid] = (n * g.in_Hp + y * g.sy + g.oy) * g.in_Wp + xx * g.sx + g.ox;
-      s_pout[b * BM + tid] =
-          valid ? (n * g.out_Hp + y * g.ty + g.py) * g.out_Wp + xx * g.tx + g.px : -1;
+      int pin, pout;
+      igemm_row_pixels(g, kt * BM + tid, pin, pout);
+      s_pin[b * BM + tid] = pin;
+      s_pout[b * BM + tid] = pout;
     }
   };
   u32x4 PX[PFX], PD[PDN];
@@ -334,7 +327,7 @@ extern "C" {
 static int wgrad_cot(const iic_conv_geom* g) { return (g->Cout % 128 == 0) ? 128 : 64; }
 
 int iic_conv_wgrad_nsplit(const iic_conv_geom* g) {
-  const long M = (long)g->N * g->MY * g->MX;
+  const long M = igemm_rows_host(g);
   const int kt = (int)((M + BM - 1) / BM);
   const int tiles = (g->Cout / wgrad_cot(g)) * (g->Cin / 64);
   int ns = 256 / (tiles > 0 ? tiles : 1);   // one workgroup (12 waves) per CU
@@ -348,7 +341,7 @@ int iic_conv_wgrad(const iic_conv_geom* g, const void* x, const void* dy, float*
   if (!g || !x || !dy || !partials || nsplit < 1) return IIC_ERR_ARG;
   if (g->Cin % 64 != 0 || g->Cout % 64 != 0 || g->ntaps < 1 || g->ntaps > IIC_MAX_TAPS)
     return IIC_ERR_UNSUPPORTED;
-  const long M = (long)g->N * g->MY * g->MX;
+  const long M = igemm_rows_host(g);
   if (M >= (1L << 31) || (long)g->N * g->in_Hp * g->in_Wp >= (1L << 31)) return IIC_ERR_UNSUPPORTED;
   if (use_tr && iic_wgrad_dma_supported(g)) return iic_wgrad_dma_launch(g, x, dy, partials, nsplit, stream);
   const int kt = (int)((M + BM - 1) / BM);

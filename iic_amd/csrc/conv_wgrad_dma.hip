@@ -300,6 +300,7 @@ extern "C" void iic_debug_enable_wgrad_dma(int v) { g_wd_enabled = v; }
 // patch does not fit twice in LDS (wide images).  g_wd_enabled = 3 forces it (tests).
 static int wd_config(const iic_conv_geom* g, int* bmk, int* nbuf) {
   if (g->ntaps != 9 || g->Cin % 64 != 0 || g->Cout % 64 != 0 || g->NP <= 0 || g->NP > 65535) return 0;
+  if (g->MP > 0 && g->MP != g->MY * g->MX) return 0;   // the row walkers assume the dense row numbering
   const int cot = (g->Cout % 128 == 0) ? 128 : 64;
   if (g_wd_enabled != 3 && wd_lds(g->NP, cot, 128, 2) <= 160 * 1024) {
     *bmk = 128;

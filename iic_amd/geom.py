@@ -31,19 +31,36 @@ class ConvSpec(object):
     return self.K * self.K
 
 
+def rows_per_image(g):
+  """GEMM rows per image: the plane MY*MX, or the padded plane g.MP (see _finish)."""
+  return int(g.MP) if g.MP > 0 else g.MY * g.MX
+
+
+def gemm_rows(g):
+  return g.N * rows_per_image(g)
+
+
+def _nr(g, m):
+  """GEMM row -> (image, in-plane index clamped to the last pixel, valid)."""
+  plane, mp = g.MY * g.MX, rows_per_image(g)
+  n = m // mp
+  r = m - n * mp
+  valid = (n < g.N) & (r < plane)
+  r = np.minimum(r, plane - 1)
+  r = np.where(n >= g.N, plane - 1, r)
+  n = np.minimum(n, g.N - 1)
+  return n, r, valid
+
+
 def _pin(g, m):
-  plane = g.MY * g.MX
-  n = m // plane
-  r = m - n * plane
+  n, r, _ = _nr(g, np.asarray(m))
   y = r // g.MX
   x = r - y * g.MX
   return (n * g.in_Hp + y * g.sy + g.oy) * g.in_Wp + x * g.sx + g.ox
 
 
 def _pout(g, m):
-  plane = g.MY * g.MX
-  n = m // plane
-  r = m - n * plane
+  n, r, _ = _nr(g, np.asarray(m))
   y = r // g.MX
   x = r - y * g.MX
   return (n * g.out_Hp + y * g.ty + g.py) * g.out_Wp + x * g.tx + g.px
@@ -56,12 +73,29 @@ def _finish(g, taps):
     assert off >= 0
     g.tap_off[i] = off
     g.tap_w[i] = tw
-  M = g.N * g.MY * g.MX
-  for bm, field in ((BM, "NP"), (2 * BM, "NP256"), (BM // 2, "NP64")):
-    m0 = np.arange(0, M, bm, dtype=np.int64)
-    m1 = np.minimum(m0 + bm, M) - 1
-    span = int((_pin(g, m1) - _pin(g, m0)).max())
-    setattr(g, field, span + max(off for off, _ in taps) + 1)
+  def spans():
+    M = gemm_rows(g)
+    for bm, field in ((BM, "NP"), (2 * BM, "NP256"), (BM // 2, "NP64")):
+      m0 = np.arange(0, M, bm, dtype=np.int64)
+      m1 = np.minimum(m0 + bm, M) - 1
+      span = int((_pin(g, m1) - _pin(g, m0)).max())
+      setattr(g, field, span + max(off for off, _ in taps) + 1)
+  g.MP = 0
+  spans()
+  # Large images: a dense row numbering lets a tile straddle two images, and its input span then
+  # contains the 2*pad border rows between them (200x200 with pad 3: +1236 pixels = 178 KB of
+  # LDS).  Padding the per-image row count to a multiple of 256 keeps every tile inside one
+  # image (rows >= plane are invalid: never stored, zero weight-gradient contribution) at
+  # a few % extra rows.
+  plane = g.MY * g.MX
+  mp = (plane + 255) // 256 * 256
+  if g.NP * 144 > 96 * 1024 and mp * 8 <= plane * 9:      # big span, <= 12.5 % padding rows
+    dense = (g.NP, g.NP256, g.NP64)
+    g.MP = mp
+    spans()
+    if g.NP >= dense[0]:                                    # no gain (span is all halo): stay dense
+      g.MP = 0
+      g.NP, g.NP256, g.NP64 = dense
   return g
 
 
@@ -133,7 +167,7 @@ def bwd_data_covers_all(spec):
 def geom_key(g):
   return (g.N, g.MY, g.MX, g.in_Hp, g.in_Wp, g.Cin, g.sy, g.sx, g.oy, g.ox, g.out_Hp, g.out_Wp,
           g.Cout, g.ty, g.tx, g.py, g.px, g.ntaps, tuple(g.tap_off[:g.ntaps]),
-          tuple(g.tap_w[:g.ntaps]), g.NP, g.NP256, g.NP64)
+          tuple(g.tap_w[:g.ntaps]), g.NP, g.NP256, g.NP64, g.MP)
 
 
 # ---------------------------------------------------------------------------------------
@@ -142,8 +176,9 @@ def geom_key(g):
 
 def emulate_igemm(g, x_pt, w_tco_ci, out_pt=None, accumulate=False):
   """out[pout(m)] (+)= sum_t x[pin(m)+off_t] @ w[tap_w[t]].T ; arrays are float64 numpy."""
-  M = g.N * g.MY * g.MX
-  m = np.arange(M, dtype=np.int64)
+  m = np.arange(gemm_rows(g), dtype=np.int64)
+  m = m[_nr(g, m)[2]]                      # valid rows only
+  M = len(m)
   pin, pout = _pin(g, m), _pout(g, m)
   xf = x_pt.reshape(-1, g.Cin)
   if out_pt is None:
@@ -161,8 +196,8 @@ def emulate_igemm(g, x_pt, w_tco_ci, out_pt=None, accumulate=False):
 
 def emulate_wgrad(g, x_pt, dy_pt, wtaps):
   """dW[t][co][ci] = sum_m dy[pout(m)][co] * x[pin(m)+off_t][ci] (forward geometry)."""
-  M = g.N * g.MY * g.MX
-  m = np.arange(M, dtype=np.int64)
+  m = np.arange(gemm_rows(g), dtype=np.int64)
+  m = m[_nr(g, m)[2]]                      # valid rows only
   pin, pout = _pin(g, m), _pout(g, m)
   xf = x_pt.reshape(-1, g.Cin)
   dyf = dy_pt.reshape(-1, g.Cout)

@@ -36,19 +36,24 @@ class Adam(torch.optim.Optimizer):
         assert p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
         if not p.grad.is_contiguous():
           p.grad = p.grad.contiguous()
-      steps = set(self.state[p]["step"] for p in ps)
-      assert len(steps) == 1, "parameters of one group must share the step count"
-      step = steps.pop() + 1
-      n = len(ps)
-      VP = ctypes.c_void_p * n
-      LP = ctypes.c_long * n
-      check(lib().iic_adam_step(
-        n, VP(*[p.data_ptr() for p in ps]), VP(*[p.grad.data_ptr() for p in ps]),
-        VP(*[self.state[p]["exp_avg"].data_ptr() for p in ps]),
-        VP(*[self.state[p]["exp_avg_sq"].data_ptr() for p in ps]),
-        LP(*[p.numel() for p in ps]), float(group["lr"]), float(group["betas"][0]),
-        float(group["betas"][1]), float(group["eps"]), step, stream_ptr()), "iic_adam_step")
+      # torch.optim.Adam keeps a step count PER PARAMETER: a two-head net only produces
+      # gradients for the head that was used (net5g_two_head.py:62-81), so head-A and head-B
+      # parameters advance at different rates.  One fused launch per distinct step count.
+      by_step = {}
       for p in ps:
-        self.state[p]["step"] = step
+        by_step.setdefault(self.state[p]["step"], []).append(p)
+      for step0, grp in by_step.items():
+        step = step0 + 1
+        n = len(grp)
+        VP = ctypes.c_void_p * n
+        LP = ctypes.c_long * n
+        check(lib().iic_adam_step(
+          n, VP(*[p.data_ptr() for p in grp]), VP(*[p.grad.data_ptr() for p in grp]),
+          VP(*[self.state[p]["exp_avg"].data_ptr() for p in grp]),
+          VP(*[self.state[p]["exp_avg_sq"].data_ptr() for p in grp]),
+          LP(*[p.numel() for p in grp]), float(group["lr"]), float(group["betas"][0]),
+          float(group["betas"][1]), float(group["eps"]), step, stream_ptr()), "iic_adam_step")
+        for p in grp:
+          self.state[p]["step"] = step
     bump_weights_epoch()
     return loss

@@ -100,6 +100,10 @@ typedef struct {
   int32_t NP;                   /* LDS patch pixels per 128-row tile (max input span + 1)      */
   int32_t NP256;                /* same for 256-row tiles (0 = unknown: 128-row tiles only)    */
   int32_t NP64;                 /* same for 64-row tiles  (0 = unknown)                         */
+  int32_t MP;                   /* GEMM rows per image: 0 = MY*MX (dense), else a multiple of   */
+                                /* 256 >= MY*MX; rows r >= MY*MX of an image are invalid (never */
+                                /* stored, no statistics, zero weight gradient): tiles of large */
+                                /* images then never straddle two images                        */
 } iic_conv_geom;
 
 long iic_conv_lds_bytes(const iic_conv_geom* g, int BN);

@@ -31,7 +31,7 @@ def test_header_symbols_exported_and_bound():
 
 def test_geom_struct_matches_header_size():
   from iic_amd import _lib
-  assert ctypes.sizeof(_lib.ConvGeom) == 4 * (3 + 3 + 4 + 3 + 4 + 1 + 32 + 32 + 3)
+  assert ctypes.sizeof(_lib.ConvGeom) == 4 * (3 + 3 + 4 + 3 + 4 + 1 + 32 + 32 + 4)
 
 
 def test_product_path_has_no_cpu_fallback():

@@ -14,6 +14,8 @@ CASES = [  # cin, cout, K, stride, pad, dil, N, H, W, pad_in, pad_out
   (8, 16, 1, 2, 0, 1, 3, 13, 13, 1, 1),
   (8, 8, 5, 1, 2, 1, 2, 12, 12, 2, 2),
   (8, 8, 3, 1, 1, 2, 2, 12, 12, 2, 2),   # dilated, pad 1 => output shrinks by 2
+  (4, 4, 3, 1, 1, 1, 2, 66, 66, 3, 3),   # large image, wide border: padded per-image row count (MP)
+  (4, 4, 3, 1, 1, 2, 2, 70, 70, 3, 3),   # same, dilated (segmentation trunk)
 ]
 
 
@@ -37,7 +39,9 @@ def test_forward_geometry(case):
   if po > 0:  # border untouched (zero)
     assert not out[:, :po].any() and not out[:, :, :po].any()
   # patch bound: every row's taps stay inside [p_lo, p_lo + NP)
-  M = g.N * g.MY * g.MX
+  M = geom.gemm_rows(g)
+  if H * W >= 4096:
+    assert g.MP > 0 and g.MP % 256 == 0 and g.MP >= g.MY * g.MX   # padded planes: tiles never straddle images
   m = np.arange(M)
   pin = geom._pin(g, m)
   p_lo = pin[(m // 128) * 128]

@@ -229,6 +229,57 @@ def _conv_forward_and_stats(case, frag=False):
   assert torch.equal(wb.float().cpu(), bf16_round(w).permute(2, 3, 1, 0).reshape(K * K, cin, cout))
 
 
+@pytest.mark.parametrize("cin,cout,d,frag", [(64, 128, 1, False), (128, 128, 1, True), (64, 64, 2, False)])
+def test_conv_large_images_padded_row_numbering(cin, cout, d, frag):
+  """Large images with a wide PT border (segmentation trunk: 100x100, border 3): the geometry pads
+  the per-image GEMM row count (iic_conv_geom.MP) so that no tile straddles two images; rows in
+  the padding are invalid (not stored, no statistics, no weight gradient).  Forward + statistics,
+  backward-data and backward-weight against torch on the same bf16 operands."""
+  from iic_amd import geom, ops
+  N, H, P, K = 2, 100, 3, 3
+  x, w = _conv_inputs(cin, cout, K, N, H, 7)
+  wr = bf16_round(w)
+  spec = geom.ConvSpec(cin, cout, K, 1, 1, d)
+  Ho = spec.out_size(H)
+  xt = x.clone().requires_grad_(True)
+  wt = wr.clone().requires_grad_(True)
+  ref = F.conv2d(xt, wt, stride=1, padding=1, dilation=d)
+  dy = bf16_round(torch.from_numpy(np.random.default_rng(9).standard_normal(tuple(ref.shape)).astype(np.float32)))
+  ref.backward(dy)
+  g = geom.fwd_geom(spec, N, H, H, P, P)
+  assert g.MP > 0 and g.MP % 256 == 0, "this case must exercise the padded row numbering"
+  pw = ops.PreppedWeights(w.to(dev()))
+  if frag:
+    assert ops.frag_supported(g)
+  wop = pw[0] if frag else pw.rows(False)
+  xp = ops.pt_from_nchw(x.to(dev()), P)
+  out = torch.zeros((N, Ho + 2 * P, Ho + 2 * P, cout), dtype=torch.bfloat16, device=dev())
+  stats = ops.new_stats(cout, dev())
+  ops.conv_igemm(g, xp, wop, out, stats=stats)
+  torch.cuda.synchronize()
+  got = ops.pt_to_nchw(out, P).cpu()
+  scale = ref.abs().max().item()
+  assert (got - ref.detach()).abs().max().item() <= 1e-2 * scale
+  o = out.float()
+  assert float(o[:, :P].abs().max()) == 0 and float(o[:, :, -P:].abs().max()) == 0
+  st = stats.sum(0).cpu()
+  cnt = N * Ho * Ho
+  assert torch.allclose(st[0] / cnt, ref.detach().mean((0, 2, 3)), atol=2e-3 * scale)
+  assert torch.allclose(st[1] / cnt, (ref.detach() ** 2).mean((0, 2, 3)), rtol=2e-3, atol=1e-4 * scale * scale)
+  # backward-data (dy lives in a PT tensor with the same border) and backward-weight
+  geoms = geom.bwd_data_geoms(spec, N, H, H, P, P)
+  dyp = ops.pt_from_nchw(dy.to(dev()), P)
+  dx = torch.zeros((N, H + 2 * P, H + 2 * P, cin), dtype=torch.bfloat16, device=dev())
+  for gb in geoms:
+    ops.conv_igemm(gb, dyp, pw[1] if (frag and ops.frag_supported(gb)) else pw.rows(True), dx)
+  dW = ops.conv_wgrad(g, xp, dyp, K * K, use_tr=True)
+  torch.cuda.synchronize()
+  gx = ops.pt_to_nchw(dx, P).cpu()
+  assert (gx - xt.grad).abs().max().item() <= 1e-2 * xt.grad.abs().max().item()
+  gw = dW.view(cout, cin, K, K).cpu()
+  assert (gw - wt.grad).abs().max().item() <= 3e-3 * wt.grad.abs().max().item()
+
+
 @pytest.mark.parametrize("bm", [0, 256, "frag"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_backward_data(case, bm):
@@ -531,3 +582,27 @@ def test_adam_matches_torch():
   torch.cuda.synchronize()
   for a, b in zip(mine, theirs):
     assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+
+
+def test_adam_per_parameter_step_counts():
+  """Two-head training: parameters that get no gradient in a step are skipped and keep their own
+  step count (bias correction), exactly like torch.optim.Adam."""
+  from iic_amd.optim import Adam
+  torch.manual_seed(3)
+  shapes = [(7, 5), (33,), (4, 3, 3, 3)]
+  ps = [torch.nn.Parameter(torch.randn(s, device=dev())) for s in shapes]
+  rs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+  ours, ref = Adam(ps, lr=1e-2), torch.optim.Adam(rs, lr=1e-2)
+  for it in range(6):
+    active = [0, 1] if it % 2 == 0 else [0, 2]       # parameter 0 always, 1 and 2 alternate
+    for o in (ours, ref):
+      o.zero_grad(set_to_none=True)
+    for i in active:
+      g = torch.randn(shapes[i], device=dev())
+      ps[i].grad = g.clone()
+      rs[i].grad = g.clone()
+    ours.step()
+    ref.step()
+  for p, r in zip(ps, rs):
+    assert torch.allclose(p, r, rtol=1e-5, atol=1e-6), (p - r).abs().max()
+  assert [ours.state[p]["step"] for p in ps] == [6, 3, 3]
