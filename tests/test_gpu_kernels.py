@@ -606,3 +606,52 @@ def test_adam_per_parameter_step_counts():
   for p, r in zip(ps, rs):
     assert torch.allclose(p, r, rtol=1e-5, atol=1e-6), (p - r).abs().max()
   assert [ours.state[p]["step"] for p in ps] == [6, 3, 3]
+
+
+@pytest.mark.parametrize("cin,cout,H", [(64, 64, 49), (128, 128, 25), (256, 256, 13), (512, 512, 7)])
+def test_full_size_kernel_generations_agree(cin, cout, H):
+  """North-star shapes at the FULL batch (660 images): the second-generation kernels
+  (weights-direct / persistent DMA conv, DMA weight gradient) against the first-generation ones,
+  which are checked against torch at small sizes above.  Same bf16 operands, fp32 accumulation in
+  a different order => outputs agree to a bf16 ulp, statistics and weight gradients to fp32
+  reduction noise."""
+  import ctypes
+  from iic_amd import _lib, geom, ops
+  L = ctypes.CDLL(_lib.LIB_PATH)
+  N = 660
+  g0 = torch.Generator(device="cpu").manual_seed(cin + H)
+  x = torch.randn(N, H + 2, H + 2, cin, generator=g0).to(torch.bfloat16)
+  x[:, 0] = 0; x[:, -1] = 0; x[:, :, 0] = 0; x[:, :, -1] = 0
+  dy = torch.randn(N, H + 2, H + 2, cout, generator=g0).to(torch.bfloat16)
+  dy[:, 0] = 0; dy[:, -1] = 0; dy[:, :, 0] = 0; dy[:, :, -1] = 0
+  w = torch.randn(cout, cin, 3, 3, generator=g0) / math.sqrt(cin * 9)
+  x, dy, w = x.to(dev()), dy.to(dev()), w.to(dev())
+  spec = geom.ConvSpec(cin, cout, 3, 1, 1)
+  gf = geom.fwd_geom(spec, N, H, H, 1, 1)
+  gb = geom.bwd_data_geoms(spec, N, H, H, 1, 1)
+  pw = ops.PreppedWeights(w)
+  assert ops.frag_supported(gf) and all(ops.frag_supported(g) for g in gb)
+
+  def run(new):
+    y = torch.zeros(N, H + 2, H + 2, cout, dtype=torch.bfloat16, device=dev())
+    dx = torch.zeros(N, H + 2, H + 2, cin, dtype=torch.bfloat16, device=dev())
+    st = ops.new_stats(cout, dev())
+    ops.conv_igemm(gf, x, pw[0] if new else pw.rows(False), y, stats=st)
+    for g in gb:
+      ops.conv_igemm(g, dy, pw[1] if new else pw.rows(True), dx)
+    L.iic_debug_enable_wgrad_dma(1 if new else 0)
+    try:
+      dW = ops.conv_wgrad(gf, x, dy, 9, use_tr=True).clone()
+    finally:
+      L.iic_debug_enable_wgrad_dma(1)
+    torch.cuda.synchronize()
+    return y.float(), dx.float(), st.sum(0), dW
+
+  y1, dx1, st1, dW1 = run(True)
+  y0, dx0, st0, dW0 = run(False)
+  for a, b in ((y1, y0), (dx1, dx0)):
+    d = (a - b).abs()
+    assert float(d.max()) <= 2 ** -7 * float(b.abs().max()), float(d.max())    # <= 1 bf16 ulp of the largest
+    assert float((d > 0).float().mean()) < 0.02                                 # and only rarely
+  assert torch.allclose(st1, st0, rtol=1e-4, atol=1e-2)
+  assert float((dW1 - dW0).abs().max()) <= 1e-4 * float(dW0.abs().max())
