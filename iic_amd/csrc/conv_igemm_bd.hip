@@ -30,7 +30,8 @@
 
 // ABL: timing-ablation build (tools/conv_perf.py --ablate; results are WRONG by design):
 //   1 = no patch reload at chunk boundaries, 2 = B fragments always from the same address
-//   (L2-hot), 4 = no epilogue, 8 = no chunk-boundary barriers either, 16 = no A-fragment LDS reads.
+//   (L2-hot), 4 = no epilogue, 8 = no chunk-boundary barriers either, 16 = no A-fragment LDS reads,
+//   32 = no global stores of the tile, 64 = no BatchNorm statistics.
 template <bool GATHER, int ABL>
 __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
     const iic_conv_geom g, const bf16_t* __restrict__ in, const unsigned char* __restrict__ wfrag,
@@ -182,19 +183,29 @@ __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
     return;
   }
   const bool tail = igemm_tile_has_invalid(g, m0, BD_BM);
-  if (stats) {
-#pragma unroll
-    for (int ns = 0; ns < 2; ++ns) {
-      float s = 0.f, ss = 0.f;
+  if (stats && !(ABL & 64)) {
+    if (tail) {       // rows past the end / in the row padding do not count
 #pragma unroll
       for (int ms = 0; ms < 4; ++ms)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v = acc[ms][ns][r];
-          if (tail && s_pout[wm * 128 + ms * 32 + mfma32_row(r, lane)] < 0) v = 0.f;
-          s += v;
-          ss += v * v;
+        for (int r = 0; r < 16; ++r)
+          if (s_pout[wm * 128 + ms * 32 + mfma32_row(r, lane)] < 0) {
+            acc[ms][0][r] = 0.f;
+            acc[ms][1][r] = 0.f;
+          }
+    }
+#pragma unroll
+    for (int ns = 0; ns < 2; ++ns) {
+      f32x2 s2 = {0.f, 0.f}, ss2 = {0.f, 0.f};      // packed fp32 adds / fmas: half the VALU count
+#pragma unroll
+      for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2 v = {acc[ms][ns][r], acc[ms][ns][r + 1]};
+          s2 += v;
+          ss2 += v * v;
         }
+      float s = s2[0] + s2[1], ss = ss2[0] + ss2[1];
       s += __shfl_xor(s, 32, 64);
       ss += __shfl_xor(ss, 32, 64);
       if (lane < 32) {
@@ -205,7 +216,7 @@ __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
     }
   }
   __syncthreads();   // all waves finished reading sA; s_red complete
-  if (stats && tid < BD_BN) {
+  if (stats && tid < BD_BN && !(ABL & 64)) {
     float* st = stats + (long)(blockIdx.x % IIC_STAT_STRIPES) * 2 * g.Cout;
     atomicAdd(st + n0 + tid, s_red[0 * BD_BN + tid] + s_red[2 * BD_BN + tid]);
     atomicAdd(st + g.Cout + n0 + tid, s_red[1 * BD_BN + tid] + s_red[3 * BD_BN + tid]);
@@ -221,8 +232,9 @@ __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
         sC[row * CLD + col] = f32_to_bf16(acc[ms][ns][r]);
       }
   __syncthreads();
-  igemm_store_tile<BD_BN, BD_BM, BD_THREADS>(sC, s_pout, out, res_grad, res_act, accumulate, g.Cout,
-                                             n0, tid);
+  if (!(ABL & 32))
+    igemm_store_tile<BD_BN, BD_BM, BD_THREADS>(sC, s_pout, out, res_grad, res_act, accumulate, g.Cout,
+                                               n0, tid);
 }
 
 // fp32 OIHW -> bf16 MFMA-B-fragment order.  mode 0 (forward operand): GEMM N = Cout, K = Cin;
@@ -314,6 +326,9 @@ int iic_conv_igemm_frag(const iic_conv_geom* g, const void* in, const void* wfra
     case 15: BD_LAUNCH(false, 15); break;
     case 16: BD_LAUNCH(false, 16); break;
     case 31: BD_LAUNCH(false, 31); break;
+    case 32: BD_LAUNCH(false, 32); break;
+    case 64: BD_LAUNCH(false, 64); break;
+    case 96: BD_LAUNCH(false, 96); break;
     default: BD_LAUNCH(false, 0); break;
   }
   return iic_launch_status();
