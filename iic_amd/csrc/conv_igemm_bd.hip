@@ -32,7 +32,12 @@
 //   1 = no patch reload at chunk boundaries, 2 = B fragments always from the same address
 //   (L2-hot), 4 = no epilogue, 8 = no chunk-boundary barriers either, 16 = no A-fragment LDS reads,
 //   32 = no global stores of the tile, 64 = no BatchNorm statistics.
-template <bool GATHER, int ABL>
+// DMA: the patch is fetched by LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, every piece of
+// a chunk in flight at once instead of 4-piece batches that each wait a full memory latency) into
+// unpadded 128-byte rows whose 16-byte slot is XOR-ed with (row >> 1) & 7 -- the swizzle is
+// applied on the DMA's SOURCE address; A-fragment addresses then cost ~2 VALU per read instead of
+// an immediate offset.  !DMA: register-staged loads into 144-byte-pitch rows (first version).
+template <bool GATHER, int ABL, bool DMA>
 __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
     const iic_conv_geom g, const bf16_t* __restrict__ in, const unsigned char* __restrict__ wfrag,
     bf16_t* __restrict__ out, float* __restrict__ stats, const bf16_t* __restrict__ res_grad,
@@ -45,7 +50,8 @@ __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
   float* s_red = reinterpret_cast<float*>(s_pout + BD_BM);         // [2 wm][2][128]
   bf16_t* sC = reinterpret_cast<bf16_t*>(smem_raw);                // epilogue reuse of sA
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, g5 = lane >> 5;
 
@@ -68,12 +74,32 @@ __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
   __syncthreads();
   const int p_lo = s_pin[0];
   const int npix = GATHER ? BD_BM : g.NP256;
-  int arow[4];
+  int arow[4];     // !DMA: byte offset of the lane's row (tap 0) + k-chunk; DMA: patch row index
 #pragma unroll
   for (int ms = 0; ms < 4; ++ms) {
     const int row = wm * 128 + ms * 32 + l31;
-    arow[ms] = (GATHER ? row : (s_pin[row] - p_lo)) * ROWB + g5 * 16;
+    const int pr = GATHER ? row : (s_pin[row] - p_lo);
+    arow[ms] = DMA ? pr : pr * ROWB + g5 * 16;
   }
+  // DMA patch loader: 1-KB blocks over the 4 waves; piece q -> LDS byte q*16 (row q>>3, physical
+  // slot q&7), source = logical slot (q&7) ^ ((row>>1)&7) of the row's pixel
+  const int nblk = (npix * 128 + 1023) >> 10;
+  auto dma_patch = [&](int c0) {
+    for (int blk = wave; blk < nblk; blk += BD_THREADS / 64) {
+      const int q = blk * 64 + lane;
+      const int r = q >> 3;
+      const int ls = (q & 7) ^ ((r >> 1) & 7);
+      long p = GATHER ? (long)s_pin[r < BD_BM ? r : BD_BM - 1] : (long)p_lo + r;
+      p = p < in_pixels ? p : in_pixels - 1;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(in + (p * g.Cin + c0 + ls * 8)),
+          (__attribute__((address_space(3))) void*)(sA + blk * 1024), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  // DMA layout: byte address of A fragment (row R, k-step ks, lane half g5) = R*128 + ((2ks+g5) ^ key)*16
+  auto a_base = [&](int R) { return R * 128 + (((g5 ^ (R >> 1)) & 1) << 4); };
+  auto a_kk = [&](int R) { return ((R >> 2) & 3) << 5; };
 
   f32x16 acc[4][2];
 #pragma unroll
@@ -104,8 +130,12 @@ __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
       for (int ns = 0; ns < 2; ++ns)
         Bc[ks][ns] = *reinterpret_cast<const u32x4*>(p + ns * 4096 + ks * 1024);
   }
-  // prologue: the accumulators are not live yet => 16 pieces (64 VGPRs) in flight per thread
-  igemm_load_patch<GATHER, BD_THREADS, 16>(sA, in, g.Cin, 0, p_lo, npix, in_pixels, s_pin, tid);
+  if (DMA) {
+    dma_patch(0);
+  } else {
+    // the accumulators are not live yet => 16 pieces (64 VGPRs) in flight per thread
+    igemm_load_patch<GATHER, BD_THREADS, 16>(sA, in, g.Cin, 0, p_lo, npix, in_pixels, s_pin, tid);
+  }
   __syncthreads();
 
   // ---- main loop: flat (chunk, tap) iterations; barriers only when the chunk changes ------
@@ -118,11 +148,20 @@ __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
   // the iteration and recycles the B registers as A temporaries (=> vmcnt(0) every iteration).
   int tap = 0, chunk = 0;
   bf16x8 a[2][4];
-  int pcur[4];
+  int pcur[4], kcur[4];       // kcur: DMA only (k-step XOR term of the row's swizzle)
 #pragma unroll
   for (int ms = 0; ms < 4; ++ms) {
-    pcur[ms] = arow[ms] + (GATHER ? 0 : __builtin_amdgcn_readlane(v_tapoff, 0) * ROWB);
-    a[0][ms] = *reinterpret_cast<const bf16x8*>(sA + pcur[ms]);
+    const int t0 = GATHER ? 0 : __builtin_amdgcn_readlane(v_tapoff, 0);
+    if (DMA) {
+      const int R = arow[ms] + t0;
+      pcur[ms] = a_base(R);
+      kcur[ms] = a_kk(R);
+      a[0][ms] = *reinterpret_cast<const bf16x8*>(sA + pcur[ms] + kcur[ms]);
+    } else {
+      pcur[ms] = arow[ms] + t0 * ROWB;
+      kcur[ms] = 0;
+      a[0][ms] = *reinterpret_cast<const bf16x8*>(sA + pcur[ms]);
+    }
   }
   for (int it = 0; it < NIT; ++it) {
     int tn = tap + 1, cn = chunk;
@@ -130,20 +169,34 @@ __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
     const bool more = (it + 1 < NIT);
     if (!more) { tn = tap; cn = chunk; }   // the ring always reloads: no branch around a load
     const unsigned char* nb = (ABL & 2) ? frag_ptr(0, 0) : frag_ptr(tn, cn);
-    const int toffn = GATHER ? 0 : __builtin_amdgcn_readlane(v_tapoff, tn) * ROWB;
-    int pnext[4];
+    const int toffn = GATHER ? 0 : __builtin_amdgcn_readlane(v_tapoff, tn);
+    int pnext[4], knext[4];
 #pragma unroll
-    for (int ms = 0; ms < 4; ++ms) pnext[ms] = arow[ms] + toffn;
+    for (int ms = 0; ms < 4; ++ms) {
+      if (DMA) {
+        const int R = arow[ms] + toffn;
+        pnext[ms] = a_base(R);
+        knext[ms] = a_kk(R);
+      } else {
+        pnext[ms] = arow[ms] + toffn * ROWB;
+        knext[ms] = 0;
+      }
+    }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int cur = ks & 1, nxt = cur ^ 1;
 #pragma unroll
       for (int ms = 0; ms < 4; ++ms)
-        if (!(ABL & 16))
-          a[nxt][ms] = (ks < 3) ? *reinterpret_cast<const bf16x8*>(sA + pcur[ms] + (ks + 1) * 32)
-                                : *reinterpret_cast<const bf16x8*>(sA + pnext[ms]);
-        else
+        if (!(ABL & 16)) {
+          if (DMA)
+            a[nxt][ms] = (ks < 3) ? *reinterpret_cast<const bf16x8*>(sA + pcur[ms] + (((ks + 1) << 5) ^ kcur[ms]))
+                                  : *reinterpret_cast<const bf16x8*>(sA + pnext[ms] + knext[ms]);
+          else
+            a[nxt][ms] = (ks < 3) ? *reinterpret_cast<const bf16x8*>(sA + pcur[ms] + (ks + 1) * 32)
+                                  : *reinterpret_cast<const bf16x8*>(sA + pnext[ms]);
+        } else {
           a[nxt][ms] = a[cur][ms];
+        }
       __builtin_amdgcn_sched_barrier(0);   // reads of the NEXT k-step issue before these MFMAs
       const bf16x8 b0 = __builtin_bit_cast(bf16x8, Bc[ks][0]);
       const bf16x8 b1 = __builtin_bit_cast(bf16x8, Bc[ks][1]);
@@ -157,14 +210,22 @@ __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int ms = 0; ms < 4; ++ms) pcur[ms] = pnext[ms];
+    for (int ms = 0; ms < 4; ++ms) {
+      pcur[ms] = pnext[ms];
+      kcur[ms] = knext[ms];
+    }
     if (more && tn == 0 && !(ABL & 8)) {       // next iteration starts a new channel chunk
       __syncthreads();           // everyone is done reading the patch
-      if (!(ABL & 1))
-        igemm_load_patch<GATHER, BD_THREADS, BD_RELOAD_NB>(sA, in, g.Cin, cn * 64, p_lo, npix, in_pixels, s_pin, tid);
+      if (!(ABL & 1)) {
+        if (DMA)
+          dma_patch(cn * 64);
+        else
+          igemm_load_patch<GATHER, BD_THREADS, BD_RELOAD_NB>(sA, in, g.Cin, cn * 64, p_lo, npix, in_pixels, s_pin, tid);
+      }
       __syncthreads();
 #pragma unroll
-      for (int ms = 0; ms < 4; ++ms) a[0][ms] = *reinterpret_cast<const bf16x8*>(sA + pcur[ms]);
+      for (int ms = 0; ms < 4; ++ms)
+        a[0][ms] = *reinterpret_cast<const bf16x8*>(sA + pcur[ms] + (DMA ? kcur[ms] : 0));
     }
     tap = tn;
     chunk = cn;
@@ -271,8 +332,12 @@ extern "C" void iic_debug_enable_p64(int v) { g_p64_enabled = v; }
 
 extern "C" {
 
+static int g_bd_dma = 1;        // 1: LDS-DMA patch loads (128-B swizzled rows), 0: register-staged (144-B rows)
+extern "C" void iic_debug_bd_dma(int v) { g_bd_dma = v; }
+
 static long bd_lds_a(const iic_conv_geom* g) {
-  long a = (long)(g->ntaps == 1 ? BD_BM : g->NP256) * ROWB;
+  const long npix = g->ntaps == 1 ? BD_BM : g->NP256;
+  long a = g_bd_dma ? ((npix * 128 + 1023) & ~1023L) : npix * ROWB;
   long c = (long)BD_BM * (BD_BN + 8) * 2;
   long m = a > c ? a : c;
   return (m + 15) & ~15L;
@@ -304,17 +369,23 @@ int iic_conv_igemm_frag(const iic_conv_geom* g, const void* in, const void* wfra
   const int la = (int)bd_lds_a(g);
   const long lds = la + 2L * BD_BM * 4 + 4L * BD_BN * 4;
   hipStream_t s = (hipStream_t)stream;
-#define BD_LAUNCH(GA_, AB_)                                                                       \
+#define BD_LAUNCH2(GA_, AB_, DM_)                                                                 \
   do {                                                                                           \
     static bool attr = false;                                                                    \
     if (!attr) {                                                                                 \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bd_kernel<GA_, AB_>),  \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);         \
+      (void)hipFuncSetAttribute(                                                                 \
+          reinterpret_cast<const void*>(&conv_igemm_bd_kernel<GA_, AB_, DM_>),                   \
+          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                               \
       attr = true;                                                                               \
     }                                                                                            \
-    hipLaunchKernelGGL((conv_igemm_bd_kernel<GA_, AB_>), dim3(grid), dim3(BD_THREADS), lds, s,   \
-                       *g, (const bf16_t*)in, (const unsigned char*)wfrag, (bf16_t*)out, stats,  \
-                       (const bf16_t*)res_grad, (const bf16_t*)res_act, accumulate, mt, la);     \
+    hipLaunchKernelGGL((conv_igemm_bd_kernel<GA_, AB_, DM_>), dim3(grid), dim3(BD_THREADS), lds, \
+                       s, *g, (const bf16_t*)in, (const unsigned char*)wfrag, (bf16_t*)out,      \
+                       stats, (const bf16_t*)res_grad, (const bf16_t*)res_act, accumulate, mt,   \
+                       la);                                                                      \
+  } while (0)
+#define BD_LAUNCH(GA_, AB_)                                                                       \
+  do {                                                                                           \
+    if (g_bd_dma) BD_LAUNCH2(GA_, AB_, true); else BD_LAUNCH2(GA_, AB_, false);                  \
   } while (0)
   if (g->ntaps == 1) BD_LAUNCH(true, 0);
   else switch (iic_debug_get_ablate()) {

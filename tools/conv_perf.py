@@ -43,10 +43,16 @@ def main():
   ap.add_argument("--bm", type=int, default=0)
   ap.add_argument("--frag", type=int, default=1, help="1: weights-direct kernel where supported (A/B column)")
   ap.add_argument("--no-wgrad", action="store_true")
+  ap.add_argument("--bd-dma", type=int, default=1, help="weights-direct kernel: 1 = LDS-DMA patch loads, 0 = register-staged")
   ap.add_argument("--frag-ablate", type=str, default="", help="comma list of ablation codes for the frag kernel")
   a = ap.parse_args()
   dev = torch.device("cuda:0")
   N = a.n
+  if not a.bd_dma:
+    import ctypes
+    from iic_amd import _lib
+    ctypes.CDLL(_lib.LIB_PATH).iic_debug_bd_dma(0)
+    print("weights-direct kernel: register-staged patch loads")
   if a.bm:
     import ctypes
     from iic_amd import _lib
