@@ -54,7 +54,7 @@ _SIGNATURES = {
   "iic_conv_igemm_frag_supported": (c_int, [POINTER(ConvGeom)]),
   "iic_conv_igemm_frag": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P, _P, _P, c_int, _P]),
   "iic_weight_prep_frag": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
-  "iic_bn_finalize": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_long, c_float, c_float, c_int, _P]),
+  "iic_bn_finalize": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_long, c_long, c_float, c_float, c_int, _P]),
   "iic_bn_apply": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
   "iic_bn_bwd_reduce": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
   "iic_bn_bwd_finalize": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_long, _P]),

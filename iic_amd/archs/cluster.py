@@ -48,6 +48,15 @@ def _side_stream(device):
 
 
 SHARD_INPUTS = [False]  # set by iic_amd.run under torchrun: forward keeps only this rank's rows
+# Replica de-duplication (opt-in: IIC_DEDUP=<r> or DEDUP[0] = r).  The reference
+# replicates imgs_curr num_dataloaders times in all_imgs (cluster_sobel.py:215-226).  When a training
+# batch consists of r exact copies of its first B/r rows, the trunk runs on those rows only and
+# the 512-d features are repeated r times (autograd sums the replicas' gradients): batch mean and
+# biased variance of every BatchNorm are invariant under exact replication and the backward is
+# linear in the upstream gradient, so outputs and parameter gradients are unchanged; the unbiased
+# running_var factor uses the true batch size.  Removes 1/3 of view 1's conv work at r = 3.
+# NOT used by bench.py (it would change the FLOP accounting of the metric).
+DEDUP = [int(os.environ.get("IIC_DEDUP", "1"))]
 _WEIGHTS_EPOCH = [0]   # bumped by iic_amd.optim.Adam (raw-pointer updates do not bump _version)
 
 
@@ -434,6 +443,19 @@ class ClusterNet5gTrunk(nn.Module):
       from .. import dist as idist
       lo, hi = idist.shard_rows(x.size(0))
       x = x[lo:hi]
+    r = DEDUP[0]
+    if r > 1 and self.training and x.size(0) % r == 0 and x.size(0) >= 2 * r:
+      u = x.size(0) // r
+      if all(bool(torch.equal(x[:u], x[i * u:(i + 1) * u])) for i in range(1, r)):
+        ops.BN_REPLICAS[0] = r
+        try:
+          f = self._run(x[:u], penultimate_features)
+        finally:
+          ops.BN_REPLICAS[0] = 1
+        return f.repeat(r, 1)
+    return self._run(x, penultimate_features)
+
+  def _run(self, x, penultimate_features):
     x = _StemFn.apply(x, self.conv1.weight, self.bn1.weight, self.bn1.bias, self)
     x = self.layer1(x)
     x = self.layer2(x)

@@ -26,8 +26,8 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
 __global__ void bn_finalize_kernel(float* __restrict__ stats, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* __restrict__ running_mean,
                                    float* __restrict__ running_var, long long* __restrict__ nbt,
-                                   float* __restrict__ coef, int C, long count, float eps,
-                                   float momentum, int training) {
+                                   float* __restrict__ coef, int C, long count, long ucount,
+                                   float eps, float momentum, int training) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c == 0 && training && nbt) *nbt += 1;
   if (c >= C) return;
@@ -47,7 +47,9 @@ __global__ void bn_finalize_kernel(float* __restrict__ stats, const float* __res
     mean = (float)m;
     var = (float)v;
     if (running_mean) {
-      const double unb = count > 1 ? v * (double)count / (double)(count - 1) : v;
+      // ucount: sample count for the unbiased-variance factor; differs from `count` only when the
+      // batch holds exact replicas that were forwarded once (replica de-duplication)
+      const double unb = ucount > 1 ? v * (double)ucount / (double)(ucount - 1) : v;
       running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
       running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
     }
@@ -267,13 +269,14 @@ extern "C" {
 
 int iic_bn_finalize(float* stats, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, long long* num_batches_tracked, float* coef, int C,
-                    long count, float eps, float momentum, int training, void* stream) {
+                    long count, long unbiased_count, float eps, float momentum, int training,
+                    void* stream) {
   if (!gamma || !beta || !coef || C <= 0) return IIC_ERR_ARG;
   if (training && (!stats || count <= 0)) return IIC_ERR_ARG;
   if (!training && (!running_mean || !running_var)) return IIC_ERR_ARG;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                      stats, gamma, beta, running_mean, running_var, num_batches_tracked, coef, C,
-                     count, eps, momentum, training);
+                     count, unbiased_count > 0 ? unbiased_count : count, eps, momentum, training);
   return iic_launch_status();
 }
 

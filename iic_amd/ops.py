@@ -190,11 +190,17 @@ BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
 
+# Replica de-duplication (opt-in, archs.cluster.DEDUP): while a de-duplicated forward runs, the
+# unbiased running_var factor is computed for the TRUE batch (unique rows x this factor).
+BN_REPLICAS = [1]
+
+
 def bn_finalize(stats, gamma, beta, running_mean, running_var, nbt, C, count, training):
   coef = torch.empty((4, C), dtype=F32, device=gamma.device)
   check(lib().iic_bn_finalize(ptr(stats), ptr(gamma), ptr(beta), ptr(running_mean),
-                              ptr(running_var), ptr(nbt), ptr(coef), C, count, BN_EPS,
-                              BN_MOMENTUM, 1 if training else 0, stream_ptr()), "iic_bn_finalize")
+                              ptr(running_var), ptr(nbt), ptr(coef), C, count,
+                              count * BN_REPLICAS[0], BN_EPS, BN_MOMENTUM, 1 if training else 0,
+                              stream_ptr()), "iic_bn_finalize")
   return coef
 
 

@@ -150,10 +150,15 @@ int iic_weight_prep_frag(const float* w_oihw, void* w_frag, int Cout, int Cin, i
  * Statistics: stats stripes produced by iic_conv_igemm; finalised per channel here.
  * ------------------------------------------------------------------------------- */
 /* coef[0..3][C]: scale, shift, mean, invstd.  use_running: eval() with
- * track_running_stats.  running_* nullable (track_running_stats=False).  Re-zeroes stats. */
+ * track_running_stats.  running_* nullable (track_running_stats=False).  Re-zeroes stats.
+ * unbiased_count (0 = count): sample count of the unbiased running_var factor n/(n-1); differs
+ * from `count` only under replica de-duplication (cluster_sobel.py:215-226 replicates imgs_curr
+ * num_dataloaders times; forwarding the unique images once leaves mean / biased variance
+ * unchanged, only this factor sees the true batch size).                                    */
 int iic_bn_finalize(float* stats, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, long long* num_batches_tracked, float* coef, int C,
-                    long count, float eps, float momentum, int training, void* stream);
+                    long count, long unbiased_count, float eps, float momentum, int training,
+                    void* stream);
 /* out = relu( scale*y+shift  [+ res]  [+ scale2*y2+shift2] ) on PT interiors.            */
 int iic_bn_apply(const void* y, const float* coef, const void* res, const void* y2,
                  const float* coef2, void* out, int N, int H, int W, int P, int C, int relu,

@@ -215,6 +215,93 @@ def test_net5g_96_step_runs_and_decreases_loss():
   assert losses[-1] < losses[0], losses
 
 
+def test_replica_deduplication():
+  """all_imgs = r exact replicas of the unique images
+  (cluster_sobel.py:215-226).  Forwarding the unique rows once and repeating the features
+  reproduces the full replicated forward/backward: BN batch statistics are replication-invariant,
+  the backward is linear in the upstream gradient, the unbiased running_var factor uses the true
+  batch size.
+  (a) exactness where depth cannot amplify rounding: the stem (conv + BN + ReLU + pool) alone;
+  (b) whole net: agreement class of two runs that differ only in rounding (see the golden test)."""
+  from iic_amd import archs, ops
+  from iic_amd.archs import cluster as cl
+  from iic_amd.losses import IID_loss_heads
+  from iic_amd.transforms import sobel_process
+  torch.manual_seed(1)
+  g = torch.Generator().manual_seed(11)
+  base = torch.rand(64, 1, 64, 64, generator=g)
+  imgs = base.repeat(3, 1, 1, 1).to(dev())
+  imgs_tf = torch.clamp(torch.flip(imgs, dims=[3]) * 0.9 + 0.05 * torch.rand(192, 1, 64, 64, generator=g).to(dev()), 0, 1)
+  ref_net = archs.ClusterNet5g(_cfg(input_sz=64, num_sub_heads=2, output_k=10)).to(dev()).train()
+  with torch.no_grad():
+    for h in ref_net.head.heads:
+      h[0].weight.normal_(0, 0.3)
+  state = {k: v.clone() for k, v in ref_net.state_dict().items()}
+
+  # ---- (a) stem only: full replicated batch vs unique batch with summed upstream gradients
+  stem = {}
+  gup = torch.randn(192, 35, 35, 64, generator=g).to(dev()).to(torch.bfloat16)   # PT layout, border 1
+  gup[:, 0] = 0; gup[:, -1] = 0; gup[:, :, 0] = 0; gup[:, :, -1] = 0
+  gsum = (gup[:64].float() + gup[64:128].float() + gup[128:].float())
+  for mode in ("full", "unique"):
+    net = archs.ClusterNet5g(_cfg(input_sz=64, num_sub_heads=2, output_k=10)).to(dev()).train()
+    net.load_state_dict(state)
+    t = net.trunk
+    x = sobel_process(imgs if mode == "full" else imgs[:64], False)
+    ops.BN_REPLICAS[0] = 1 if mode == "full" else 3
+    try:
+      out = cl._StemFn.apply(x, t.conv1.weight, t.bn1.weight, t.bn1.bias, t)
+    finally:
+      ops.BN_REPLICAS[0] = 1
+    o = out.detach().float().clone()
+    out.backward(gup if mode == "full" else gsum.to(torch.bfloat16))
+    torch.cuda.synchronize()
+    stem[mode] = (o, t.conv1.weight.grad.clone(), t.bn1.weight.grad.clone(), t.bn1.bias.grad.clone(),
+                  t.bn1.running_mean.clone(), t.bn1.running_var.clone())
+  of, wf, gf, bf, rmf, rvf = stem["full"]
+  ou, wu, gu, bu, rmu, rvu = stem["unique"]
+  d = (of[:64] - ou).abs()
+  assert float(d.max()) <= 2 ** -7 * float(ou.abs().max()) and float((d > 0).float().mean()) < 1e-3
+  assert torch.equal(of[:64], of[64:128]) and torch.equal(of[:64], of[128:])
+  assert torch.allclose(rmf, rmu, rtol=1e-5, atol=1e-7) and torch.allclose(rvf, rvu, rtol=1e-5, atol=1e-8)
+  # the summed gradient is rounded to bf16 once more than the three replicas' gradients
+  assert _cos(wf, wu) > 0.9995 and _cos(gf, gu) > 0.9995 and _cos(bf, bu) > 0.9995
+  assert abs(float(wu.norm() / wf.norm()) - 1) < 5e-3
+
+  # ---- (b) whole net
+  res = {}
+  for r in (1, 3):
+    net = archs.ClusterNet5g(_cfg(input_sz=64, num_sub_heads=2, output_k=10)).to(dev()).train()
+    net.load_state_dict(state)
+    cl.DEDUP[0] = r
+    try:
+      xo = net.forward_packed(sobel_process(imgs, False))
+      xt = net.forward_packed(sobel_process(imgs_tf, False))
+    finally:
+      cl.DEDUP[0] = 1
+    assert xo.shape == (192, 2, 10)
+    loss, _ = IID_loss_heads(xo, xt, lamb=1.0)
+    loss.mean().backward()
+    torch.cuda.synchronize()
+    res[r] = (xo.detach().clone(), float(loss.mean().detach()), {n: p.grad.clone() for n, p in net.named_parameters()},
+              {k: v.clone() for k, v in net.state_dict().items() if "running" in k})
+  (o1, l1, g1, s1), (o3, l3, g3, s3) = res[1], res[3]
+  assert torch.equal(o3[:64], o3[64:128]) and torch.equal(o3[:64], o3[128:])
+  assert float((o1 - o3).abs().mean()) < 4e-3 and abs(l1 - l3) < 3e-4, (l1, l3)    # loss ~ -4e-4 here
+  names = [n for n in g1 if float(g1[n].norm()) > 1e-8]
+  cs = {n: _cos(g1[n], g3[n]) for n in names}
+  rs = {n: float(g3[n].norm() / g1[n].norm()) for n in names}
+  os.makedirs("gpurun_out", exist_ok=True)
+  with open("gpurun_out/dedup_grads.txt", "w") as f:
+    for n in names:
+      f.write("%-45s cos %.4f  norm ratio %.4f\n" % (n, cs[n], rs[n]))
+  assert np.median(list(cs.values())) > 0.8 and min(cs.values()) > 0.6, \
+      (float(np.median(list(cs.values()))), min(cs.values()))
+  assert abs(np.median(list(rs.values())) - 1.0) < 0.1, float(np.median(list(rs.values())))
+  k = "trunk.bn1.running_var"
+  assert torch.allclose(s1[k], s3[k], rtol=1e-4, atol=1e-6), (s1[k] - s3[k]).abs().max()
+
+
 def test_north_star_full_size_properties():
   """BASELINE.json configs[1] at FULL size (660 pairs, 96x96, k=70, 5 sub-heads), checked
   through size-independent properties of the domain:
