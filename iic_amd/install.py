@@ -30,6 +30,13 @@ PATCHES = [
   ("code.archs", "SegmentationNet10aTwoHead", "iic_amd.archs", "SegmentationNet10aTwoHead"),
   ("code.archs.segmentation", "SegmentationNet10a", "iic_amd.archs", "SegmentationNet10a"),
   ("code.archs.segmentation", "SegmentationNet10aTwoHead", "iic_amd.archs", "SegmentationNet10aTwoHead"),
+  # evaluation matching (cluster_eval.py:11 binds these by name from .eval_metrics)
+  ("code.utils.cluster.eval_metrics", "_original_match", "iic_amd.eval_metrics", "_original_match"),
+  ("code.utils.cluster.eval_metrics", "_hungarian_match", "iic_amd.eval_metrics", "_hungarian_match"),
+  ("code.utils.cluster.eval_metrics", "_acc", "iic_amd.eval_metrics", "_acc"),
+  ("code.utils.cluster.cluster_eval", "_original_match", "iic_amd.eval_metrics", "_original_match"),
+  ("code.utils.cluster.cluster_eval", "_hungarian_match", "iic_amd.eval_metrics", "_hungarian_match"),
+  ("code.utils.cluster.cluster_eval", "_acc", "iic_amd.eval_metrics", "_acc"),
   ("code.utils.segmentation.IID_losses", "IID_segmentation_loss", "iic_amd.seg_losses", "IID_segmentation_loss"),
   ("code.utils.segmentation.IID_losses", "IID_segmentation_loss_uncollapsed", "iic_amd.seg_losses",
    "IID_segmentation_loss_uncollapsed"),

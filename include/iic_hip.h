@@ -265,6 +265,18 @@ int iic_adam_step(int n, float* const* params, const float* const* grads, float*
 /* one-time device probes used by the test-suite (documented in DESIGN.md) */
 int iic_probe_tr16(void* out_u16_64x4, void* stream);
 
+/* ---------------------------------------------------------------------------------
+ * Evaluation counts -- replaces the per-(cluster, class) masked sums with
+ * a host sync each of code/utils/cluster/eval_metrics.py:18-24 (_original_match), :42-46
+ * (_hungarian_match) and the equality count of _acc (:69).
+ * preds / targets: int64 [n] (torch.long, as the reference's flat_preds / flat_targets);
+ * counts int64 [k_pred][k_gt] (zeroed here): counts[c1][c2] = #{i : preds[i]==c1, targets[i]==c2}.
+ * Labels outside [0, k) match nothing.  k_pred * k_gt <= 16384.
+ * ------------------------------------------------------------------------------- */
+int iic_contingency(const long long* preds, const long long* targets, long n, int k_pred, int k_gt,
+                    long long* counts, void* stream);
+int iic_count_equal(const long long* a, const long long* b, long n, long long* count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

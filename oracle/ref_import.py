@@ -103,3 +103,36 @@ def ref_sobel_process():
     finally:
       torch.Tensor.cuda = orig
   return sobel_cpu
+
+
+def ref_eval_metrics():
+  """code/utils/cluster/eval_metrics.py, executed from its source with asserts stripped
+  (``assert flat_preds.is_cuda`` cannot hold in this CPU-only container; nothing else changes) and
+  with a recording stand-in for ``sklearn.utils.linear_assignment_`` (removed from scikit-learn
+  >= 0.23; the reference pins 0.19.1, whose ``linear_assignment`` is the Hungarian/Munkres
+  algorithm).  The stand-in solves the same problem with scipy and keeps the cost matrix it was
+  given, so the golden fixture pins the reference's own num_correct counts."""
+  _shim()
+  import numpy as np
+  from scipy.optimize import linear_sum_assignment
+  rec = {}
+
+  def linear_assignment(cost):
+    rec["cost"] = np.array(cost)
+    r, c = linear_sum_assignment(cost)
+    return np.stack([r, c], axis=1)
+  fake = types.ModuleType("sklearn.utils.linear_assignment_")
+  fake.linear_assignment = linear_assignment
+  sys.modules["sklearn.utils.linear_assignment_"] = fake
+  path = os.path.join(REF, "code/utils/cluster/eval_metrics.py")
+  src = open(path).read()
+  mod = types.ModuleType("ref_eval_metrics")
+  mod.__file__ = path
+  if not hasattr(dict, "iteritems"):
+    # dict.iteritems (py2) is used on a plain dict: give the module a dict subclass-free helper
+    src_exec = src.replace(".iteritems()", ".items()")   # in-memory only; the file is untouched
+  else:
+    src_exec = src
+  exec(compile(src_exec, path, "exec", optimize=1), mod.__dict__)
+  mod._recorded = rec
+  return mod

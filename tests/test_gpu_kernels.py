@@ -655,3 +655,37 @@ def test_full_size_kernel_generations_agree(cin, cout, H):
     assert float((d > 0).float().mean()) < 0.02                                 # and only rarely
   assert torch.allclose(st1, st0, rtol=1e-4, atol=1e-2)
   assert float((dW1 - dW0).abs().max()) <= 1e-4 * float(dW0.abs().max())
+
+
+def test_eval_matching_against_reference_golden():
+  """iic_amd.eval_metrics (one contingency kernel) vs the reference's own matching functions
+  (tests/golden/eval.npz) -- integer work, exact; plus a large random case vs the oracle."""
+  from iic_amd import eval_metrics as em
+  from oracle import eval_oracle
+  g = np.load(os.path.join(G, "eval.npz"))
+  n_cases = len([k for k in g.files if k.endswith("/k")])
+  for i in range(n_cases):
+    p, t = g["c%d/preds" % i], g["c%d/targets" % i]
+    kp, kt = (int(v) for v in g["c%d/k" % i])
+    pd, td = torch.from_numpy(p).to(dev()), torch.from_numpy(t).to(dev())
+    assert em._original_match(pd, td, kp, kt) == [tuple(int(v) for v in r) for r in g["c%d/original_match" % i]]
+    if kp == kt:
+      c = g["c%d/num_correct" % i]
+      assert np.array_equal(em._counts(pd, td, kp, kt), c)
+      hm = em._hungarian_match(pd, td, kp, kt)
+      ref = [tuple(int(v) for v in r) for r in g["c%d/hungarian_match" % i]]
+      assert sum(c[a, b] for a, b in hm) == sum(c[a, b] for a, b in ref)
+      re = torch.zeros_like(pd)
+      for a, b in hm:
+        re[pd == a] = b
+      assert abs(em._acc(re, td, kt) - float(g["c%d/acc" % i][0])) < 1e-12
+  # segmentation-sized input with labels outside [0, k) (masked pixels = -1): they match nothing
+  rng = np.random.default_rng(0)
+  n = 3_000_000
+  p = rng.integers(0, 24, n)
+  t = rng.integers(-1, 3, n)
+  pd, td = torch.from_numpy(p).to(dev()), torch.from_numpy(t).to(dev())
+  assert np.array_equal(em._counts(pd, td, 24, 3), eval_oracle.contingency(p, t, 24, 3))
+  assert em._original_match(pd, td, 24, 3) == eval_oracle.original_match(p, t, 24, 3)
+  with pytest.raises(AssertionError):
+    em._original_match(torch.from_numpy(p), td, 24, 3)        # the reference's is_cuda assert is kept

@@ -13,6 +13,10 @@ def test_install_rebinds_reference_names(tmp_path, monkeypatch):
     (root / d / "__init__.py").write_text("")
   (root / "code/utils/cluster/IID_losses.py").write_text("def IID_loss(*a, **k):\n  return 'ref'\n")
   (root / "code/utils/cluster/transforms.py").write_text("def sobel_process(*a, **k):\n  return 'ref'\n")
+  (root / "code/utils/cluster/eval_metrics.py").write_text(
+    "def _original_match(*a):\n  return 'ref'\ndef _hungarian_match(*a):\n  return 'ref'\ndef _acc(*a):\n  return 'ref'\n")
+  (root / "code/utils/cluster/cluster_eval.py").write_text(
+    "from .eval_metrics import _hungarian_match, _original_match, _acc\n")
   (root / "code/archs/__init__.py").write_text("class ClusterNet5g: pass\nclass ClusterNet5gTwoHead: pass\nclass ClusterNet6c: pass\nclass ClusterNet6cTwoHead: pass\nclass SegmentationNet10a: pass\nclass SegmentationNet10aTwoHead: pass\n")
   (root / "code/archs/segmentation/__init__.py").write_text("class SegmentationNet10a: pass\nclass SegmentationNet10aTwoHead: pass\n")
   (root / "code/utils/segmentation/IID_losses.py").write_text("def IID_segmentation_loss(*a, **k):\n  return 0\ndef IID_segmentation_loss_uncollapsed(*a, **k):\n  return 0\n")
@@ -35,6 +39,9 @@ def test_install_rebinds_reference_names(tmp_path, monkeypatch):
   assert ns["IID_loss"] is losses.IID_loss
   assert ns["sobel_process"] is transforms.sobel_process
   assert ns["net_cls"] is archs.ClusterNet5g
+  from iic_amd import eval_metrics
+  import code.utils.cluster.cluster_eval as ce      # binds the names at import: patched in place
+  assert ce._original_match is eval_metrics._original_match and ce._acc is eval_metrics._acc
   assert xrange is range  # noqa: F821
   for k in [k for k in sys.modules if k == "code" or k.startswith("code.")]:
     del sys.modules[k]

@@ -143,3 +143,27 @@ def test_net10a_oracle_matches_reference(g_nets):
   params = net_oracle.make_net10a_params(4, 3, 1, True, seed=5, randomize_bn=True)
   ys = net_oracle.net10a_forward(params, torch.from_numpy(g_nets["net10a_in"]), 24, True, "head", 1)
   assert np.abs(ys[0].detach().numpy() - g_nets["net10a_out"]).max() < 2e-6
+
+
+def test_eval_metrics_oracle_matches_reference():
+  """oracle/eval_oracle.py vs the reference's own _original_match / _hungarian_match / _acc
+  (tests/golden/eval.npz, produced by oracle/gen_golden_eval.py)."""
+  from oracle import eval_oracle
+  g = np.load(os.path.join(G, "eval.npz"))
+  n_cases = len([k for k in g.files if k.endswith("/k")])
+  assert n_cases >= 6
+  for i in range(n_cases):
+    p, t = g["c%d/preds" % i], g["c%d/targets" % i]
+    kp, kt = (int(v) for v in g["c%d/k" % i])
+    assert eval_oracle.original_match(p, t, kp, kt) == [tuple(int(v) for v in r) for r in g["c%d/original_match" % i]]
+    if kp == kt:
+      c = eval_oracle.contingency(p, t, kp, kt)
+      assert np.array_equal(c, g["c%d/num_correct" % i])
+      hm = eval_oracle.hungarian_match(p, t, kp, kt)
+      ref = [tuple(int(v) for v in r) for r in g["c%d/hungarian_match" % i]]
+      assert sum(c[a, b] for a, b in hm) == sum(c[a, b] for a, b in ref)     # same optimum
+      assert sorted(b for _, b in hm) == list(range(kt))                       # a permutation
+      re = np.zeros_like(p)
+      for a, b in hm:
+        re[p == a] = b
+      assert abs(eval_oracle.acc(re, t) - float(g["c%d/acc" % i][0])) < 1e-12
