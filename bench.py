@@ -178,6 +178,10 @@ def main():
   # weak scaling: every rank owns `pairs` pairs (its shard of the global batch of pairs*world)
   imgs, imgs_tf = make_batch(args.pairs, INPUT_SZ, dev, seed=rank)
   params = list(net.parameters())
+  # N > 1: gradient all-reduce overlapped with backward (IIC_DIST_OVERLAP=0: after backward)
+  reducer = None
+  if world > 1 and os.environ.get("IIC_DIST_OVERLAP", "1") != "0":
+    reducer = idist.GradReducer(params)
 
   def step():
     net.zero_grad(set_to_none=True)
@@ -188,7 +192,10 @@ def main():
     loss, _ = IID_loss_heads(xo, xt, lamb=1.0)
     loss = loss.mean()
     loss.backward()
-    idist.all_reduce_grads(params)
+    if reducer is not None:
+      reducer.finish()
+    else:
+      idist.all_reduce_grads(params)
     opt.step()
     return loss
 

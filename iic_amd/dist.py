@@ -82,3 +82,77 @@ def all_reduce_grads(params, bucket_bytes=64 << 20):
       flush()
       bucket, size = [], 0
   flush()
+
+
+class GradReducer(object):
+  """Bucketed SUM all-reduce of parameter gradients OVERLAPPED with the backward pass.
+
+  Parameters are bucketed in reverse registration order (the order backward produces their
+  gradients).  A post-accumulate-grad hook counts a bucket down; when its last gradient is
+  final the bucket is flattened and all-reduced asynchronously (RCCL runs on its own stream,
+  ordered after the work already enqueued on the compute stream), while the rest of backward
+  keeps running.  ``finish()`` (between backward() and optimizer.step()) waits and scatters the
+  sums back into ``.grad``.  Parameters that receive no gradient in a step (inactive head of a
+  two-head net) are detected in finish(): incomplete buckets are reduced there.
+  """
+
+  def __init__(self, params, bucket_bytes=32 << 20):
+    self.params = [p for p in params if p.requires_grad]
+    self.buckets = []          # lists of params
+    cur, size = [], 0
+    for p in reversed(self.params):
+      cur.append(p)
+      size += p.numel() * p.element_size()
+      if size >= bucket_bytes:
+        self.buckets.append(cur)
+        cur, size = [], 0
+    if cur:
+      self.buckets.append(cur)
+    self.bucket_of = {}
+    for bi, b in enumerate(self.buckets):
+      for p in b:
+        self.bucket_of[p] = bi
+    self._reset()
+    self.handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
+
+  def _reset(self):
+    self.pending = [len(b) for b in self.buckets]
+    self.ready = [set() for _ in self.buckets]
+    self.inflight = {}         # bucket index -> (flat, work, params)
+
+  def _launch(self, bi, members):
+    if not members:
+      return
+    flat = torch.cat([p.grad.reshape(-1) for p in members])
+    work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=_STATE["group"], async_op=True)
+    self.inflight[bi] = (flat, work, members)
+
+  def _hook(self, p):
+    if not enabled():
+      return
+    bi = self.bucket_of[p]
+    self.ready[bi].add(p)
+    self.pending[bi] -= 1
+    if self.pending[bi] == 0:
+      self._launch(bi, self.buckets[bi])
+
+  def finish(self):
+    """Call after backward(): reduces buckets that never completed (parameters without a
+    gradient this step are skipped -- every rank skips the same ones), waits, scatters."""
+    if enabled():
+      for bi, b in enumerate(self.buckets):
+        if bi not in self.inflight:
+          self._launch(bi, [p for p in b if p.grad is not None])
+      for bi in sorted(self.inflight):
+        flat, work, members = self.inflight[bi]
+        work.wait()
+        off = 0
+        for p in members:
+          n = p.grad.numel()
+          p.grad.copy_(flat[off:off + n].view_as(p.grad))
+          off += n
+    self._reset()
+
+  def remove(self):
+    for h in self.handles:
+      h.remove()

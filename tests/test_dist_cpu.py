@@ -42,6 +42,28 @@ def _worker(rank, world, port, q):
   idist.all_reduce_grads(ps, bucket_bytes=32)
   tot = sum(range(1, world + 1))
   ok = ok and all(torch.allclose(p.grad, torch.full_like(p, float(tot + world * i))) for i, p in enumerate(ps))
+  # overlapped reducer: hooks fire during backward, incomplete buckets (a parameter without a
+  # gradient) are handled in finish(); result == plain SUM over ranks
+  torch.manual_seed(0)
+  ws = [torch.nn.Parameter(torch.randn(6, 4)), torch.nn.Parameter(torch.randn(4, 3)),
+        torch.nn.Parameter(torch.randn(3)), torch.nn.Parameter(torch.randn(5))]     # last: never used
+  red = idist.GradReducer(ws, bucket_bytes=64)
+  for it in range(2):
+    for w in ws:
+      w.grad = None
+    x = torch.full((2, 6), float(rank + 1 + it))
+    y = ((x @ ws[0]) @ ws[1] + ws[2]).sum()
+    y.backward()
+    local = [w.grad.clone() if w.grad is not None else None for w in ws]
+    red.finish()
+    for w, l in zip(ws, local):
+      if l is None:
+        ok = ok and w.grad is None
+        continue
+      tot = l.clone()
+      dist.all_reduce(tot)
+      ok = ok and torch.allclose(w.grad, tot)
+  red.remove()
   q.put((rank, bool(ok), lo, hi))
   dist.destroy_process_group()
 
