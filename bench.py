@@ -227,7 +227,7 @@ def main():
     fence()
     if timer is not None:
       timer.uninstall()
-  loss_val = float(last)
+  loss_val = float(last.detach())
   if world > 1:
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
