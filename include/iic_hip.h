@@ -277,6 +277,26 @@ int iic_contingency(const long long* preds, const long long* targets, long n, in
                     long long* counts, void* stream);
 int iic_count_equal(const long long* a, const long long* b, long n, long long* count, void* stream);
 
+/* ---------------------------------------------------------------------------------
+ * Paired augmentation on the GPU -- replaces the per-sample PIL pipeline
+ * code/utils/cluster/transforms.py:107-217 (sobel_make_transforms, default branch: RandomCrop ->
+ * Resize(BILINEAR) -> [RandomHorizontalFlip -> ColorJitter] -> custom_greyscale_to_tensor :12-25)
+ * that the DataLoader workers of code/utils/cluster/data.py:223-290 run on the host.  Results are
+ * bit-identical to PIL 's (oracle/augment_oracle.py).
+ * imgs_u8  uint8 [B][H][W][3] (HWC, as the datasets hold them), resident in HBM.
+ * iparams  int32 [N][12]: source image, crop x0, crop y0, flip, n_ops, op[4] (0 brightness,
+ *          1 contrast, 2 saturation, 3 hue -- in application order), hue shift (int8 wrap), 0, 0.
+ * fparams  float [N][4]: factor of brightness, contrast, saturation; [3] = hue factor (not read:
+ *          the kernel uses the uint8 increment in iparams[9]).
+ * bounds   int32 [S][2] (first tap, tap count), kk int32 [S][ksize]: Pillow's 22-bit resampling
+ *          coefficients for crop -> S (square crops: both passes use the same table).
+ * lut      float [256] = v / 255 as torch computes it.
+ * out      float [N][C][S][S], C = 4 (R,G,B,grey) with include_rgb else 1 (grey).
+ * ------------------------------------------------------------------------------- */
+int iic_augment(const void* imgs_u8, int B, int H, int W, const int* iparams, const float* fparams,
+                int N, const int* bounds, const int* kk, int ksize, int crop, int S,
+                const float* lut, float* out, int include_rgb, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

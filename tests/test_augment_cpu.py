@@ -1,0 +1,107 @@
+"""Paired-augmentation oracle (oracle/augment_oracle.py): the numpy algorithm specification of
+csrc/augment.hip against the PIL restatement of the reference pipeline
+(/root/reference/code/utils/cluster/transforms.py:107-217), bit for bit, plus the host-side
+tables of iic_amd/augment.py."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from oracle import augment_oracle as ao   # noqa: E402
+
+
+def _image(rng, H, W, kind):
+  if kind == "noise":
+    return rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+  if kind == "smooth":
+    y, x = np.mgrid[0:H, 0:W]
+    a = np.stack([127 + 120 * np.sin(x / 9.0 + y / 17.0), 127 + 120 * np.cos(x / 5.0), (x * y) % 256], -1)
+    return np.clip(a + rng.normal(0, 4, a.shape), 0, 255).astype(np.uint8)
+  if kind == "grey":
+    g = rng.integers(0, 256, (H, W, 1), dtype=np.uint8)
+    return np.repeat(g, 3, 2)
+  return np.full((H, W, 3), int(rng.integers(0, 256)), np.uint8)
+
+
+@pytest.mark.parametrize("H,crop,S", [(96, 84, 96), (32, 20, 24), (96, 64, 64), (40, 36, 24)])
+def test_numpy_spec_matches_pil(H, crop, S):
+  rng = np.random.default_rng(H * 1000 + crop)
+  bad = 0
+  for t, kind in enumerate(["noise", "smooth", "grey", "flat", "noise", "smooth"]):
+    img = _image(rng, H, H, kind)
+    for p in ao.random_params(rng, 3, (H, H), crop):
+      for include_rgb in (True, False):
+        a = ao.pil_pipeline(img, p["crop_xy"], crop, S, include_rgb, p["flip"], p["order"], p["factors"])
+        b = ao.np_pipeline(img, p["crop_xy"], crop, S, include_rgb, p["flip"], p["order"], p["factors"])
+        assert a.shape == b.shape == ((4 if include_rgb else 1), S, S) and a.dtype == b.dtype == np.float32
+        bad += int(not np.array_equal(a, b))
+    # tf1 / tf3: no flip, no jitter
+    a = ao.pil_pipeline(img, (1, 2), crop, S, True)
+    b = ao.np_pipeline(img, (1, 2), crop, S, True)
+    bad += int(not np.array_equal(a, b))
+  assert bad == 0
+
+
+def test_jitter_extremes_match_pil():
+  """Factor range ends, every single op alone, hue wrap-around both ways."""
+  rng = np.random.default_rng(5)
+  img = _image(rng, 48, 48, "noise")
+  cases = []
+  for op, vals in ((ao.OP_BRIGHTNESS, (0.6, 1.0, 1.4)), (ao.OP_CONTRAST, (0.6, 1.0, 1.4)),
+                   (ao.OP_SATURATION, (0.6, 1.0, 1.4, 0.0)), (ao.OP_HUE, (-0.125, -0.004, 0.0, 0.004, 0.125, 0.5, -0.5))):
+    for v in vals:
+      cases.append(([op], {op: v}))
+  for order, factors in cases:
+    a = ao.pil_pipeline(img, (3, 5), 40, 48, True, True, order, factors)
+    b = ao.np_pipeline(img, (3, 5), 40, 48, True, True, order, factors)
+    assert np.array_equal(a, b), (order, factors)
+
+
+def test_host_tables_match_oracle_and_identity():
+  from iic_amd.augment import bilinear_tables, hue_shift
+  for i, o in ((84, 96), (20, 24), (64, 64), (36, 24), (96, 32), (7, 31)):
+    b0, k0 = ao.resample_coeffs(i, o)
+    b1, k1 = bilinear_tables(i, o)
+    assert np.array_equal(b0, b1) and np.array_equal(k0, k1)
+    assert (k1.sum(1) - (1 << 22)).__abs__().max() <= k1.shape[1]       # weights sum to ~1.0
+  b, k = bilinear_tables(64, 64)                                         # same size: identity taps
+  assert (k[:, 0] == 1 << 22).all() and (k[:, 1:] == 0).all() and (b[:, 0] == np.arange(64)).all()
+  for f in (-0.5, -0.125, -0.001, 0.0, 0.001, 0.125, 0.5):
+    assert hue_shift(f) == ao.hue_delta(f)
+
+
+def test_paired_dataloaders_order_and_lengths():
+  """The loader list mirrors _create_dataloaders (data.py:259-335): same sequential indices in
+  every loader, tf1 first then tf2 loaders, short last batch kept."""
+  import torch
+  from iic_amd.augment import paired_dataloaders
+
+  class Stub(object):
+    B = 10
+    def __init__(self):
+      self.calls = []
+    def plain(self, idx):
+      self.calls.append(("plain", tuple(idx)))
+      return torch.tensor(idx, dtype=torch.float32)
+    def jittered(self, idx):
+      self.calls.append(("jit", tuple(idx)))
+      return torch.tensor(idx, dtype=torch.float32) + 0.5
+
+  aug = Stub()
+  targets = torch.arange(10) * 3
+  loaders = paired_dataloaders(aug, targets, 4, 2)
+  assert len(loaders) == 3 and all(len(l) == 3 for l in loaders)
+  seen = 0
+  for tup in zip(*[iter(l) for l in loaders]):
+    a, t = tup[0]
+    n = a.shape[0]
+    assert n == (4 if seen < 8 else 2)
+    for d in (1, 2):
+      b, t2 = tup[d]
+      assert torch.equal(b, a + 0.5) and torch.equal(t, t2)
+    assert torch.equal(t, targets[seen:seen + n])
+    seen += n
+  assert seen == 10
+  assert [c[0] for c in aug.calls[:3]] == ["plain", "jit", "jit"]
