@@ -141,6 +141,11 @@ def main():
   ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="pairs per GPU (default 660)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-roofline", action="store_true")
+  ap.add_argument("--with-augment", action="store_true",
+                  help="also build every step's batch inside the timed region with the GPU paired "
+                       "augmentation (iic_amd.augment, SURVEY 8f rank 1) from a resident uint8 "
+                       "dataset, as cluster_sobel.py:205-232 does from its dataloaders; the default "
+                       "(off) is the metric's own timed region, which excludes data loading")
   args = ap.parse_args()
 
   world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -183,10 +188,29 @@ def main():
   if world > 1 and os.environ.get("IIC_DIST_OVERLAP", "1") != "0":
     reducer = idist.GradReducer(params)
 
+  aug = None
+  if args.with_augment:
+    import numpy as np
+    from iic_amd.augment import PairedAugmenter
+    g = torch.Generator().manual_seed(100 + rank)
+    dataset = torch.randint(0, 256, (8192, INPUT_SZ, INPUT_SZ, 3), dtype=torch.uint8, generator=g).to(dev)
+    aug = PairedAugmenter(dataset, 84, INPUT_SZ, False, seed=rank)     # cluster_sobel.py:52,76-77 defaults
+    aug_state = {"pos": 0}
+
+  def next_batch():
+    # one iteration of the zipped loaders: dataloader_batch_sz = pairs / 3 base images, tf1 once
+    # (replicated into the 3 slots) and 3 independent tf2 draws (cluster_sobel.py:215-226)
+    nb = args.pairs // 3
+    idx = (aug_state["pos"] + np.arange(nb)) % 8192
+    aug_state["pos"] = int((aug_state["pos"] + nb) % 8192)
+    base, tfs = aug.paired_batch(idx, 3)
+    return base.repeat(3, 1, 1, 1), torch.cat(tfs, 0)
+
   def step():
     net.zero_grad(set_to_none=True)
-    a = sobel_process(imgs, False)
-    b = sobel_process(imgs_tf, False)
+    bi, bt = next_batch() if aug is not None else (imgs, imgs_tf)
+    a = sobel_process(bi, False)
+    b = sobel_process(bt, False)
     xo = net.forward_packed(a)
     xt = net.forward_packed(b)
     loss, _ = IID_loss_heads(xo, xt, lamb=1.0)
@@ -240,7 +264,8 @@ def main():
       "metric": "paired-images/sec, STL10 96x96 ClusterNet5g+IID_loss",
       "value": value, "unit": "paired-images/sec", "n_gpus": world, "steps": args.steps,
       "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-      "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+      "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+      "data": "synthetic" if aug is None else "synthetic uint8 dataset, GPU paired augmentation in the timed region",
       "config": {"workload": "STL10 96x96 ClusterNet5g IID+ (cluster_sobel.py train step), "
                              "batch %d pairs/GPU, 5 sub-heads, k=70, bf16 MFMA convs / fp32 "
                              "stem+heads+loss, fused HIP Adam" % args.pairs,

@@ -182,13 +182,15 @@ int iic_augment(const void* imgs_u8, int B, int H, int W, const int* iparams, co
   hipStream_t s = (hipStream_t)stream;
 #define AUG_LAUNCH(RGB_)                                                                          \
   do {                                                                                           \
-    if (lds > 48 * 1024) {                                                                       \
+    static bool attr = false; /* one-time: raise the dynamic LDS limit (static s_red on top) */   \
+    if (!attr) {                                                                                 \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&augment_kernel<RGB_>),              \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=           \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) !=         \
           hipSuccess) {                                                                          \
         (void)hipGetLastError();                                                                 \
         return IIC_ERR_UNSUPPORTED;                                                              \
       }                                                                                          \
+      attr = true;                                                                               \
     }                                                                                            \
     hipLaunchKernelGGL(augment_kernel<RGB_>, dim3(N), dim3(256), lds, s, (const uint8_t*)imgs_u8, \
                        H, W, iparams, fparams, bounds, kk, ksize, crop, S, lut, out);            \
