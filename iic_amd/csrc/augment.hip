@@ -18,8 +18,14 @@
 //     wrap-around hue shift of torchvision's adjust_hue;
 //   * grey: L = (19595 R + 38470 G + 7471 B + 0x8000) >> 16; to_tensor: value / 255 in float32
 //     (256-entry table from the host).
-// The random parameters (crop offsets, flip, jitter factors and their shuffled order) are inputs:
-// iic_amd/augment.py draws them with torchvision's distributions.
+// The same kernel serves the greyscale scripts' pipelines (transforms.py:220-330, mode "L" images,
+// CH = 1): optional RandomRotation first (PIL Image.rotate, NEAREST = ImagingTransformAffine's
+// 16.16 fixed-point inverse mapping, zero fill; the coefficients come from the host), a crop size
+// chosen per image out of a few (one resampling table per size), ToTensor at the end.  On an L
+// image ColorJitter's saturation and hue are identities (ImageEnhance.Color blends the image with
+// itself; adjust_hue returns L images unchanged).
+// The random parameters (rotation, crop size and offsets, flip, jitter factors and their shuffled
+// order) are inputs: iic_amd/augment.py draws them with torchvision's distributions.
 #include "common.h"
 #include "../../include/iic_hip.h"
 
@@ -30,7 +36,8 @@
 #pragma clang fp contract(off)
 
 #define AUG_PREC 22
-#define AUG_IP 12      // ints per output image:  src, x0, y0, flip, nops, op[4], hue_delta, pad, pad
+#define AUG_IP 20      // ints per output image:  src, x0, y0, flip, nops, op[4], hue_delta, table,
+                       //                         rotate?, a0..a5 (16.16 fixed point), pad, pad
 #define AUG_FP 4       // floats per output image: factor of op 0 (brightness), 1 (contrast), 2 (saturation), -
 
 __device__ __forceinline__ int aug_luma(int r, int g, int b) {
@@ -88,47 +95,70 @@ __device__ __forceinline__ void aug_hue(int& r, int& g, int& b, int delta) {
   }
 }
 
-template <bool INC_RGB>
+struct AugTabs {           // one entry per crop size: Pillow coefficient table of crop -> S
+  int crop[IIC_AUG_MAX_TABLES], ksize[IIC_AUG_MAX_TABLES], boff[IIC_AUG_MAX_TABLES], koff[IIC_AUG_MAX_TABLES];
+};
+
+template <int CH, bool INC_RGB>
 __global__ __launch_bounds__(256) void augment_kernel(
     const uint8_t* __restrict__ imgs, int H, int W, const int* __restrict__ iparams,
-    const float* __restrict__ fparams, const int* __restrict__ bounds, const int* __restrict__ kk,
-    int KS, int crop, int S, const float* __restrict__ lut, float* __restrict__ out) {
+    const float* __restrict__ fparams, const AugTabs tabs, const int* __restrict__ bounds,
+    const int* __restrict__ kk, int S, const float* __restrict__ lut, float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  uint8_t* sB = smem_raw;                       // [crop][S][3]  after the horizontal pass
-  uint8_t* sC = smem_raw + ((crop * S * 3 + 15) & ~15);   // [S][S][3]
   __shared__ int s_red[4];
   const int n = blockIdx.x, tid = threadIdx.x;
   const int* ip = iparams + (long)n * AUG_IP;
   const float* fp = fparams + (long)n * AUG_FP;
   const int src = ip[0], x0 = ip[1], y0 = ip[2], flip = ip[3], nops = ip[4], hdelta = ip[9];
-  const uint8_t* im = imgs + (long)src * H * W * 3;
+  const int tab = ip[10], rot = ip[11];
+  const int a0 = ip[12], a1 = ip[13], a2 = ip[14], a3 = ip[15], a4 = ip[16], a5 = ip[17];
+  const int crop = tabs.crop[tab], KS = tabs.ksize[tab];
+  const int* bnd = bounds + tabs.boff[tab] * 2;
+  const int* kt = kk + tabs.koff[tab];
+  uint8_t* sB = smem_raw;                                    // [crop][S][CH] after the horizontal pass
+  uint8_t* sC = smem_raw + ((crop * S * CH + 15) & ~15);     // [S][S][CH]
+  const uint8_t* im = imgs + (long)src * H * W * CH;
 
-  // ---- horizontal pass (global -> sB)
-  for (int idx = tid; idx < crop * S * 3; idx += 256) {
-    const int c = idx % 3, xo = (idx / 3) % S, y = idx / (3 * S);
-    const int xmin = bounds[xo * 2], cnt = bounds[xo * 2 + 1];
+  // ---- horizontal pass (global [-> rotation gather] -> sB)
+  for (int idx = tid; idx < crop * S * CH; idx += 256) {
+    const int c = idx % CH, xo = (idx / CH) % S, y = idx / (CH * S);
+    const int xmin = bnd[xo * 2], cnt = bnd[xo * 2 + 1];
     int ss = 1 << (AUG_PREC - 1);
-    const uint8_t* row = im + ((long)(y0 + y) * W + x0 + xmin) * 3 + c;
-    for (int k = 0; k < cnt; ++k) ss += (int)row[k * 3] * kk[xo * KS + k];
+    const int Y = y0 + y, X = x0 + xmin;
+    if (rot) {
+      int xx = a2 + a1 * Y + a0 * X, yy = a5 + a4 * Y + a3 * X;
+      for (int k = 0; k < cnt; ++k) {
+        const int xin = xx >> 16, yin = yy >> 16;
+        const int v = (xin >= 0 && xin < W && yin >= 0 && yin < H) ? (int)im[((long)yin * W + xin) * CH + c] : 0;
+        ss += v * kt[xo * KS + k];
+        xx += a0;
+        yy += a3;
+      }
+    } else {
+      const uint8_t* row = im + ((long)Y * W + X) * CH + c;
+      for (int k = 0; k < cnt; ++k) ss += (int)row[k * CH] * kt[xo * KS + k];
+    }
     sB[idx] = (uint8_t)aug_clip8(ss >> AUG_PREC);
   }
   __syncthreads();
   // ---- vertical pass (sB -> sC)
-  for (int idx = tid; idx < S * S * 3; idx += 256) {
-    const int c = idx % 3, xo = (idx / 3) % S, yo = idx / (3 * S);
-    const int ymin = bounds[yo * 2], cnt = bounds[yo * 2 + 1];
+  for (int idx = tid; idx < S * S * CH; idx += 256) {
+    const int c = idx % CH, xo = (idx / CH) % S, yo = idx / (CH * S);
+    const int ymin = bnd[yo * 2], cnt = bnd[yo * 2 + 1];
     int ss = 1 << (AUG_PREC - 1);
-    for (int k = 0; k < cnt; ++k) ss += (int)sB[((ymin + k) * S + xo) * 3 + c] * kk[yo * KS + k];
+    for (int k = 0; k < cnt; ++k) ss += (int)sB[((ymin + k) * S + xo) * CH + c] * kt[yo * KS + k];
     sC[idx] = (uint8_t)aug_clip8(ss >> AUG_PREC);
   }
   __syncthreads();
   // ---- ColorJitter ops in their shuffled order (pointwise on whole pixels, in place)
   for (int o = 0; o < nops; ++o) {
     const int op = ip[5 + o];
+    if (CH == 1 && op >= 2) continue;                // saturation / hue: identities on an L image
     int mean = 0;
     if (op == 1) {                                   // contrast: rounded mean of the L image
       int part = 0;
-      for (int px = tid; px < S * S; px += 256) part += aug_luma(sC[px * 3], sC[px * 3 + 1], sC[px * 3 + 2]);
+      for (int px = tid; px < S * S; px += 256)
+        part += CH == 1 ? (int)sC[px] : aug_luma(sC[px * 3], sC[px * 3 + 1], sC[px * 3 + 2]);
 #pragma unroll
       for (int sft = 32; sft > 0; sft >>= 1) part += __shfl_xor(part, sft, 64);
       if ((tid & 63) == 0) s_red[tid >> 6] = part;
@@ -139,6 +169,10 @@ __global__ __launch_bounds__(256) void augment_kernel(
     }
     const float alpha = op < 3 ? fp[op] : 0.f;
     for (int px = tid; px < S * S; px += 256) {
+      if (CH == 1) {
+        sC[px] = (uint8_t)aug_blend(op == 0 ? 0 : mean, sC[px], alpha);
+        continue;
+      }
       int r = sC[px * 3], g = sC[px * 3 + 1], b = sC[px * 3 + 2];
       if (op == 0) {
         r = aug_blend(0, r, alpha); g = aug_blend(0, g, alpha); b = aug_blend(0, b, alpha);
@@ -154,12 +188,16 @@ __global__ __launch_bounds__(256) void augment_kernel(
     }
     __syncthreads();
   }
-  // ---- custom_greyscale_to_tensor (+ the horizontal flip, which commutes with the ops above)
-  constexpr int C = INC_RGB ? 4 : 1;
+  // ---- custom_greyscale_to_tensor / ToTensor (+ the horizontal flip, which commutes with the ops above)
+  constexpr int C = CH == 1 ? 1 : (INC_RGB ? 4 : 1);
   float* on = out + (long)n * C * S * S;
   for (int px = tid; px < S * S; px += 256) {
     const int y = px / S, x = px - y * S;
-    const int sp = (y * S + (flip ? S - 1 - x : x)) * 3;
+    const int sp = (y * S + (flip ? S - 1 - x : x)) * CH;
+    if (CH == 1) {
+      on[px] = lut[sC[sp]];
+      continue;
+    }
     const int r = sC[sp], g = sC[sp + 1], b = sC[sp + 2];
     if (INC_RGB) {
       on[px] = lut[r];
@@ -172,19 +210,30 @@ __global__ __launch_bounds__(256) void augment_kernel(
 
 extern "C" {
 
-int iic_augment(const void* imgs_u8, int B, int H, int W, const int* iparams, const float* fparams,
-                int N, const int* bounds, const int* kk, int ksize, int crop, int S,
-                const float* lut, float* out, int include_rgb, void* stream) {
-  if (!imgs_u8 || !iparams || !fparams || !bounds || !kk || !lut || !out) return IIC_ERR_ARG;
-  if (B <= 0 || N <= 0 || crop <= 0 || crop > H || crop > W || S <= 0 || ksize <= 0) return IIC_ERR_ARG;
-  const size_t lds = ((size_t)(crop * S * 3 + 15) & ~(size_t)15) + (size_t)S * S * 3;
+int iic_augment(const void* imgs_u8, int B, int H, int W, int channels, const int* iparams,
+                const float* fparams, int N, const int* tables_host, int n_tables,
+                const int* bounds, const int* kk, int S, const float* lut, float* out,
+                int include_rgb, void* stream) {
+  if (!imgs_u8 || !iparams || !fparams || !tables_host || !bounds || !kk || !lut || !out) return IIC_ERR_ARG;
+  if (B <= 0 || N <= 0 || S <= 0 || H <= 0 || W <= 0) return IIC_ERR_ARG;
+  if (channels != 1 && channels != 3) return IIC_ERR_UNSUPPORTED;
+  if (n_tables < 1 || n_tables > IIC_AUG_MAX_TABLES) return IIC_ERR_ARG;
+  AugTabs tabs;
+  int max_crop = 0;
+  for (int t = 0; t < IIC_AUG_MAX_TABLES; ++t) {
+    const int* e = tables_host + 4 * (t < n_tables ? t : 0);
+    if (e[0] <= 0 || e[0] > H || e[0] > W || e[1] <= 0 || e[2] < 0 || e[3] < 0) return IIC_ERR_ARG;
+    tabs.crop[t] = e[0]; tabs.ksize[t] = e[1]; tabs.boff[t] = e[2]; tabs.koff[t] = e[3];
+    max_crop = e[0] > max_crop ? e[0] : max_crop;
+  }
+  const size_t lds = ((size_t)(max_crop * S * channels + 15) & ~(size_t)15) + (size_t)S * S * channels;
   if (lds > 150 * 1024) return IIC_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
-#define AUG_LAUNCH(RGB_)                                                                          \
+#define AUG_LAUNCH(CH_, RGB_)                                                                     \
   do {                                                                                           \
     static bool attr = false; /* one-time: raise the dynamic LDS limit (static s_red on top) */   \
     if (!attr) {                                                                                 \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&augment_kernel<RGB_>),              \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&augment_kernel<CH_, RGB_>),         \
                               hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) !=         \
           hipSuccess) {                                                                          \
         (void)hipGetLastError();                                                                 \
@@ -192,10 +241,13 @@ int iic_augment(const void* imgs_u8, int B, int H, int W, const int* iparams, co
       }                                                                                          \
       attr = true;                                                                               \
     }                                                                                            \
-    hipLaunchKernelGGL(augment_kernel<RGB_>, dim3(N), dim3(256), lds, s, (const uint8_t*)imgs_u8, \
-                       H, W, iparams, fparams, bounds, kk, ksize, crop, S, lut, out);            \
+    hipLaunchKernelGGL((augment_kernel<CH_, RGB_>), dim3(N), dim3(256), lds, s,                   \
+                       (const uint8_t*)imgs_u8, H, W, iparams, fparams, tabs, bounds, kk, S, lut, \
+                       out);                                                                     \
   } while (0)
-  if (include_rgb) AUG_LAUNCH(true); else AUG_LAUNCH(false);
+  if (channels == 1) AUG_LAUNCH(1, false);
+  else if (include_rgb) AUG_LAUNCH(3, true);
+  else AUG_LAUNCH(3, false);
   return iic_launch_status();
 }
 

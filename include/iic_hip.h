@@ -278,24 +278,34 @@ int iic_contingency(const long long* preds, const long long* targets, long n, in
 int iic_count_equal(const long long* a, const long long* b, long n, long long* count, void* stream);
 
 /* ---------------------------------------------------------------------------------
- * Paired augmentation on the GPU -- replaces the per-sample PIL pipeline
- * code/utils/cluster/transforms.py:107-217 (sobel_make_transforms, default branch: RandomCrop ->
- * Resize(BILINEAR) -> [RandomHorizontalFlip -> ColorJitter] -> custom_greyscale_to_tensor :12-25)
- * that the DataLoader workers of code/utils/cluster/data.py:223-290 run on the host.  Results are
- * bit-identical to PIL 's (oracle/augment_oracle.py).
- * imgs_u8  uint8 [B][H][W][3] (HWC, as the datasets hold them), resident in HBM.
- * iparams  int32 [N][12]: source image, crop x0, crop y0, flip, n_ops, op[4] (0 brightness,
- *          1 contrast, 2 saturation, 3 hue -- in application order), hue shift (int8 wrap), 0, 0.
+ * Paired augmentation on the GPU -- replaces the per-sample PIL pipelines
+ * of code/utils/cluster/transforms.py that the DataLoaders of code/utils/cluster/data.py:223-335
+ * run on the host:
+ *   :107-217 sobel_make_transforms, default branch (RGB sources, channels = 3): RandomCrop ->
+ *            Resize(BILINEAR) -> [RandomHorizontalFlip -> ColorJitter] -> custom_greyscale_to_tensor (:12-25)
+ *   :220-330 greyscale_make_transforms (mode "L" sources, channels = 1): [RandomRotation] ->
+ *            crop (one of several sizes) -> Resize -> [flip] -> [ColorJitter] -> ToTensor
+ * Results are bit-identical to PIL's (oracle/augment_oracle.py).
+ * imgs_u8  uint8 [B][H][W][channels] (HWC, as the datasets hold them), resident in HBM.
+ * iparams  int32 [N][20]: source image, crop x0, crop y0, flip, n_ops, op[4] (0 brightness,
+ *          1 contrast, 2 saturation, 3 hue -- in application order), hue shift (uint8 wrap),
+ *          table index, rotate flag, a0..a5 = PIL's inverse rotation matrix in 16.16 fixed point
+ *          (source x = (a2 + a1*y + a0*x) >> 16, source y = (a5 + a4*y + a3*x) >> 16), 0, 0.
  * fparams  float [N][4]: factor of brightness, contrast, saturation; [3] = hue factor (not read:
  *          the kernel uses the uint8 increment in iparams[9]).
- * bounds   int32 [S][2] (first tap, tap count), kk int32 [S][ksize]: Pillow's 22-bit resampling
- *          coefficients for crop -> S (square crops: both passes use the same table).
+ * tables_host  HOST int32 [n_tables][4] = (crop size, taps per output = row pitch of its kk table,
+ *          first row of its bounds table, first int of its kk table), n_tables <= 8;
+ * bounds   int32 [rows][2] (first tap, tap count), kk int32: Pillow's 22-bit resampling
+ *          coefficients of crop -> S per table (square crops: both passes use the same table).
  * lut      float [256] = v / 255 as torch computes it.
- * out      float [N][C][S][S], C = 4 (R,G,B,grey) with include_rgb else 1 (grey).
+ * out      float [N][C][S][S]; channels 3: C = 4 (R,G,B,grey) with include_rgb else 1 (grey);
+ *          channels 1: C = 1.
  * ------------------------------------------------------------------------------- */
-int iic_augment(const void* imgs_u8, int B, int H, int W, const int* iparams, const float* fparams,
-                int N, const int* bounds, const int* kk, int ksize, int crop, int S,
-                const float* lut, float* out, int include_rgb, void* stream);
+#define IIC_AUG_MAX_TABLES 8
+int iic_augment(const void* imgs_u8, int B, int H, int W, int channels, const int* iparams,
+                const float* fparams, int N, const int* tables_host, int n_tables,
+                const int* bounds, const int* kk, int S, const float* lut, float* out,
+                int include_rgb, void* stream);
 
 #ifdef __cplusplus
 }

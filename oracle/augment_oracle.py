@@ -7,6 +7,13 @@ augmentation for the clustering scripts, /root/reference/code/utils/cluster/tran
        ColorJitter(0.4, 0.4, 0.4, 0.125) -> custom_greyscale_to_tensor(include_rgb)
   tf3: CenterCrop(rand_crop_sz) -> Resize(input_sz) -> custom_greyscale_to_tensor(include_rgb)
 
+and of `greyscale_make_transforms` (transforms.py:220-330; the MNIST scripts, mode "L" images):
+
+  tf1: {RandomCrop | CenterCrop | RandomChoice of both}(tf1_crop_sz) -> Resize(input_sz) -> ToTensor
+  tf2: [RandomApply(RandomRotation(rot_val), 0.5)] -> RandomChoice(RandomCrop(sz) for sz in
+       tf2_crop_szs) -> Resize -> [RandomHorizontalFlip] -> [ColorJitter] -> ToTensor
+  tf3: CenterCrop -> Resize -> ToTensor
+
 The reference composes torchvision 0.2.1 transforms (package_versions.txt), which are thin
 wrappers over PIL.  torchvision is absent here; its functional ops are restated below on PIL
 itself (present: the arithmetic that matters -- bilinear resampling, ImageEnhance blends, the
@@ -45,11 +52,16 @@ def hue_delta(hue_factor):
   return int(hue_factor * 255) % 256
 
 
-def pil_pipeline(img_u8, crop_xy, crop_sz, out_sz, include_rgb, flip=False, order=(), factors=None):
-  """img_u8: HWC uint8 RGB.  order: sequence of OP_* (the shuffled ColorJitter order);
-  factors: dict op -> factor (brightness / contrast / saturation factors, hue_factor).
-  Returns float32 [C, out_sz, out_sz] like custom_greyscale_to_tensor."""
+def pil_pipeline(img_u8, crop_xy, crop_sz, out_sz, include_rgb, flip=False, order=(), factors=None,
+                 angle=None):
+  """img_u8: HWC uint8 RGB (sobel pipelines) or HW uint8 (mode "L", greyscale pipelines).
+  order: sequence of OP_* (the shuffled ColorJitter order); factors: dict op -> factor
+  (brightness / contrast / saturation factors, hue_factor); angle: RandomRotation's draw in degrees
+  (F.rotate(img, angle, resample=False, expand=False, center=None)) or None.
+  Returns float32 [C, out_sz, out_sz]: custom_greyscale_to_tensor for RGB input, ToTensor for L."""
   img = Image.fromarray(img_u8)
+  if angle is not None:
+    img = img.rotate(angle, Image.NEAREST, False, None)                     # F.rotate
   x0, y0 = crop_xy
   img = img.crop((x0, y0, x0 + crop_sz, y0 + crop_sz))                     # F.crop
   img = img.resize((out_sz, out_sz), Image.BILINEAR)                       # F.resize
@@ -63,13 +75,20 @@ def pil_pipeline(img_u8, crop_xy, crop_sz, out_sz, include_rgb, flip=False, orde
       img = ImageEnhance.Contrast(img).enhance(f)
     elif op == OP_SATURATION:
       img = ImageEnhance.Color(img).enhance(f)
-    else:
+    elif img.mode != "L":                  # adjust_hue returns mode L / 1 / I / F images unchanged
       img = tv_adjust_hue(img, f)
+  if img.mode == "L":                                                       # ToTensor
+    return (np.asarray(img).astype(np.float32) / np.float32(255))[None]
   grey = np.asarray(img.convert("L")).astype(np.float32) / np.float32(255)  # to_tensor: .float().div(255)
   if not include_rgb:
     return grey[None]
   rgb = np.transpose(np.asarray(img).astype(np.float32) / np.float32(255), (2, 0, 1))
   return np.concatenate([rgb, grey[None]], 0)
+
+
+def center_crop_xy(w, h, crop_sz):
+  """torchvision 0.2.1 F.center_crop: i = int(round((h - th) / 2.)), j = int(round((w - tw) / 2.))."""
+  return int(round((w - crop_sz) / 2.)), int(round((h - crop_sz) / 2.))
 
 
 # ------------------------------------------------------------------------------------------
@@ -173,9 +192,43 @@ def np_hsv2rgb(a):
   return np.stack([np.where(s0, V, R), np.where(s0, V, G), np.where(s0, V, B)], -1)
 
 
-def np_pipeline(img_u8, crop_xy, crop_sz, out_sz, include_rgb, flip=False, order=(), factors=None):
+def rotation_coeffs(angle, w, h):
+  """PIL Image.rotate's inverse affine matrix (python doubles, cos / sin rounded to 15 digits,
+  centre (w/2, h/2)) and ImagingTransformAffine's 16.16 fixed-point form of it (nearest filter):
+  source x = (a2 + a1*y + a0*x) >> 16, source y = (a5 + a4*y + a3*x) >> 16."""
+  a = -math.radians(angle % 360.0)
+  m = [round(math.cos(a), 15), round(math.sin(a), 15), 0.0, round(-math.sin(a), 15), round(math.cos(a), 15), 0.0]
+  cx, cy = w / 2, h / 2
+  m[2] = m[0] * (-cx) + m[1] * (-cy) + m[2] + cx
+  m[5] = m[3] * (-cx) + m[4] * (-cy) + m[5] + cy
+
+  def fix(v):
+    return int(math.floor(v * 65536.0 + 0.5))
+  return (fix(m[0]), fix(m[1]), fix(m[2] + m[0] * 0.5 + m[1] * 0.5),
+          fix(m[3]), fix(m[4]), fix(m[5] + m[3] * 0.5 + m[4] * 0.5))
+
+
+def np_rotate(a, angle):
+  if angle % 360.0 == 0:
+    return a                                                 # PIL fast path: a copy
+  h, w = a.shape[:2]
+  a0, a1, a2, a3, a4, a5 = rotation_coeffs(angle, w, h)
+  y, x = np.mgrid[0:h, 0:w]
+  xin, yin = (a2 + a1 * y + a0 * x) >> 16, (a5 + a4 * y + a3 * x) >> 16
+  ok = (xin >= 0) & (xin < w) & (yin >= 0) & (yin < h)
+  out = np.zeros_like(a)
+  out[ok] = a[yin[ok], xin[ok]]
+  return out
+
+
+def np_pipeline(img_u8, crop_xy, crop_sz, out_sz, include_rgb, flip=False, order=(), factors=None,
+                angle=None):
   x0, y0 = crop_xy
-  a = np_resize(img_u8[y0:y0 + crop_sz, x0:x0 + crop_sz].astype(np.int64), out_sz)
+  grey_in = img_u8.ndim == 2
+  a = img_u8[..., None] if grey_in else img_u8
+  if angle is not None:
+    a = np_rotate(a, angle)
+  a = np_resize(a[y0:y0 + crop_sz, x0:x0 + crop_sz].astype(np.int64), out_sz)
   if flip:
     a = a[:, ::-1]
   for op in order:
@@ -183,9 +236,11 @@ def np_pipeline(img_u8, crop_xy, crop_sz, out_sz, include_rgb, flip=False, order
     if op == OP_BRIGHTNESS:
       a = np_blend(np.zeros_like(a), a, f)
     elif op == OP_CONTRAST:
-      L = np_luma(a)
+      L = a[..., 0] if grey_in else np_luma(a)
       mean = int(float(L.sum()) / float(L.size) + 0.5)      # int(ImageStat.Stat(L).mean[0] + 0.5)
       a = np_blend(np.full_like(a, mean), a, f)
+    elif grey_in:
+      pass       # mode L: Color's degenerate is the image itself (blend = identity), hue is skipped
     elif op == OP_SATURATION:
       L = np_luma(a)
       a = np_blend(np.repeat(L[..., None], 3, -1), a, f)
@@ -194,6 +249,8 @@ def np_pipeline(img_u8, crop_xy, crop_sz, out_sz, include_rgb, flip=False, order
       hsv[..., 0] = (hsv[..., 0] + hue_delta(f)) % 256
       a = np_hsv2rgb(hsv)
   lut = np.arange(256, dtype=np.float32) / np.float32(255)
+  if grey_in:
+    return lut[a[..., 0]][None]
   grey = lut[np_luma(a)]
   if not include_rgb:
     return grey[None]

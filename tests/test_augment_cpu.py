@@ -105,3 +105,56 @@ def test_paired_dataloaders_order_and_lengths():
     seen += n
   assert seen == 10
   assert [c[0] for c in aug.calls[:3]] == ["plain", "jit", "jit"]
+
+
+def test_greyscale_spec_matches_pil_with_rotation():
+  """Mode-L pipeline of greyscale_make_transforms (transforms.py:220-330): PIL rotate (NEAREST
+  fixed-point affine) -> crop (16 / 20 / 24) -> resize 24 -> flip -> jitter -> ToTensor."""
+  rng = np.random.default_rng(3)
+  bad = 0
+  for t in range(90):
+    img = rng.integers(0, 256, (28, 28), dtype=np.uint8)
+    if t % 3 == 0:
+      img = ((img > 128) * 255).astype(np.uint8)
+    crop = [16, 20, 24][t % 3]
+    p = ao.random_params(rng, 1, (28, 28), crop)[0]
+    ang = float(rng.uniform(-25, 25)) if t % 2 else (None if t % 4 else float(rng.uniform(-180, 180)))
+    a = ao.pil_pipeline(img, p["crop_xy"], crop, 24, False, p["flip"], p["order"], p["factors"], angle=ang)
+    b = ao.np_pipeline(img, p["crop_xy"], crop, 24, False, p["flip"], p["order"], p["factors"], angle=ang)
+    assert a.shape == b.shape == (1, 24, 24)
+    bad += int(not np.array_equal(a, b))
+  assert bad == 0
+
+
+def test_greyscale_draws_follow_the_reference_flags():
+  """Host-side parameter draws of GreyscaleAugmenter for the MNIST command (commands.txt:30):
+  RandomApply(rotation, 0.5), RandomChoice over crop sizes, centre_half tf1, no flip."""
+  import types
+  import torch
+  from iic_amd.augment import GreyscaleAugmenter, rotation_fixed_point
+  cfg = types.SimpleNamespace(crop_orig=True, tf1_crop="centre_half", tf1_crop_sz=20, tf3_crop_diff=False,
+                              tf3_crop_sz=0, rot_val=25, always_rot=False, crop_other=True, tf2_crop="random",
+                              tf2_crop_szs=[16, 20, 24], input_sz=24, no_flip=True, no_jitter=False,
+                              demean=False, per_img_demean=False)
+  aug = GreyscaleAugmenter(torch.zeros(10, 28, 28, dtype=torch.uint8), cfg, seed=0)
+  assert aug.crop_szs == [20, 16, 24]
+  idx = np.arange(2000) % 10
+  ip, fp = aug.draw(idx, "jittered")
+  crop = np.asarray(aug.crop_szs)[ip[:, 10]]
+  assert (ip[:, 1] >= 0).all() and (ip[:, 1] + crop <= 28).all() and (ip[:, 2] + crop <= 28).all()
+  assert 0.4 < ip[:, 11].mean() < 0.6 and (ip[:, 3] == 0).all() and (ip[:, 4] == 4).all()
+  assert all(abs((ip[:, 10] == t).mean() - 1 / 3) < 0.05 for t in range(3))
+  assert (np.sort(ip[:, 5:9], 1) == np.arange(4)).all()
+  assert fp[:, :3].min() >= 0.6 - 1e-6 and fp[:, :3].max() <= 1.4 + 1e-6
+  rot = np.nonzero(ip[:, 11])[0]
+  assert np.abs(aug.last_angles[rot]).max() <= 25 and np.isnan(aug.last_angles[ip[:, 11] == 0]).all()
+  i = int(rot[0])
+  assert tuple(ip[i, 12:18]) == ao.rotation_coeffs(float(aug.last_angles[i]), 28, 28) \
+      == rotation_fixed_point(float(aug.last_angles[i]), 28, 28)
+  ip1, _ = aug.draw(idx, "plain")                    # centre_half: half the crops at the centre (4, 4)
+  centred = ((ip1[:, 1] == 4) & (ip1[:, 2] == 4)).mean()
+  assert 0.45 < centred < 0.6 and (ip1[:, 10] == 0).all() and (ip1[:, 4] == 0).all()
+  ip3, _ = aug.draw(idx, "center")
+  assert (ip3[:, 1] == 4).all() and (ip3[:, 2] == 4).all()
+  with __import__("pytest").raises(AssertionError):
+    aug.apply(ip3, np.zeros((2000, 4), np.float32))  # CPU dataset: there is no CPU path

@@ -25,15 +25,17 @@ def _dataset(rng, B, H):
   return imgs
 
 
-def _oracle(imgs, ip, fp, crop, S, include_rgb):
+def _oracle(imgs, ip, fp, crop, S, include_rgb, angles=None):
   out = []
   for i in range(ip.shape[0]):
+    ang = None if angles is None or np.isnan(angles[i]) else float(angles[i])
+    c = crop[ip[i, 10]] if isinstance(crop, (list, tuple)) else crop
     order = [int(o) for o in ip[i, 5:5 + ip[i, 4]]]
     factors = {ao.OP_BRIGHTNESS: float(fp[i, 0]), ao.OP_CONTRAST: float(fp[i, 1]),
                ao.OP_SATURATION: float(fp[i, 2]), ao.OP_HUE: float(fp[i, 3])}
     assert ao.hue_delta(float(fp[i, 3])) == ip[i, 9]
-    a = ao.pil_pipeline(imgs[ip[i, 0]], (int(ip[i, 1]), int(ip[i, 2])), crop, S, include_rgb,
-                        bool(ip[i, 3]), order, factors)
+    a = ao.pil_pipeline(imgs[ip[i, 0]], (int(ip[i, 1]), int(ip[i, 2])), c, S, include_rgb,
+                        bool(ip[i, 3]), order, factors, angle=ang)
     out.append(a)
   return np.stack(out)
 
@@ -68,7 +70,7 @@ def test_augment_single_ops_and_extremes():
     for op, vals in ((0, (0.6, 1.0, 1.4)), (1, (0.6, 1.0, 1.4)), (2, (0.0, 0.6, 1.4)),
                      (3, (-0.5, -0.125, -0.004, 0.0, 0.004, 0.125, 0.5))):
       for v in vals:
-        ip = np.zeros(12, np.int32)
+        ip = np.zeros(20, np.int32)
         fp = np.zeros(4, np.float32)
         ip[[0, 1, 2, 3, 4, 5]] = (src, 3, 5, src & 1, 1, op)
         fp[op] = v
@@ -110,7 +112,7 @@ def test_augment_all_colours_exhaustive():
   aug = PairedAugmenter(torch.from_numpy(imgs).cuda(), 64, 64, True)
   rng = np.random.default_rng(1)
   for op in (3, 2, 0, 1):
-    ip = np.zeros((4096, 12), np.int32)
+    ip = np.zeros((4096, 20), np.int32)
     fp = np.zeros((4096, 4), np.float32)
     ip[:, 0] = np.arange(4096)
     ip[:, 4] = 1
@@ -122,3 +124,42 @@ def test_augment_all_colours_exhaustive():
     want = _oracle(imgs, ip, fp, 64, 64, True)
     bad = [i for i in range(4096) if not np.array_equal(got[i], want[i])]
     assert not bad, (op, len(bad), bad[:3])
+
+
+def _mnist_cfg(**kw):
+  import types
+  cfg = dict(crop_orig=True, tf1_crop="centre_half", tf1_crop_sz=20, tf3_crop_diff=False, tf3_crop_sz=0,
+             rot_val=25, always_rot=False, crop_other=True, tf2_crop="random", tf2_crop_szs=[16, 20, 24],
+             input_sz=24, no_flip=True, no_jitter=False, demean=False, per_img_demean=False)
+  cfg.update(kw)
+  return types.SimpleNamespace(**cfg)
+
+
+@pytest.mark.parametrize("variant", ["mnist685", "always_rot_flip", "no_crop_no_jitter"])
+def test_greyscale_pipeline_bit_exact_vs_pil(variant):
+  """greyscale_make_transforms (transforms.py:220-330) with the MNIST command's flags
+  (examples/commands.txt:30) and two other flag sets: rotation (PIL NEAREST affine), per-sample crop
+  size, resize, jitter on mode-L images, ToTensor."""
+  from iic_amd.augment import GreyscaleAugmenter
+  rng = np.random.default_rng(7)
+  imgs = rng.integers(0, 256, (16, 28, 28), dtype=np.uint8)
+  imgs[1] = (imgs[1] > 128) * 255                 # digit-like: saturated strokes on black
+  imgs[2] = 0
+  imgs[3] = 255
+  cfg = {"mnist685": _mnist_cfg(),
+         "always_rot_flip": _mnist_cfg(always_rot=True, no_flip=False, tf1_crop="random", tf2_crop="centre_half",
+                                       tf3_crop_diff=True, tf3_crop_sz=24, rot_val=180),
+         "no_crop_no_jitter": _mnist_cfg(crop_orig=False, crop_other=False, no_jitter=True, input_sz=32)}[variant]
+  aug = GreyscaleAugmenter(torch.from_numpy(imgs).cuda(), cfg, seed=11)
+  idx = rng.integers(0, 16, 96)
+  for mode in ("jittered", "plain", "center"):
+    ip, fp = aug.draw(idx, mode)
+    got = aug.apply(ip, fp).cpu().numpy()
+    want = _oracle(imgs, ip, fp, aug.crop_szs, cfg.input_sz, False,
+                   aug.last_angles if mode == "jittered" else None)
+    assert got.shape == want.shape == (96, 1, cfg.input_sz, cfg.input_sz)
+    bad = [i for i in range(len(idx)) if not np.array_equal(got[i], want[i])]
+    assert not bad, (variant, mode, bad[:5], ip[bad[0]])
+    if mode == "jittered" and variant == "mnist685":
+      assert 20 < int(ip[:, 11].sum()) < 76            # RandomApply(p=0.5)
+      assert set(np.unique(ip[:, 10])) == {0, 1, 2}   # all three crop sizes drawn
