@@ -465,6 +465,58 @@ def test_bn_forward_backward_kernels():
   assert torch.equal(dy_a, dy_m)
 
 
+@pytest.mark.parametrize("N,H,W,P,C", [(5, 49, 49, 1, 64), (7, 25, 25, 1, 128), (9, 13, 13, 1, 256),
+                                       (11, 7, 7, 1, 512), (3, 3, 5, 2, 512), (2, 20, 36, 2, 64),
+                                       (1, 1, 1, 1, 64)])
+def test_bn_backward_kernel_generations_agree(N, H, W, P, C):
+  """Second-generation backward passes (pixel walkers, coefficients in registers) against the first:
+  bn_bwd_apply is the same expression per element => bit-identical; bn_bwd_reduce sums in another
+  order => fp32 summation noise only.  All mask modes, with and without the shared downsample BN;
+  borders must stay untouched."""
+  import ctypes
+  from iic_amd import ops, _lib
+  L = ctypes.CDLL(_lib.LIB_PATH)
+  d = dev()
+  g = torch.Generator().manual_seed(N * 1000 + C)
+  shape = (N, H + 2 * P, W + 2 * P, C)
+
+  def pt(scale=1.0):
+    t = torch.zeros(shape, dtype=torch.bfloat16)
+    t[:, P:P + H, P:P + W] = (torch.randn(N, H, W, C, generator=g) * scale).to(torch.bfloat16)
+    return t.to(d)
+  dout, y, y2 = pt(), pt(1.5), pt()
+  act = torch.relu(pt())
+  coef = (torch.randn(4, C, generator=g) * 0.5).to(d)
+  bcoef = torch.randn(3, C, generator=g).to(d)
+  bcoef2 = torch.randn(3, C, generator=g).to(d)
+  try:
+    for mode in ("none", "act", "from_y"):
+      for has2 in (False, True):
+        a = act if mode == "act" else None
+        mc = coef if mode == "from_y" else None
+        res = {}
+        for gen in (0, 2):                       # 2 = second generation for every mask mode
+          L.iic_debug_bn_v2(gen, 0)
+          s1, s2 = ops.new_stats(C, d), ops.new_stats(C, d)
+          ops.bn_bwd_reduce(dout, a, y, s1, N, H, W, P, C, y2=y2 if has2 else None,
+                            sums2=s2 if has2 else None, mask_coef=mc)
+          dy = torch.full(shape, 7.0, dtype=torch.bfloat16, device=d)
+          dy2 = torch.full(shape, 7.0, dtype=torch.bfloat16, device=d)
+          ops.bn_bwd_apply(dout, a, y, bcoef, dy, N, H, W, P, C, y2=y2 if has2 else None,
+                           bcoef2=bcoef2 if has2 else None, dy2=dy2 if has2 else None, mask_coef=mc)
+          torch.cuda.synchronize()
+          res[gen] = (s1.sum(0), s2.sum(0), dy, dy2)
+        for k in (0, 1):
+          ref, got = res[0][k], res[2][k]
+          assert (ref - got).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item()) , (mode, has2, k)
+        assert torch.equal(res[0][2], res[2][2]) and torch.equal(res[0][3], res[2][3]), (mode, has2)
+        border = res[2][2].clone()
+        border[:, P:P + H, P:P + W] = 7.0
+        assert (border == 7.0).all()              # only interior pixels are written
+  finally:
+    L.iic_debug_bn_v2(1, 0)
+
+
 # --------------------------------------------------------------------------------------
 # sobel + stem
 # --------------------------------------------------------------------------------------
