@@ -1,6 +1,6 @@
 """Yardstick (NOT the product path): the reference-equivalent train step through stock
 PyTorch-ROCm / MIOpen on the same MI355X -- the oracle restatement of ClusterNet5g + IID_loss
-moved to the GPU, fp32 and bf16-autocast channels_last.  python tools/torch_gpu_baseline.py"""
+moved to the GPU, fp32 and bf16-autocast channels_last.  python oracle/torch_gpu_yardstick.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
