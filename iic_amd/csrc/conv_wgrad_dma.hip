@@ -290,7 +290,7 @@ static long wd_lds(int np, int cot, int bmk, int nbuf) {
   return nbuf * (wd_xb_bytes(np) + (long)bmk * cot * 2) + WD_TAB_BYTES(bmk) + 64;
 }
 
-static int g_wd_enabled = 1;     // 0: register-staged kernel, 1: DMA kernel, 3: force 64-pixel K-tiles, 4: never 3 x 128-pixel buffers
+static int g_wd_enabled = 1;     // 0: register-staged kernel, 1: DMA kernel, 3: force 64-pixel K-tiles
 extern "C" void iic_debug_enable_wgrad_dma(int v) { g_wd_enabled = v; }
 
 // K-tile size / ring depth.  Measured at the ClusterNet5g shapes (tools/conv_perf.py): 128-pixel
@@ -304,9 +304,7 @@ static int wd_config(const iic_conv_geom* g, int* bmk, int* nbuf) {
   const int cot = (g->Cout % 128 == 0) ? 128 : 64;
   if (g_wd_enabled != 3 && wd_lds(g->NP, cot, 128, 2) <= 160 * 1024) {
     *bmk = 128;
-    // a third buffer where it fits (64-cout layers): two K-tiles of prefetch, 201 -> 191 us at
-    // layer1 (g_wd_enabled = 4 keeps two buffers there: tests / A-B)
-    *nbuf = (g_wd_enabled != 4 && cot == 64 && wd_lds(g->NP, cot, 128, 3) <= 160 * 1024) ? 3 : 2;
+    *nbuf = 2;
     return 1;
   }
   if (g->NP64 > 0) {
@@ -357,8 +355,6 @@ int iic_wgrad_dma_launch(const iic_conv_geom* g, const void* x, const void* dy, 
     if (cot == 128) WD_LAUNCH(128, 64, 4); else WD_LAUNCH(64, 64, 4);
   } else if (bmk == 64) {
     if (cot == 128) WD_LAUNCH(128, 64, 3); else WD_LAUNCH(64, 64, 3);
-  } else if (nbuf == 3) {
-    WD_LAUNCH(64, 128, 3);
   } else {
     if (cot == 128) WD_LAUNCH(128, 128, 2); else WD_LAUNCH(64, 128, 2);
   }

@@ -348,13 +348,12 @@ def _wgrad_dma(mode):
   ctypes.CDLL(_lib.LIB_PATH).iic_debug_enable_wgrad_dma(int(mode))
 
 
-@pytest.mark.parametrize("dma", [1, 3, 4, 0])
+@pytest.mark.parametrize("dma", [1, 3, 0])
 @pytest.mark.parametrize("case,nsplit", [((64, 64, 3, 1, 1, 2, 49), 2), ((128, 128, 3, 1, 1, 20, 25), 3),
                                          ((512, 512, 3, 1, 1, 6, 7), 1), ((64, 64, 3, 1, 1, 5, 13), 1)])
 def test_conv_backward_weight_long_k_ranges(case, nsplit, dma):
   """Few splits => every workgroup walks many K-tiles: the LDS-DMA ring of conv_wgrad_dma.hip
-  (dma=1: 128-pixel tiles, 3 buffers at 64 couts else 2; dma=4: always 2; dma=3: 64-pixel tiles,
-  3-4 buffers) and the register-staged
+  (dma=1: 128-pixel tiles, 2 buffers; dma=3: 64-pixel tiles, 3-4 buffers) and the register-staged
   pipeline of conv_wgrad.hip (dma=0)."""
   _wgrad_dma(dma)
   try:

@@ -91,10 +91,8 @@ def main():
       L = ctypes.CDLL(_lib.LIB_PATH)
       L.iic_debug_enable_wgrad_dma(3)     # 64-pixel K-tiles, 3-4 buffers
       t_w0 = timeit(lambda: ops.conv_wgrad(gf, x, dy, K * K, True), a.iters)
-      L.iic_debug_enable_wgrad_dma(4)     # 128-pixel K-tiles, never a third buffer
-      t_w5 = timeit(lambda: ops.conv_wgrad(gf, x, dy, K * K, True), a.iters)
       L.iic_debug_enable_wgrad_dma(1)
-    extra = "" if a.no_wgrad else " | wgrad(dma 64-px ring) %7.1f us | (128-px, 2 buffers) %7.1f us" % (t_w0, t_w5)
+    extra = "" if a.no_wgrad else " | wgrad(dma 64-px ring) %7.1f us" % t_w0
     if a.frag:
       if ops.frag_supported(gf):
         t2 = timeit(lambda: ops.conv_igemm(gf, x, pw[0], y, stats=st), a.iters)
