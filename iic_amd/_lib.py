@@ -76,7 +76,7 @@ _SIGNATURES = {
   "iic_maxpool2_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
   "iic_sobel": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
   "iic_avgpool_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
-  "iic_avgpool_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+  "iic_avgpool_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
   "iic_gemm_f32": (c_int, [_P, c_long, c_long, _P, c_long, c_long, _P, _P, c_long, c_int, c_int, c_int, c_int, _P]),
   "iic_gemm_f32_splitk": (c_int, [_P, c_long, c_long, _P, c_long, c_long, _P, c_long, c_int, c_int, c_int, c_int, _P]),
   "iic_seg_window_gather": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),

@@ -57,6 +57,16 @@ SHARD_INPUTS = [False]  # set by iic_amd.run under torchrun: forward keeps only 
 # running_var factor uses the true batch size.  Removes 1/3 of view 1's conv work at r = 3.
 # NOT used by bench.py (it would change the FLOP accounting of the metric).
 DEDUP = [int(os.environ.get("IIC_DEDUP", "1"))]
+# Pre-masked gradient chain through the residual trunk (IIC_PREMASK=0 disables it).  Every block
+# hands its input gradient over already multiplied by the ReLU mask of that input (the conv
+# backward-data epilogue applies it: IIC_ACC_PREMASK), and the average-pool backward does the same
+# for the last block.  A block's gradient g = dout * (out > 0) then arrives ready-made: its second
+# BatchNorm backward (reduce + apply) and the residual-gradient fusion no longer read `out` -- two
+# full-tensor reads less per block and view, same values bit for bit (masking commutes with the
+# bf16 rounding of the stored gradient).  Only valid where a block output has exactly one
+# consumer, i.e. the trunk's own sequential forward; standalone blocks keep masking themselves.
+PREMASK = [os.environ.get("IIC_PREMASK", "1") != "0"]
+
 _WEIGHTS_EPOCH = [0]   # bumped by iic_amd.optim.Adam (raw-pointer updates do not bump _version)
 
 
@@ -221,6 +231,8 @@ class _BlockFn(torch.autograd.Function):
       ctx.blk = blk
       ctx.dims = (N, H, W, Ho, Wo, Cin, planes)
       ctx.bn_batch = (_bn_training(blk.bn1) and _bn_training(blk.bn2))
+      # (set by the trunk for the duration of its sequential forward, see PREMASK)
+      ctx.dout_premasked, ctx.mask_dx = blk._dout_premasked, blk._mask_dx
       ctx.save_for_backward(x, y1, a1, y2, out, yd, coef1, coef2, coefd, g1, g2, gd)
     else:
       for t in (y1, a1, y2, yd):
@@ -242,17 +254,20 @@ class _BlockFn(torch.autograd.Function):
     gf1, gb1 = h1.geoms(N, H, W)
     gf2, gb2 = h2.geoms(N, Ho, Wo)
 
-    # ---- bn2 (+ downsample bn) backward; g = dout * (out > 0)
+    # ---- bn2 (+ downsample bn) backward; g = dout * (out > 0), or dout itself when the consumer
+    # of `out` already applied that mask (PREMASK)
+    pre, mask_dx = ctx.dout_premasked, ctx.mask_dx
+    m_out = None if pre else out
     s2 = h2.stats(dev, "bwd")
     sd = hd.stats(dev, "bwd") if hd is not None else None
-    ops.bn_bwd_reduce(dout, out, y2, s2, N, Ho, Wo, 1, planes, y2=yd, sums2=sd)
+    ops.bn_bwd_reduce(dout, m_out, y2, s2, N, Ho, Wo, 1, planes, y2=yd, sums2=sd)
     bc2, dg2, db2 = ops.bn_bwd_finalize(s2, g2.detach(), coef2, planes, cnt)
     dy2 = ops.pt_alloc(N, Ho, Wo, planes, 1, dev)
     bcd = dgd = dbd = dyd = None
     if hd is not None:
       bcd, dgd, dbd = ops.bn_bwd_finalize(sd, gd.detach(), coefd, planes, cnt)
       dyd = ops.pt_alloc(N, Ho, Wo, planes, 1, dev)
-    ops.bn_bwd_apply(dout, out, y2, bc2, dy2, N, Ho, Wo, 1, planes, y2=yd, bcoef2=bcd, dy2=dyd)
+    ops.bn_bwd_apply(dout, m_out, y2, bc2, dy2, N, Ho, Wo, 1, planes, y2=yd, bcoef2=bcd, dy2=dyd)
 
     dual = DUAL_STREAM[0]
     main = torch.cuda.current_stream()
@@ -290,15 +305,21 @@ class _BlockFn(torch.autograd.Function):
     # ---- conv1 backward: weight grad (side) || data grad (+ residual / downsample gradient)
     dW1 = on_side(lambda: ops.conv_wgrad(gf1, x, dy1, 9, use_tr)).view(planes, Cin, 3, 3)
     dx = ops.pt_alloc(N, H, W, Cin, 1, dev)
+    # dx = bwd-data(conv1) + identity-branch gradient [, times the ReLU mask of x: mask_dx]
+    mx = x if mask_dx else None
     if hd is None:
       for g in gb1:
-        ops.conv_igemm(g, dy1, h1.weights()[1], dx, res_grad=dout, res_act=out)
+        if pre or mask_dx:
+          assert pre, "a block that pre-masks its input gradient needs a pre-masked output gradient"
+          ops.conv_igemm(g, dy1, h1.weights()[1], dx, res_grad=dout, res_act=mx, premask=True)
+        else:
+          ops.conv_igemm(g, dy1, h1.weights()[1], dx, res_grad=dout, res_act=out)
     else:
       for g in gb1:
-        ops.conv_igemm(g, dy1, h1.weights()[1], dx)
+        ops.conv_igemm(g, dy1, h1.weights()[1], dx, res_act=mx, premask=mask_dx)
       _, gbd = hd.geoms(N, H, W)
-      for g in gbd:
-        ops.conv_igemm(g, dyd, hd.weights()[1], dx, accumulate=True)
+      for g in gbd:      # (the mask is idempotent: pixels this launch adds to are masked again)
+        ops.conv_igemm(g, dyd, hd.weights()[1], dx, accumulate=True, res_act=mx, premask=mask_dx)
     if dual:   # buffers below are recycled on the main stream: the side stream must be done
       main.wait_event(side.record_event())
 
@@ -323,6 +344,8 @@ class BasicBlock(nn.Module):
     self._h2 = _ConvHolder(self.conv2)
     self._hd = _ConvHolder(downsample[0]) if downsample is not None else None
     self._use_tr = True
+    self._dout_premasked = False      # see PREMASK; only the trunk's forward turns these on
+    self._mask_dx = False
 
   def forward(self, x):
     ds = self.downsample
@@ -337,16 +360,20 @@ class BasicBlock(nn.Module):
 # ------------------------------------------------------------------------------------
 class _AvgPoolFn(torch.autograd.Function):
   @staticmethod
-  def forward(ctx, x):
+  def forward(ctx, x, premask):
     N, Hp, Wp, C = x.shape
     ctx.dims = (N, Hp - 2, Wp - 2, C)
+    ctx.premask = bool(premask)
+    if premask:
+      ctx.save_for_backward(x)      # its ReLU mask is applied to the gradient here (PREMASK)
     return ops.avgpool_fwd(x, N, Hp - 2, Wp - 2, 1, C)
 
   @staticmethod
   def backward(ctx, dfeats):
     N, H, W, C = ctx.dims
     dx = ops.pt_alloc(N, H, W, C, 1, dfeats.device)
-    return ops.avgpool_bwd(dfeats.contiguous(), dx, N, H, W, 1, C)
+    act = ctx.saved_tensors[0] if ctx.premask else None
+    return ops.avgpool_bwd(dfeats.contiguous(), dx, N, H, W, 1, C, mask_act=act), None
 
 
 class _HeadsFn(torch.autograd.Function):
@@ -456,14 +483,26 @@ class ClusterNet5gTrunk(nn.Module):
     return self._run(x, penultimate_features)
 
   def _run(self, x, penultimate_features):
-    x = _StemFn.apply(x, self.conv1.weight, self.bn1.weight, self.bn1.bias, self)
-    x = self.layer1(x)
-    x = self.layer2(x)
-    x = self.layer3(x)
-    if penultimate_features:
-      return ops.pt_to_nchw(x, 1).reshape(x.size(0), -1)
-    x = self.layer4(x)
-    return _AvgPoolFn.apply(x)   # avg_pool_sz == final spatial size for 96 / 64 / 32 inputs
+    # PREMASK: in the plain sequential forward every block output has one consumer (the next
+    # block, or the average pool), so gradients can travel pre-masked; the penultimate-features
+    # path taps layer3's output with torch ops and keeps the self-masking blocks
+    blocks = [b for layer in (self.layer1, self.layer2, self.layer3, self.layer4) for b in layer]
+    chain = PREMASK[0] and not penultimate_features
+    for i, b in enumerate(blocks):
+      b._dout_premasked = chain
+      b._mask_dx = chain and i > 0        # block 0's input gradient goes to the stem (own masking)
+    try:
+      x = _StemFn.apply(x, self.conv1.weight, self.bn1.weight, self.bn1.bias, self)
+      x = self.layer1(x)
+      x = self.layer2(x)
+      x = self.layer3(x)
+      if penultimate_features:
+        return ops.pt_to_nchw(x, 1).reshape(x.size(0), -1)
+      x = self.layer4(x)
+      return _AvgPoolFn.apply(x, chain)   # avg_pool_sz == final spatial size for 96 / 64 / 32 inputs
+    finally:
+      for b in blocks:
+        b._dout_premasked = b._mask_dx = False
 
 
 def _initialize_weights(net):

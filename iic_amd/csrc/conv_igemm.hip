@@ -324,7 +324,7 @@ int iic_conv_igemm(const iic_conv_geom* g, const void* in, const void* w, void* 
   if (!g || !in || !w || !out) return IIC_ERR_ARG;
   if (g->Cin % 64 != 0 || g->Cout % 64 != 0 || g->ntaps < 1 || g->ntaps > IIC_MAX_TAPS)
     return IIC_ERR_UNSUPPORTED;
-  if ((res_grad == nullptr) != (res_act == nullptr)) return IIC_ERR_ARG;
+  if (!(accumulate & IIC_ACC_PREMASK) && (res_grad == nullptr) != (res_act == nullptr)) return IIC_ERR_ARG;
   const int BN = pick_bn(g->Cout);
   const long M = igemm_rows_host(g);
   if (M <= 0 || g->NP <= 0) return IIC_ERR_ARG;

@@ -357,7 +357,7 @@ int iic_conv_igemm_frag(const iic_conv_geom* g, const void* in, const void* wfra
                         float* stats, const void* res_grad, const void* res_act, int accumulate,
                         void* stream) {
   if (!g || !in || !wfrag || !out) return IIC_ERR_ARG;
-  if ((res_grad == nullptr) != (res_act == nullptr)) return IIC_ERR_ARG;
+  if (!(accumulate & IIC_ACC_PREMASK) && (res_grad == nullptr) != (res_act == nullptr)) return IIC_ERR_ARG;
   if (!iic_conv_igemm_frag_supported(g)) return IIC_ERR_UNSUPPORTED;
   if (g_p64_enabled && iic_p64_supported(g))
     return iic_p64_launch(g, in, wfrag, out, stats, res_grad, res_act, accumulate, stream);

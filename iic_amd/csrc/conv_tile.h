@@ -75,7 +75,11 @@ __device__ __forceinline__ void igemm_load_patch(unsigned char* sA, const bf16_t
 }
 
 // sC [BM][BN + PAD] bf16 (LDS) -> out rows s_pout[row] (skipped when < 0), 16-byte stores.
-// accumulate: out += previous contents; res_grad/res_act: out += res_grad where res_act > 0.
+// accumulate is a flag word (include/iic_hip.h): IIC_ACC_ADD: out += previous contents;
+// without IIC_ACC_PREMASK: res_grad/res_act: out += res_grad where res_act > 0;
+// with IIC_ACC_PREMASK: out = (value [+ previous] [+ res_grad]) where res_act > 0, else 0 -- the
+// gradient leaves already multiplied by the ReLU mask of the activation it belongs to (res_act =
+// this conv's INPUT activation), so its consumers do not read that activation again.
 template <int BN, int BM, int NTHREADS, int PAD = 8>
 __device__ __forceinline__ void igemm_store_tile(const bf16_t* sC, const int* s_pout,
                                                  bf16_t* __restrict__ out,
@@ -83,24 +87,41 @@ __device__ __forceinline__ void igemm_store_tile(const bf16_t* sC, const int* s_
                                                  const bf16_t* __restrict__ res_act, int accumulate,
                                                  int Cout, int n0, int tid) {
   constexpr int CLD = BN + PAD;
+  const bool add_prev = accumulate & IIC_ACC_ADD, premask = accumulate & IIC_ACC_PREMASK;
   for (int idx = tid; idx < BM * (BN / 8); idx += NTHREADS) {
     const int row = idx / (BN / 8), ch = idx - row * (BN / 8);
     const int po = s_pout[row];
     if (po < 0) continue;
     uint4 v = *reinterpret_cast<const uint4*>(sC + row * CLD + ch * 8);
     const long o = (long)po * Cout + n0 + ch * 8;
-    if (accumulate || res_grad) {
+    if (add_prev || res_grad || res_act) {
       uint32_t vv[4] = {v.x, v.y, v.z, v.w};
       float f[8];
 #pragma unroll
       for (int i = 0; i < 4; ++i) { f[2 * i] = bf16lo(vv[i]); f[2 * i + 1] = bf16hi(vv[i]); }
-      if (accumulate) {
+      if (add_prev) {
         const uint4 ov = *reinterpret_cast<const uint4*>(out + o);
         const uint32_t oo[4] = {ov.x, ov.y, ov.z, ov.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) { f[2 * i] += bf16lo(oo[i]); f[2 * i + 1] += bf16hi(oo[i]); }
       }
-      if (res_grad) {
+      if (premask) {
+        if (res_grad) {
+          const uint4 gv = *reinterpret_cast<const uint4*>(res_grad + o);
+          const uint32_t gg[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { f[2 * i] += bf16lo(gg[i]); f[2 * i + 1] += bf16hi(gg[i]); }
+        }
+        if (res_act) {
+          const uint4 av = *reinterpret_cast<const uint4*>(res_act + o);
+          const uint32_t aa[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (!(bf16lo(aa[i]) > 0.f)) f[2 * i] = 0.f;
+            if (!(bf16hi(aa[i]) > 0.f)) f[2 * i + 1] = 0.f;
+          }
+        }
+      } else if (res_grad) {
         const uint4 gv = *reinterpret_cast<const uint4*>(res_grad + o);
         const uint4 av = *reinterpret_cast<const uint4*>(res_act + o);
         const uint32_t gg[4] = {gv.x, gv.y, gv.z, gv.w}, aa[4] = {av.x, av.y, av.z, av.w};

@@ -33,9 +33,12 @@ __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const bf16_t* __restri
 }
 
 // din[n][y][x][c] = dfeats[n][c] / (H*W)
+// act (nullable): din is zeroed where act <= 0 (the ReLU mask of the pooled activation, so that the
+// last block's BatchNorm backward does not have to read it: archs/cluster.py PREMASK)
 __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dfeats,
-                                                          bf16_t* __restrict__ din, int H, int W,
-                                                          int P, int C) {
+                                                          bf16_t* __restrict__ din,
+                                                          const bf16_t* __restrict__ act, int H,
+                                                          int W, int P, int C) {
   const int n = blockIdx.x;
   const int Hp = H + 2 * P, Wp = W + 2 * P;
   const float inv = 1.f / (float)(H * W);
@@ -43,8 +46,16 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restric
     const uint32_t v = pack_bf16x2(dfeats[(long)n * C + 2 * c2] * inv,
                                    dfeats[(long)n * C + 2 * c2 + 1] * inv);
     for (int y = 0; y < H; ++y)
-      for (int x = 0; x < W; ++x)
-        *reinterpret_cast<uint32_t*>(din + (((long)n * Hp + y + P) * Wp + x + P) * C + 2 * c2) = v;
+      for (int x = 0; x < W; ++x) {
+        const long o = (((long)n * Hp + y + P) * Wp + x + P) * C + 2 * c2;
+        uint32_t w = v;
+        if (act) {
+          const uint32_t a = *reinterpret_cast<const uint32_t*>(act + o);
+          if (!(bf16lo(a) > 0.f)) w &= 0xffff0000u;
+          if (!(bf16hi(a) > 0.f)) w &= 0x0000ffffu;
+        }
+        *reinterpret_cast<uint32_t*>(din + o) = w;
+      }
   }
 }
 
@@ -163,10 +174,10 @@ int iic_avgpool_fwd(const void* in_pt, float* feats, int N, int H, int W, int P,
 }
 
 int iic_avgpool_bwd(const float* dfeats, void* din_pt, int N, int H, int W, int P, int C,
-                    void* stream) {
+                    const void* mask_act_pt, void* stream) {
   if (!dfeats || !din_pt || N <= 0 || (C & 1)) return IIC_ERR_ARG;
   hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, dfeats,
-                     (bf16_t*)din_pt, H, W, P, C);
+                     (bf16_t*)din_pt, (const bf16_t*)mask_act_pt, H, W, P, C);
   return iic_launch_status();
 }
 

@@ -143,10 +143,15 @@ def frag_supported(g):
   return ok
 
 
-def conv_igemm(g, x_pt, w_t, out_pt, stats=None, res_grad=None, res_act=None, accumulate=False):
+ACC_ADD, ACC_PREMASK = 1, 2     # include/iic_hip.h IIC_ACC_*
+
+
+def conv_igemm(g, x_pt, w_t, out_pt, stats=None, res_grad=None, res_act=None, accumulate=False,
+               premask=False):
   """w_t: a row-major bf16 operand tensor (first-generation kernel) or a WOperand handle
-  (second-generation weights-direct kernel wherever the geometry supports it)."""
-  acc = 1 if accumulate else 0
+  (second-generation weights-direct kernel wherever the geometry supports it).
+  premask: out = (value [+ previous] [+ res_grad]) where res_act > 0 else 0 (IIC_ACC_PREMASK)."""
+  acc = (ACC_ADD if accumulate else 0) | (ACC_PREMASK if premask else 0)
   if isinstance(w_t, WOperand):
     if frag_supported(g):
       check(lib().iic_conv_igemm_frag(ctypes.byref(g), ptr(x_pt), ptr(w_t.pw.frag(w_t.bwd)),
@@ -318,8 +323,8 @@ def avgpool_fwd(x_pt, N, H, W, P, C):
   return feats
 
 
-def avgpool_bwd(dfeats, out_pt, N, H, W, P, C):
-  check(lib().iic_avgpool_bwd(ptr(dfeats), ptr(out_pt), N, H, W, P, C, stream_ptr()),
+def avgpool_bwd(dfeats, out_pt, N, H, W, P, C, mask_act=None):
+  check(lib().iic_avgpool_bwd(ptr(dfeats), ptr(out_pt), N, H, W, P, C, ptr(mask_act), stream_ptr()),
         "iic_avgpool_bwd")
   return out_pt
 

@@ -111,8 +111,14 @@ long iic_conv_lds_bytes(const iic_conv_geom* g, int BN);
  * w: bf16 [wtaps][Cout][Cin].  stats (nullable): fp32 [IIC_STAT_STRIPES][2][Cout],
  * += per-channel sum / sum of squares of the fp32 accumulators (BatchNorm batch stats).
  * res_grad/res_act (nullable, PT like out): out += res_grad where res_act > 0 (fused
- * ReLU-masked residual gradient).  accumulate != 0: out += previous contents.          */
+ * ReLU-masked residual gradient).  accumulate is a flag word: IIC_ACC_ADD: out += previous
+ * contents; IIC_ACC_PREMASK changes the meaning of res_grad / res_act (each nullable on its
+ * own): out = (value [+ previous] [+ res_grad]) where res_act > 0, else 0 -- a backward-data
+ * launch hands its gradient over already multiplied by the ReLU mask of the activation it
+ * belongs to (res_act = the conv's input activation, archs/cluster.py PREMASK).           */
 #define IIC_STAT_STRIPES 32
+#define IIC_ACC_ADD 1
+#define IIC_ACC_PREMASK 2
 int iic_conv_igemm(const iic_conv_geom* g, const void* in, const void* w, void* out,
                    float* stats, const void* res_grad, const void* res_act, int accumulate,
                    void* stream);
@@ -230,6 +236,7 @@ int iic_sobel(const float* imgs, float* out, int N, int C, int H, int W, int inc
 int iic_avgpool_fwd(const void* in_pt, float* feats, int N, int H, int W, int P, int C,
                     void* stream);
 int iic_avgpool_bwd(const float* dfeats, void* din_pt, int N, int H, int W, int P, int C,
+                    const void* mask_act_pt /* nullable: din = 0 where this activation <= 0 */,
                     void* stream);
 /* C[m][n] (+)= sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] (+ bias[n]); exact fp32 MFMA      */
 int iic_gemm_f32(const float* A, long sam, long sak, const float* B, long sbk, long sbn,

@@ -334,6 +334,27 @@ def _conv_backward_data(case, frag=False):
     want = 2 * ref + rg * (ra > 0).float()
     got2 = ops.pt_to_nchw(dx2, 1).cpu()
     assert (got2 - want).abs().max().item() <= 2e-2 * want.abs().max().item()
+    # IIC_ACC_PREMASK: out = (value [+ previous] [+ res_grad]) where res_act > 0 else 0 -- exact
+    # against the plain launch's own bf16 output (the epilogue works on the bf16-rounded tile)
+    rgp, rap = ops.pt_from_nchw(rg.to(dev()), 1), ops.pt_from_nchw(ra.to(dev()), 1)
+    plain = dx.float()
+    m = (rap.float() > 0).float()
+    interior = torch.zeros_like(m)
+    interior[:, 1:-1, 1:-1] = 1
+    for name, kw, expect in (
+        ("mask", dict(res_act=rap), plain * m),
+        ("grad", dict(res_grad=rgp), plain + rgp.float() * interior),
+        ("grad+mask", dict(res_grad=rgp, res_act=rap), (plain + rgp.float()) * m)):
+      dx3 = torch.zeros_like(dx)
+      for g in geoms:
+        ops.conv_igemm(g, dyp, wb, dx3, premask=True, **kw)
+      torch.cuda.synchronize()
+      assert torch.equal(dx3, expect.to(torch.bfloat16)), name
+    dx4 = dx.clone()                      # accumulate onto the plain result, then mask
+    for g in geoms:
+      ops.conv_igemm(g, dyp, wb, dx4, accumulate=True, premask=True, res_act=rap)
+    torch.cuda.synchronize()
+    assert torch.equal(dx4, ((plain + plain).to(torch.bfloat16).float() * m).to(torch.bfloat16))
 
 
 @pytest.mark.parametrize("use_tr", [False, True])

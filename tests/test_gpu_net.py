@@ -94,7 +94,7 @@ def test_net5g_small_vs_reference_golden(use_tr):
             "out_tf_err_vs_bf16emu": float(np.abs(out_tf - eout_tf).max()),
             "out_err_vs_fp32_reference": float(np.abs(out - g["net5g_out"]).max()),
             "bf16emu_vs_fp32_reference": float(np.abs(eout - g["net5g_out"]).max()),
-            "loss": float(tot), "loss_bf16emu": float(eloss), "loss_fp32_reference": float(g["net5g_loss"][0])}
+            "loss": float(tot.detach()), "loss_bf16emu": float(eloss), "loss_fp32_reference": float(g["net5g_loss"][0])}
   os.makedirs("gpurun_out", exist_ok=True)
   with open("gpurun_out/net5g_small_report_tr%d.txt" % int(use_tr), "w") as f:
     f.write("%s\n" % report)
@@ -418,3 +418,58 @@ def test_basic_block_teacher_forced(layer, bidx, cin, planes, stride, H):
     assert c >= 0.998 and abs(r - 1) < 2e-2, (n, c, r)
   assert torch.allclose(blk.bn1.running_mean.cpu(), params[pre + ".bn1.running_mean"], atol=1e-3)
   assert torch.allclose(blk.bn2.running_var.cpu(), params[pre + ".bn2.running_var"], rtol=1e-2, atol=1e-3)
+
+
+def test_premasked_gradient_chain_matches_self_masking_blocks():
+  """archs.cluster.PREMASK: blocks that receive their output gradient already multiplied by the
+  ReLU mask (applied by the consumer's backward-data epilogue / the average-pool backward) against
+  the same blocks masking for themselves -- a plain block, a stride-2 downsample block and another
+  plain block, then the average pool.  The masked values are identical bit for bit; sums differ by
+  fp32 accumulation order only."""
+  from iic_amd import ops
+  from iic_amd.archs import cluster as cl
+  torch.manual_seed(3)
+  d = dev()
+  N, H = 6, 14
+  ds = torch.nn.Sequential(torch.nn.Conv2d(64, 128, 1, 2, bias=False),
+                           torch.nn.BatchNorm2d(128, track_running_stats=True))
+  blocks = [cl.BasicBlock(64, 64, track_running_stats=True),
+            cl.BasicBlock(64, 128, 2, ds, track_running_stats=True),
+            cl.BasicBlock(128, 128, track_running_stats=True)]
+  for b in blocks:
+    b.to(d).train()
+    for m in b.modules():
+      if isinstance(m, torch.nn.BatchNorm2d):
+        m.weight.data.uniform_(0.5, 1.5)
+        m.bias.data.normal_(0, 0.3)
+  x0 = torch.relu(torch.randn(N, 64, H, H))
+  dfe = torch.randn(N, 128)
+  res = {}
+  for chain in (False, True):
+    for b in blocks:
+      b.zero_grad()
+    x = ops.pt_from_nchw(x0.to(d), 1).requires_grad_(True)
+    for i, b in enumerate(blocks):
+      b._dout_premasked, b._mask_dx = chain, chain and i > 0
+    try:
+      h = x
+      for b in blocks:
+        h = b(h)
+      f = cl._AvgPoolFn.apply(h, chain)
+    finally:
+      for b in blocks:
+        b._dout_premasked = b._mask_dx = False
+    f.backward(dfe.to(d))
+    torch.cuda.synchronize()
+    res[chain] = (f.detach().clone(), x.grad.detach().float().clone(),
+                  {n: p.grad.clone() for bi, b in enumerate(blocks) for n, p in
+                   ((("%d.%s" % (bi, k)), v) for k, v in b.named_parameters())})
+  f0, dx0, g0 = res[False]
+  f1, dx1, g1 = res[True]
+  assert torch.equal(f0, f1)
+  # block 0 does not pre-mask its input gradient (stem convention): dx must agree to fp32-sum noise
+  assert (dx0 - dx1).abs().max().item() <= 2e-2 * dx0.abs().max().item()
+  assert _cos(dx0, dx1) > 0.9999
+  for n in g0:
+    assert _cos(g0[n], g1[n]) > 0.9999, n
+    assert abs(float(g1[n].norm() / g0[n].norm()) - 1) < 2e-3, n
