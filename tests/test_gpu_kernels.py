@@ -626,7 +626,7 @@ def test_heads_forward_backward():
   d = dev()
   xp = ops.pt_from_nchw(xin.to(d), 1).requires_grad_(True)
   Wd, bd = W.to(d).requires_grad_(True), b.to(d).requires_grad_(True)
-  f = _AvgPoolFn.apply(xp)
+  f = _AvgPoolFn.apply(xp, False)
   p = _HeadsFn.apply(f, Wd, bd, H, k)
   (p * gout.to(d)).sum().backward()
   torch.cuda.synchronize()
@@ -635,6 +635,13 @@ def test_heads_forward_backward():
   assert torch.allclose(bd.grad.cpu(), bt.grad, rtol=1e-4, atol=1e-6)
   gx = ops.pt_to_nchw(xp.grad, 1).cpu()
   assert (gx - xt.grad).abs().max() <= 1e-2 * xt.grad.abs().max().item()
+  # pre-masked variant (archs.cluster.PREMASK): the same gradient, zero where the activation <= 0
+  xp2 = ops.pt_from_nchw(xin.to(d), 1).requires_grad_(True)
+  f2 = _AvgPoolFn.apply(xp2, True)
+  (_HeadsFn.apply(f2, Wd.detach(), bd.detach(), H, k) * gout.to(d)).sum().backward()
+  torch.cuda.synchronize()
+  assert torch.equal(f2, f)
+  assert torch.equal(xp2.grad, torch.where(xp.detach() > 0, xp.grad, torch.zeros_like(xp.grad)))
 
 
 def test_adam_matches_torch():
