@@ -20,6 +20,15 @@ itself (present: the arithmetic that matters -- bilinear resampling, ImageEnhanc
 HSV round trip, the L conversion -- is PIL's own code), with the RANDOM PARAMETERS made explicit
 so that a device implementation can be compared on identical parameters:
 
+PINNING.  The oracle runs the third-party arithmetic itself (PIL's resize / rotate / ImageEnhance /
+HSV conversion are called, not restated), but on the Pillow installed here (12.2.0), not on the
+reference's pinned Pillow 5.2.0 + torchvision 0.2.1 (package_versions.txt:73,115; neither is
+available offline).  The torchvision layer adds no arithmetic (it forwards to the PIL calls used
+below; its uint8 hue wrap is restated in tv_adjust_hue).  Parity of csrc/augment.hip is therefore
+pinned to this container's PIL bit for bit; drift between Pillow 5.2.0 and 12.2.0 in those four
+operations is NOT checked -- with respect to the reference's own pinned versions this part is
+"parity unpinned".
+
   pil_pipeline(...)   the reference's op sequence on PIL images            (the oracle)
   np_pipeline(...)    the same arithmetic in numpy integer / float32 / float64 steps, i.e. the
                       algorithm specification of csrc/augment.hip; tests check it against
