@@ -34,9 +34,15 @@
 //   32 = no global stores of the tile, 64 = no BatchNorm statistics.
 // DMA: the patch is fetched by LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, every piece of
 // a chunk in flight at once instead of 4-piece batches that each wait a full memory latency) into
-// unpadded 128-byte rows whose 16-byte slot is XOR-ed with (row >> 1) & 7 -- the swizzle is
+// unpadded 128-byte rows whose 16-byte slot is XOR-ed with a 3-bit key of the row -- the swizzle is
 // applied on the DMA's SOURCE address; A-fragment addresses then cost ~2 VALU per read instead of
-// an immediate offset.  !DMA: register-staged loads into 144-byte-pitch rows (first version).
+// an immediate offset.  The key is (D >> 1) & 7 with D = p - J * (p / in_Wp), p the row's pixel
+// index and J = in_Wp - MX the padding a GEMM row run skips at the end of an image row: D counts
+// pixels the way consecutive GEMM rows visit them, so the 16 lanes of a ds_read_b128 group (rows
+// of consecutive m, any tap) see 16 consecutive D = 16 distinct (row parity, slot) pairs = all 64
+// banks, whereas a key on the raw row index collided across every row end (SQ_LDS_BANK_CONFLICT
+// was 51 % of the LDS cycles at 13- and 25-pixel rows).  !DMA: register-staged loads into
+// 144-byte-pitch rows (first version).
 template <bool GATHER, int ABL, bool DMA>
 __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
     const iic_conv_geom g, const bf16_t* __restrict__ in, const unsigned char* __restrict__ wfrag,
@@ -48,6 +54,7 @@ __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
   int* s_pin = reinterpret_cast<int*>(smem_raw + lds_a_bytes);     // [256]
   int* s_pout = s_pin + BD_BM;                                     // [256]
   float* s_red = reinterpret_cast<float*>(s_pout + BD_BM);         // [2 wm][2][128]
+  unsigned char* s_key = reinterpret_cast<unsigned char*>(s_red + 4 * BD_BN);   // DMA: [npix] swizzle keys
   bf16_t* sC = reinterpret_cast<bf16_t*>(smem_raw);                // epilogue reuse of sA
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -74,13 +81,25 @@ __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
   __syncthreads();
   const int p_lo = s_pin[0];
   const int npix = GATHER ? BD_BM : g.NP256;
+  // swizzle key of a pixel (see the header): D = p - J * (p / in_Wp); J must be even so that D keeps
+  // the row parity (the 128-B half of the 256-B bank window is the physical row parity)
+  const int jskip = (!GATHER && g.sx == 1 && ((g.in_Wp - g.MX) & 1) == 0) ? g.in_Wp - g.MX : 0;
+  auto dense_of = [&](int p) { return p - jskip * (p / g.in_Wp); };
   int arow[4];     // !DMA: byte offset of the lane's row (tap 0) + k-chunk; DMA: patch row index
+  int drow[4];     // DMA: D of the lane's row at tap offset 0
 #pragma unroll
   for (int ms = 0; ms < 4; ++ms) {
     const int row = wm * 128 + ms * 32 + l31;
     const int pr = GATHER ? row : (s_pin[row] - p_lo);
     arow[ms] = DMA ? pr : pr * ROWB + g5 * 16;
+    drow[ms] = (DMA && !GATHER) ? dense_of(s_pin[row]) : pr;
   }
+  if (DMA && !GATHER && jskip != 0) {     // (without a skip the key is a function of r alone: no table)
+    for (int r = tid; r < npix; r += BD_THREADS) s_key[r] = (unsigned char)((dense_of(p_lo + r) >> 1) & 7);
+    __syncthreads();
+  }
+  // per-tap increment of D: tap_off = dy * in_Wp + dx  ->  dy * (in_Wp - J) + dx
+  const int v_tapd = v_tapoff - jskip * (v_tapoff / g.in_Wp);
   // DMA patch loader: 1-KB blocks over the 4 waves; piece q -> LDS byte q*16 (row q>>3, physical
   // slot q&7), source = logical slot (q&7) ^ ((row>>1)&7) of the row's pixel
   const int nblk = (npix * 128 + 1023) >> 10;
@@ -88,7 +107,9 @@ __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
     for (int blk = wave; blk < nblk; blk += BD_THREADS / 64) {
       const int q = blk * 64 + lane;
       const int r = q >> 3;
-      const int ls = (q & 7) ^ ((r >> 1) & 7);
+      const int ls = (q & 7) ^ (GATHER ? ((r >> 1) & 7)
+                                       : (jskip != 0 ? (int)s_key[r < npix ? r : npix - 1]
+                                                     : (((p_lo + r) >> 1) & 7)));
       long p = GATHER ? (long)s_pin[r < BD_BM ? r : BD_BM - 1] : (long)p_lo + r;
       p = p < in_pixels ? p : in_pixels - 1;
       __builtin_amdgcn_global_load_lds(
@@ -97,9 +118,10 @@ __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
-  // DMA layout: byte address of A fragment (row R, k-step ks, lane half g5) = R*128 + ((2ks+g5) ^ key)*16
-  auto a_base = [&](int R) { return R * 128 + (((g5 ^ (R >> 1)) & 1) << 4); };
-  auto a_kk = [&](int R) { return ((R >> 2) & 3) << 5; };
+  // DMA layout: byte address of A fragment (row R, k-step ks, lane half g5) = R*128 + ((2ks+g5) ^ key)*16,
+  // key = (D >> 1) & 7 of the row
+  auto a_base = [&](int R, int D) { return R * 128 + (((g5 ^ (D >> 1)) & 1) << 4); };
+  auto a_kk = [&](int D) { return ((D >> 2) & 3) << 5; };
 
   f32x16 acc[4][2];
 #pragma unroll
@@ -154,8 +176,9 @@ __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
     const int t0 = GATHER ? 0 : __builtin_amdgcn_readlane(v_tapoff, 0);
     if (DMA) {
       const int R = arow[ms] + t0;
-      pcur[ms] = a_base(R);
-      kcur[ms] = a_kk(R);
+      const int D = drow[ms] + (GATHER ? 0 : __builtin_amdgcn_readlane(v_tapd, 0));
+      pcur[ms] = a_base(R, D);
+      kcur[ms] = a_kk(D);
       a[0][ms] = *reinterpret_cast<const bf16x8*>(sA + pcur[ms] + kcur[ms]);
     } else {
       pcur[ms] = arow[ms] + t0 * ROWB;
@@ -170,13 +193,15 @@ __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
     if (!more) { tn = tap; cn = chunk; }   // the ring always reloads: no branch around a load
     const unsigned char* nb = (ABL & 2) ? frag_ptr(0, 0) : frag_ptr(tn, cn);
     const int toffn = GATHER ? 0 : __builtin_amdgcn_readlane(v_tapoff, tn);
+    const int tdn = GATHER ? 0 : __builtin_amdgcn_readlane(v_tapd, tn);
     int pnext[4], knext[4];
 #pragma unroll
     for (int ms = 0; ms < 4; ++ms) {
       if (DMA) {
         const int R = arow[ms] + toffn;
-        pnext[ms] = a_base(R);
-        knext[ms] = a_kk(R);
+        const int D = drow[ms] + tdn;
+        pnext[ms] = a_base(R, D);
+        knext[ms] = a_kk(D);
       } else {
         pnext[ms] = arow[ms] + toffn * ROWB;
         knext[ms] = 0;
@@ -343,13 +368,18 @@ static long bd_lds_a(const iic_conv_geom* g) {
   return (m + 15) & ~15L;
 }
 
+static long bd_key_bytes(const iic_conv_geom* g) {    // swizzle-key table of the DMA patch (1 B / row)
+  const int jskip = (g->ntaps > 1 && g->sx == 1 && ((g->in_Wp - g->MX) & 1) == 0) ? g->in_Wp - g->MX : 0;
+  return (g_bd_dma && jskip != 0) ? (((long)g->NP256 + 15) & ~15L) : 0;
+}
+
 /* 1 if iic_conv_igemm_frag can run this geometry (else use iic_conv_igemm). */
 int iic_conv_igemm_frag_supported(const iic_conv_geom* g) {
   if (!g) return 0;
   if (g_p64_enabled && iic_p64_supported(g)) return 1;
   if (g->Cin % 64 != 0 || g->Cout % BD_BN != 0 || g->ntaps < 1 || g->ntaps > IIC_MAX_TAPS) return 0;
   if (g->ntaps > 1 && g->NP256 <= 0) return 0;
-  const long lds = bd_lds_a(g) + 2L * BD_BM * 4 + 4L * BD_BN * 4;
+  const long lds = bd_lds_a(g) + 2L * BD_BM * 4 + 4L * BD_BN * 4 + bd_key_bytes(g);
   return lds <= (g_bd_one_wg ? 160 : 80) * 1024;      // two workgroups per CU, or one
 }
 
@@ -367,7 +397,7 @@ int iic_conv_igemm_frag(const iic_conv_geom* g, const void* in, const void* wfra
   const int mt = (int)((M + BD_BM - 1) / BD_BM);
   const int grid = mt * (g->Cout / BD_BN);
   const int la = (int)bd_lds_a(g);
-  const long lds = la + 2L * BD_BM * 4 + 4L * BD_BN * 4;
+  const long lds = la + 2L * BD_BM * 4 + 4L * BD_BN * 4 + bd_key_bytes(g);
   hipStream_t s = (hipStream_t)stream;
 #define BD_LAUNCH2(GA_, AB_, DM_)                                                                 \
   do {                                                                                           \
