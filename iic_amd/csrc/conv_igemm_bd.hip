@@ -47,7 +47,8 @@ template <bool GATHER, int ABL, bool DMA>
 __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
     const iic_conv_geom g, const bf16_t* __restrict__ in, const unsigned char* __restrict__ wfrag,
     bf16_t* __restrict__ out, float* __restrict__ stats, const bf16_t* __restrict__ res_grad,
-    const bf16_t* __restrict__ res_act, int accumulate, int num_mtiles, int lds_a_bytes) {
+    const bf16_t* __restrict__ res_act, int accumulate, int num_mtiles, int lds_a_bytes,
+    int dense_key) {
   constexpr int CLD = BD_BN + 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned char* sA = smem_raw;                                   // [NP256][ROWB]
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
   const int npix = GATHER ? BD_BM : g.NP256;
   // swizzle key of a pixel (see the header): D = p - J * (p / in_Wp); J must be even so that D keeps
   // the row parity (the 128-B half of the 256-B bank window is the physical row parity)
-  const int jskip = (!GATHER && g.sx == 1 && ((g.in_Wp - g.MX) & 1) == 0) ? g.in_Wp - g.MX : 0;
+  const int jskip = (dense_key && !GATHER && g.sx == 1 && ((g.in_Wp - g.MX) & 1) == 0) ? g.in_Wp - g.MX : 0;
   auto dense_of = [&](int p) { return p - jskip * (p / g.in_Wp); };
   int arow[4];     // !DMA: byte offset of the lane's row (tap 0) + k-chunk; DMA: patch row index
   int drow[4];     // DMA: D of the lane's row at tap offset 0
@@ -368,8 +369,10 @@ static long bd_lds_a(const iic_conv_geom* g) {
   return (m + 15) & ~15L;
 }
 
+static int g_bd_dense_key = 1;  // 0: swizzle key from the raw pixel index (A/B: conflicts at row ends)
+extern "C" void iic_debug_bd_dense_key(int v) { g_bd_dense_key = v; }
 static long bd_key_bytes(const iic_conv_geom* g) {    // swizzle-key table of the DMA patch (1 B / row)
-  const int jskip = (g->ntaps > 1 && g->sx == 1 && ((g->in_Wp - g->MX) & 1) == 0) ? g->in_Wp - g->MX : 0;
+  const int jskip = (g_bd_dense_key && g->ntaps > 1 && g->sx == 1 && ((g->in_Wp - g->MX) & 1) == 0) ? g->in_Wp - g->MX : 0;
   return (g_bd_dma && jskip != 0) ? (((long)g->NP256 + 15) & ~15L) : 0;
 }
 
@@ -411,7 +414,7 @@ int iic_conv_igemm_frag(const iic_conv_geom* g, const void* in, const void* wfra
     hipLaunchKernelGGL((conv_igemm_bd_kernel<GA_, AB_, DM_>), dim3(grid), dim3(BD_THREADS), lds, \
                        s, *g, (const bf16_t*)in, (const unsigned char*)wfrag, (bf16_t*)out,      \
                        stats, (const bf16_t*)res_grad, (const bf16_t*)res_act, accumulate, mt,   \
-                       la);                                                                      \
+                       la, g_bd_dense_key);                                                      \
   } while (0)
 #define BD_LAUNCH(GA_, AB_)                                                                       \
   do {                                                                                           \

@@ -45,6 +45,7 @@ def main():
   ap.add_argument("--no-wgrad", action="store_true")
   ap.add_argument("--bd-dma", type=int, default=1, help="weights-direct kernel: 1 = LDS-DMA patch loads, 0 = register-staged")
   ap.add_argument("--frag-ablate", type=str, default="", help="comma list of ablation codes for the frag kernel")
+  ap.add_argument("--dense-key-ab", action="store_true", help="A/B the weights-direct kernel's swizzle key (dense pixel count vs raw index)")
   a = ap.parse_args()
   dev = torch.device("cuda:0")
   N = a.n
@@ -97,6 +98,15 @@ def main():
       if ops.frag_supported(gf):
         t2 = timeit(lambda: ops.conv_igemm(gf, x, pw[0], y, stats=st), a.iters)
         extra += " | frag fwd %7.1f us %7.1f TF/s" % (t2, flops / t2 / 1e6)
+        if a.dense_key_ab:
+          import ctypes
+          from iic_amd import _lib
+          L = ctypes.CDLL(_lib.LIB_PATH)
+          L.iic_debug_bd_dense_key(0)
+          t4 = timeit(lambda: ops.conv_igemm(gf, x, pw[0], y, stats=st), a.iters)
+          L.iic_debug_bd_dense_key(1)
+          t5 = timeit(lambda: ops.conv_igemm(gf, x, pw[0], y, stats=st), a.iters)
+          extra += " | raw-index key %7.1f us, dense again %7.1f us" % (t4, t5)
         for code in [int(c) for c in a.frag_ablate.split(",") if c]:
           import ctypes
           from iic_amd import _lib
