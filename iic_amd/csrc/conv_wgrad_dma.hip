@@ -66,6 +66,23 @@ __device__ __forceinline__ bf16x8 wd_frag(uint32_t a0, uint32_t a1) {
   return u.v;
 }
 
+// The same read as inline asm.  hipcc treats the ds_read_tr builtin as a possible reader of LDS that
+// an in-flight LDS-DMA is writing and puts s_waitcnt vmcnt(0) in front of the first one -- right
+// after the next K-tile's DMA was issued, which serialised DMA and MFMA inside the workgroup (the
+// stall profile showed its waves parked 34-39 % of the time).  The compiler cannot see through the
+// asm, so the DMA stays in flight until the counted wait at the top of the next tile; the price is
+// that lgkmcnt has to be waited for by hand (the wait asm in the K loop ties the fragments to it).
+// Opt-in (g_wd_asm): it turned out not to change the kernel's time, see there.
+__device__ __forceinline__ void wd_tr_issue(uint32_t addr, s16x4& d) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(d) : "v"(addr));
+}
+__device__ __forceinline__ bf16x8 wd_pack(const s16x4 h0, const s16x4 h1) {
+  union { bf16x8 v; s16x4 h[2]; } u;
+  u.h[0] = h0;
+  u.h[1] = h1;
+  return u.v;
+}
+
 struct WdWalk {
   int n, y, x;
 };
@@ -90,7 +107,7 @@ __device__ __forceinline__ void wd_walk_pixels(const WdWalk& w, const iic_conv_g
   pout = valid ? (n * g.out_Hp + y * g.ty + g.py) * g.out_Wp + x * g.tx + g.px : -1;
 }
 
-template <int COT, int WD_BM, int NBUF>
+template <int COT, int WD_BM, int NBUF, bool ASMRD>
 __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_dma_kernel(
     const iic_conv_geom g, const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
     float* __restrict__ partials, int nsplit, int num_ktiles, int xb_bytes, int max_tap_off) {
@@ -251,14 +268,42 @@ __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_dma_kernel(
 #pragma unroll
       for (int ks = 0; ks < WD_BM / 16; ++ks) {
         bf16x8 a[CS], bfr[3];
+        if (ASMRD) {
+          s16x4 ah[CS][2], bh[3][2];
 #pragma unroll
-        for (int c = 0; c < CS; ++c)
-          a[c] = wd_frag(db + ks * 16 * DROW + aoff[c], db + (ks * 16 + 4) * DROW + aoff[c]);
+          for (int c = 0; c < CS; ++c) {
+            wd_tr_issue(db + ks * 16 * DROW + aoff[c], ah[c][0]);
+            wd_tr_issue(db + (ks * 16 + 4) * DROW + aoff[c], ah[c][1]);
+          }
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-          const int toff = __builtin_amdgcn_readlane(v_tapoff, tfirst + t);
-          const int R0 = rr0[ks] + toff, R1 = rr1[ks] + toff;
-          bfr[t] = wd_frag(xb + (R0 << 7) + (R0 & 2) * xs32, xb + (R1 << 7) + (R1 & 2) * xs32);
+          for (int t = 0; t < 3; ++t) {
+            const int toff = __builtin_amdgcn_readlane(v_tapoff, tfirst + t);
+            const int R0 = rr0[ks] + toff, R1 = rr1[ks] + toff;
+            wd_tr_issue(xb + (R0 << 7) + (R0 & 2) * xs32, bh[t][0]);
+            wd_tr_issue(xb + (R1 << 7) + (R1 & 2) * xs32, bh[t][1]);
+          }
+          // all reads of the k-step in flight; wait, and make every fragment depend on the wait
+          if (CS == 2)
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(ah[0][0]), "+v"(ah[0][1]), "+v"(ah[CS - 1][0]), "+v"(ah[CS - 1][1]));
+          else
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[0][0]), "+v"(ah[0][1]));
+          asm volatile("" : "+v"(bh[0][0]), "+v"(bh[0][1]), "+v"(bh[1][0]), "+v"(bh[1][1]),
+                            "+v"(bh[2][0]), "+v"(bh[2][1]));
+#pragma unroll
+          for (int c = 0; c < CS; ++c) a[c] = wd_pack(ah[c][0], ah[c][1]);
+#pragma unroll
+          for (int t = 0; t < 3; ++t) bfr[t] = wd_pack(bh[t][0], bh[t][1]);
+        } else {
+#pragma unroll
+          for (int c = 0; c < CS; ++c)
+            a[c] = wd_frag(db + ks * 16 * DROW + aoff[c], db + (ks * 16 + 4) * DROW + aoff[c]);
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            const int toff = __builtin_amdgcn_readlane(v_tapoff, tfirst + t);
+            const int R0 = rr0[ks] + toff, R1 = rr1[ks] + toff;
+            bfr[t] = wd_frag(xb + (R0 << 7) + (R0 & 2) * xs32, xb + (R1 << 7) + (R1 & 2) * xs32);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);   // all 10 transposing reads of the k-step in flight
 #pragma unroll
@@ -290,6 +335,12 @@ static long wd_lds(int np, int cot, int bmk, int nbuf) {
   return nbuf * (wd_xb_bytes(np) + (long)bmk * cot * 2) + WD_TAB_BYTES(bmk) + 64;
 }
 
+// 1: transposing reads as inline asm (see wd_tr_issue).  Measured (tools/conv_perf.py, same process):
+// the compiler's vmcnt(0) disappears from the K-tile loop, the time does not change (layer1 187 ->
+// 181 us, layer2 144 -> 143, layer3 143 -> 145, layer4 169 -> 172): the DMA wait was not what parks
+// the waves.  Default stays on the builtin; the switch is kept for the next experiments.
+static int g_wd_asm = 0;
+extern "C" void iic_debug_wgrad_asm(int v) { g_wd_asm = v; }
 static int g_wd_enabled = 1;     // 0: register-staged kernel, 1: DMA kernel, 3: force 64-pixel K-tiles
 extern "C" void iic_debug_enable_wgrad_dma(int v) { g_wd_enabled = v; }
 
@@ -338,18 +389,22 @@ int iic_wgrad_dma_launch(const iic_conv_geom* g, const void* x, const void* dy, 
   for (int i = 0; i < g->ntaps; ++i) mto = g->tap_off[i] > mto ? g->tap_off[i] : mto;
   dim3 grid((g->Cout / cot) * (g->Cin / 64), nsplit);
   hipStream_t s = (hipStream_t)stream;
-#define WD_LAUNCH(COT_, BMK_, NBUF_)                                                             \
+#define WD_LAUNCH2(COT_, BMK_, NBUF_, ASM_)                                                      \
   do {                                                                                          \
     static bool attr = false;                                                                   \
     if (!attr) {                                                                                \
       (void)hipFuncSetAttribute(                                                                \
-          reinterpret_cast<const void*>(&conv_wgrad_dma_kernel<COT_, BMK_, NBUF_>),             \
+          reinterpret_cast<const void*>(&conv_wgrad_dma_kernel<COT_, BMK_, NBUF_, ASM_>),       \
           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                              \
       attr = true;                                                                              \
     }                                                                                           \
-    hipLaunchKernelGGL((conv_wgrad_dma_kernel<COT_, BMK_, NBUF_>), grid, dim3(WD_THREADS), lds, \
-                       s, *g, (const bf16_t*)x, (const bf16_t*)dy, partials, nsplit, kt, xb,    \
-                       mto);                                                                    \
+    hipLaunchKernelGGL((conv_wgrad_dma_kernel<COT_, BMK_, NBUF_, ASM_>), grid,                  \
+                       dim3(WD_THREADS), lds, s, *g, (const bf16_t*)x, (const bf16_t*)dy,       \
+                       partials, nsplit, kt, xb, mto);                                          \
+  } while (0)
+#define WD_LAUNCH(COT_, BMK_, NBUF_)                                                             \
+  do {                                                                                          \
+    if (g_wd_asm) WD_LAUNCH2(COT_, BMK_, NBUF_, true); else WD_LAUNCH2(COT_, BMK_, NBUF_, false); \
   } while (0)
   if (bmk == 64 && nbuf == 4) {
     if (cot == 128) WD_LAUNCH(128, 64, 4); else WD_LAUNCH(64, 64, 4);

@@ -364,12 +364,15 @@ def test_conv_backward_weight(case, use_tr):
 
 
 def _wgrad_dma(mode):
+  """mode 1 / 3 / 0 as iic_debug_enable_wgrad_dma; 11: mode 1 with the inline-asm transposing reads."""
   import ctypes
   from iic_amd import _lib
-  ctypes.CDLL(_lib.LIB_PATH).iic_debug_enable_wgrad_dma(int(mode))
+  L = ctypes.CDLL(_lib.LIB_PATH)
+  L.iic_debug_wgrad_asm(1 if int(mode) == 11 else 0)
+  L.iic_debug_enable_wgrad_dma(1 if int(mode) == 11 else int(mode))
 
 
-@pytest.mark.parametrize("dma", [1, 3, 0])
+@pytest.mark.parametrize("dma", [1, 11, 3, 0])
 @pytest.mark.parametrize("case,nsplit", [((64, 64, 3, 1, 1, 2, 49), 2), ((128, 128, 3, 1, 1, 20, 25), 3),
                                          ((512, 512, 3, 1, 1, 6, 7), 1), ((64, 64, 3, 1, 1, 5, 13), 1)])
 def test_conv_backward_weight_long_k_ranges(case, nsplit, dma):

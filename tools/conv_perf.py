@@ -93,7 +93,11 @@ def main():
       L.iic_debug_enable_wgrad_dma(3)     # 64-pixel K-tiles, 3-4 buffers
       t_w0 = timeit(lambda: ops.conv_wgrad(gf, x, dy, K * K, True), a.iters)
       L.iic_debug_enable_wgrad_dma(1)
-    extra = "" if a.no_wgrad else " | wgrad(dma 64-px ring) %7.1f us" % t_w0
+      L.iic_debug_wgrad_asm(0)            # ds_read_tr builtin: compiler waits for the DMA before it
+      t_w1 = timeit(lambda: ops.conv_wgrad(gf, x, dy, K * K, True), a.iters)
+      L.iic_debug_wgrad_asm(1)
+      t_w2 = timeit(lambda: ops.conv_wgrad(gf, x, dy, K * K, True), a.iters)
+    extra = "" if a.no_wgrad else " | wgrad(dma 64-px ring) %7.1f us | builtin tr reads %7.1f us, asm again %7.1f us" % (t_w0, t_w1, t_w2)
     if a.frag:
       if ops.frag_supported(gf):
         t2 = timeit(lambda: ops.conv_igemm(gf, x, pw[0], y, stats=st), a.iters)
