@@ -158,3 +158,42 @@ def test_greyscale_draws_follow_the_reference_flags():
   assert (ip3[:, 1] == 4).all() and (ip3[:, 2] == 4).all()
   with __import__("pytest").raises(AssertionError):
     aug.apply(ip3, np.zeros((2000, 4), np.float32))  # CPU dataset: there is no CPU path
+
+
+def test_sobel_draws_and_unsupported_flags():
+  """Host-side draws of PairedAugmenter (distributions of RandomCrop / RandomHorizontalFlip /
+  ColorJitter.get_params) and the flags the GPU path refuses."""
+  import types
+  import pytest
+  import torch
+  from iic_amd.augment import GreyscaleAugmenter, PairedAugmenter, hue_shift, paired_dataloaders
+  aug = PairedAugmenter(torch.zeros(7, 96, 96, 3, dtype=torch.uint8), 84, 96, True, seed=5)
+  idx = np.arange(3000) % 7
+  ip, fp = aug.draw(idx, "jittered")
+  assert ip.shape == (3000, 20) and fp.shape == (3000, 4) and (ip[:, 0] == idx).all()
+  assert ip[:, 1].min() == 0 and ip[:, 1].max() == 12 and ip[:, 2].min() == 0 and ip[:, 2].max() == 12
+  assert 0.45 < ip[:, 3].mean() < 0.55 and (ip[:, 10] == 0).all() and (ip[:, 11] == 0).all()
+  assert (np.sort(ip[:, 5:9], 1) == np.arange(4)).all()
+  assert len({tuple(r) for r in ip[:, 5:9]}) == 24                       # every op order occurs
+  assert 0.6 <= fp[:, :3].min() and fp[:, :3].max() <= 1.4 + 1e-6 and np.abs(fp[:, 3]).max() <= 0.125
+  assert all(ip[i, 9] == hue_shift(float(fp[i, 3])) for i in range(0, 3000, 97))
+  ip1, fp1 = aug.draw(idx, "plain")
+  assert (ip1[:, 3:10] == 0).all() and (fp1 == 0).all() and ip1[:, 1].max() == 12
+  ip3, _ = aug.draw(idx, "center")
+  assert (ip3[:, 1] == 6).all() and (ip3[:, 2] == 6).all()
+  with pytest.raises(AssertionError):
+    PairedAugmenter(torch.zeros(2, 28, 28, dtype=torch.uint8), 20, 24, False)   # RGB dataset required
+  with pytest.raises(AssertionError):
+    paired_dataloaders(aug, torch.zeros(6), 4, 2)                               # one target per image
+  cfg = types.SimpleNamespace(crop_orig=True, tf1_crop="random", tf1_crop_sz=20, tf3_crop_diff=False,
+                              tf3_crop_sz=0, rot_val=0, always_rot=False, crop_other=False, tf2_crop="random",
+                              tf2_crop_szs=[20], input_sz=24, no_flip=False, no_jitter=True, demean=True,
+                              per_img_demean=False)
+  with pytest.raises(NotImplementedError):
+    GreyscaleAugmenter(torch.zeros(2, 28, 28, dtype=torch.uint8), cfg)
+  cfg.demean = False
+  g = GreyscaleAugmenter(torch.zeros(2, 28, 28, dtype=torch.uint8), cfg, seed=1)
+  ipg, fpg = g.draw(np.arange(400) % 2, "jittered")
+  assert g.crop_szs == [20, 28]                      # tf1/tf3 crop 20; tf2 without crop_other: whole image
+  assert (ipg[:, 10] == 1).all() and (ipg[:, 1:3] == 0).all() and (ipg[:, 4] == 0).all() and (ipg[:, 11] == 0).all()
+  assert 0.4 < ipg[:, 3].mean() < 0.6 and (fpg == 0).all()
