@@ -134,6 +134,50 @@ def cpu_baseline(n_pairs=96, steps=3, budget_s=90.0):
                     % (n_pairs, len(times) - 1)}
 
 
+def reference_api_rate(cfg, dev, imgs, imgs_tf, pairs, steps):
+  """The same step through the reference's OWN call sequence (cluster_sobel.py:235-272 as the
+  unchanged script issues it): net(x) -> python list of sub-head tensors, IID_loss once per
+  sub-head, `+=` / `/=` averaging, stock torch.optim.Adam, `.item()` reads of the loss
+  (cluster_sobel.py:255-266), eager launches.  Reported next to the headline number so that the
+  cost of the drop-in boundary is visible (VERDICT r1 weak #8)."""
+  from iic_amd import archs
+  from iic_amd.losses import IID_loss
+  from iic_amd.transforms import sobel_process
+  torch.manual_seed(0)
+  net = archs.ClusterNet5g(cfg).to(dev).train()
+  opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+
+  def step():
+    net.zero_grad()
+    xo = net(sobel_process(imgs, False))
+    xt = net(sobel_process(imgs_tf, False))
+    avg, avg_nl = None, None
+    for i in range(cfg.num_sub_heads):
+      loss, loss_nl = IID_loss(xo[i], xt[i], lamb=1.0)
+      if avg is None:
+        avg, avg_nl = loss, loss_nl
+      else:
+        avg += loss
+        avg_nl += loss_nl
+    avg /= cfg.num_sub_heads
+    avg_nl /= cfg.num_sub_heads
+    v = avg.item() + avg_nl.item()        # the script reads both every step (:262-266)
+    avg.backward()
+    opt.step()
+    return v
+  for _ in range(2):
+    step()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(steps):
+    step()
+  torch.cuda.synchronize()
+  dt = (time.perf_counter() - t0) / steps
+  return {"paired_images_per_sec": pairs / dt, "ms_per_step": 1e3 * dt,
+          "what": "list-returning net(x), IID_loss per sub-head, torch.optim.Adam, loss .item() "
+                  "every step, eager launches -- the unchanged script's call sequence"}
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
@@ -142,6 +186,12 @@ def main():
   ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="pairs per GPU (default 660)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-roofline", action="store_true")
+  ap.add_argument("--no-graph", action="store_true",
+                  help="issue every launch of the timed steps from Python (eager) instead of replaying "
+                       "the step as one captured HIP graph (iic_amd.graph.CapturedStep; N=1 default)")
+  ap.add_argument("--no-reference-api", action="store_true",
+                  help="skip the second measurement through the reference's own call sequence "
+                       "(net(x) -> list, IID_loss per sub-head, torch.optim.Adam; reported in config)")
   ap.add_argument("--with-augment", action="store_true",
                   help="also build every step's batch inside the timed region with the GPU paired "
                        "augmentation (iic_amd.augment, SURVEY 8f rank 1) from a resident uint8 "
@@ -180,7 +230,11 @@ def main():
   if world > 1:   # identical weights on every rank
     for p in net.parameters():
       torch.distributed.broadcast(p.data, 0)
-  opt = Adam(net.parameters(), lr=1e-4)
+  # N = 1: the whole step (sobel -> 2 forwards -> loss -> backward -> Adam) is captured once in a
+  # HIP graph and replayed -- same kernels, same arithmetic, one launch call per step instead of
+  # ~1100 from Python.  N > 1 keeps eager launches (RCCL collectives sit between the kernels).
+  use_graph = world == 1 and not args.no_graph and not args.with_augment
+  opt = Adam(net.parameters(), lr=1e-4, capturable=use_graph)
   # weak scaling: every rank owns `pairs` pairs (its shard of the global batch of pairs*world)
   imgs, imgs_tf = make_batch(args.pairs, INPUT_SZ, dev, seed=rank)
   params = list(net.parameters())
@@ -230,13 +284,20 @@ def main():
       torch.distributed.barrier()
     torch.cuda.synchronize()
 
-  for _ in range(args.warmup):
-    last = step()
+  run = step
+  if use_graph:
+    from iic_amd.graph import CapturedStep
+    run = CapturedStep(step, warmup=max(1, args.warmup))    # warm-up steps are real steps
+  else:
+    for _ in range(args.warmup):
+      last = step()
   fence()
   t0 = time.perf_counter()
+  c0 = time.thread_time()
   for _ in range(args.steps):
-    last = step()
+    last = run()
   t_enq = time.perf_counter() - t0      # host time to enqueue the K steps (no sync inside)
+  c_enq = time.thread_time() - c0
   fence()
   dt = time.perf_counter() - t0
   # Roofline of the conv kernels: HIP events around every conv launch, on the launch stream, in
@@ -252,6 +313,9 @@ def main():
     fence()
     if timer is not None:
       timer.uninstall()
+  ref_api = None
+  if world == 1 and not args.no_reference_api:
+    ref_api = reference_api_rate(cfg, dev, imgs, imgs_tf, args.pairs, args.steps)
   loss_val = float(last.detach())
   if world > 1:
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -272,7 +336,9 @@ def main():
                              "stem+heads+loss, fused HIP Adam" % args.pairs,
                  "global_batch_pairs": args.pairs * world, "input": "96x96x1 grey -> sobel 2ch",
                  "parallelism": "dp%d" % world, "final_loss": loss_val,
-                 "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps},
+                 "launch": "hip-graph replay" if use_graph else "eager (python/ctypes)",
+                 "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps,
+                 "host_cpu_ms_per_step": 1e3 * c_enq / args.steps},
     }
     if timer is not None:
       s = timer.summary()
@@ -289,6 +355,8 @@ def main():
           "step_algorithmic_tflops": value / world * FLOP_PER_PAIR / 1e12,
           "step_frac_of_peak": value / world * FLOP_PER_PAIR / 1e12 / BF16_PEAK_TFLOPS,
         }
+    if ref_api is not None:
+      out["config"]["reference_api"] = ref_api
     if world == 1 and not args.no_cpu_baseline:
       out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out))

@@ -88,6 +88,8 @@ _SIGNATURES = {
   "iic_colsum_f32": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
   "iic_adam_step": (c_int, [c_int, POINTER(_P), POINTER(_P), POINTER(_P), POINTER(_P), POINTER(c_long),
                             c_float, c_float, c_float, c_float, c_int, _P]),
+  "iic_adam_step_dev": (c_int, [c_int, POINTER(_P), POINTER(_P), POINTER(_P), POINTER(_P), POINTER(c_long),
+                                c_float, c_float, c_float, c_float, _P, _P]),
   "iic_probe_tr16": (c_int, [_P, _P]),
 }
 

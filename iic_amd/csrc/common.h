@@ -22,6 +22,24 @@ static inline int iic_launch_status() {
   return e == hipSuccess ? IIC_OK : IIC_ERR_LAUNCH;
 }
 
+// Zero-fill as a KERNEL node rather than hipMemsetAsync: inside a captured HIP graph, ROCm 7.0's
+// packet-capture replay did not keep a small memset node ordered before the kernel that follows
+// it (measured: the stem's 64-float accumulator kept its previous contents from the second replay
+// on -- tools/graph_debug2.py); a kernel node is ordered like every other launch.
+static __global__ void iic_zero_words_kernel(uint32_t* __restrict__ p, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    p[i] = 0u;
+}
+static inline int iic_zero_async(void* p, size_t bytes, hipStream_t s) {
+  if (bytes & 3) return IIC_ERR_ARG;
+  const long n = (long)(bytes >> 2);
+  long g = (n + 255) / 256;
+  if (g > 1024) g = 1024;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(iic_zero_words_kernel, dim3((unsigned)g), dim3(256), 0, s, (uint32_t*)p, n);
+  return IIC_OK;
+}
+
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) {
   return __uint_as_float(((uint32_t)v) << 16);
 }

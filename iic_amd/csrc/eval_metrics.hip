@@ -48,7 +48,7 @@ int iic_contingency(const long long* preds, const long long* targets, long n, in
   if (!preds || !targets || !counts || n < 0 || k_pred <= 0 || k_gt <= 0) return IIC_ERR_ARG;
   if ((long)k_pred * k_gt > EV_MAXBINS) return IIC_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(counts, 0, sizeof(long long) * k_pred * k_gt, s) != hipSuccess) return IIC_ERR_LAUNCH;
+  if (iic_zero_async(counts, sizeof(long long) * k_pred * k_gt, s) != IIC_OK) return IIC_ERR_LAUNCH;
   if (n == 0) return IIC_OK;
   long blocks = (n + 255) / 256;
   int grid = (int)(blocks < 1024 ? blocks : 1024);
@@ -60,7 +60,7 @@ int iic_contingency(const long long* preds, const long long* targets, long n, in
 int iic_count_equal(const long long* a, const long long* b, long n, long long* count, void* stream) {
   if (!a || !b || !count || n < 0) return IIC_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(count, 0, sizeof(long long), s) != hipSuccess) return IIC_ERR_LAUNCH;
+  if (iic_zero_async(count, sizeof(long long), s) != IIC_OK) return IIC_ERR_LAUNCH;
   if (n == 0) return IIC_OK;
   long blocks = (n + 255) / 256;
   int grid = (int)(blocks < 1024 ? blocks : 1024);

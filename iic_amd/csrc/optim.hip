@@ -35,6 +35,73 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTable t, float beta
   }
 }
 
+// Device-side step count: `steps_done` (int32 in HBM) holds the number of updates already applied
+// to this group of tensors; the bias corrections are derived from it on the device (same double
+// arithmetic as the host variant), so the launch arguments never change from step to step and
+// the whole optimiser step can live in a captured HIP graph.  adam_count_kernel bumps the
+// counter after the last chunk of the group.
+__global__ __launch_bounds__(256) void adam_dev_kernel(const AdamTable t, float lr, float beta1,
+                                                       float beta2, float eps,
+                                                       const int* __restrict__ steps_done) {
+  const double step = (double)(steps_done[0] + 1);
+  const double bc1 = 1.0 - pow((double)beta1, step);
+  const double bc2 = 1.0 - pow((double)beta2, step);
+  const float step_size = (float)((double)lr / bc1);
+  const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  const int ti = blockIdx.y;
+  float* __restrict__ p = t.p[ti];
+  const float* __restrict__ g = t.g[ti];
+  float* __restrict__ m = t.m[ti];
+  float* __restrict__ v = t.v[ti];
+  const long n = t.n[ti];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+    p[i] -= step_size * (mi / denom);
+  }
+}
+__global__ void adam_count_kernel(int* steps_done) { steps_done[0] += 1; }
+
+static void adam_fill_table(AdamTable& t, int base, int n, float* const* params,
+                            const float* const* grads, float* const* exp_avg,
+                            float* const* exp_avg_sq, const long* numel, int* cnt_out, long* gx_out) {
+  const int cnt = (n - base) < ADAM_CHUNK ? (n - base) : ADAM_CHUNK;
+  long maxn = 0;
+  for (int i = 0; i < ADAM_CHUNK; ++i) {
+    const int j = i < cnt ? base + i : base;   // pad with a duplicate of n == 0 work
+    t.p[i] = params[j]; t.g[i] = grads[j]; t.m[i] = exp_avg[j]; t.v[i] = exp_avg_sq[j];
+    t.n[i] = i < cnt ? numel[j] : 0;
+    if (t.n[i] > maxn) maxn = t.n[i];
+  }
+  long gx = (maxn + 255) / 256;
+  if (gx > 256) gx = 256;
+  if (gx < 1) gx = 1;
+  *cnt_out = cnt;
+  *gx_out = gx;
+}
+
+extern "C" int iic_adam_step_dev(int n, float* const* params, const float* const* grads,
+                                 float* const* exp_avg, float* const* exp_avg_sq, const long* numel,
+                                 float lr, float beta1, float beta2, float eps, int* steps_done,
+                                 void* stream) {
+  if (n <= 0 || !params || !grads || !exp_avg || !exp_avg_sq || !numel || !steps_done)
+    return IIC_ERR_ARG;
+  for (int base = 0; base < n; base += ADAM_CHUNK) {
+    AdamTable t;
+    int cnt;
+    long gx;
+    adam_fill_table(t, base, n, params, grads, exp_avg, exp_avg_sq, numel, &cnt, &gx);
+    hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)gx, cnt), dim3(256), 0, (hipStream_t)stream,
+                       t, lr, beta1, beta2, eps, (const int*)steps_done);
+  }
+  hipLaunchKernelGGL(adam_count_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, steps_done);
+  return iic_launch_status();
+}
+
 extern "C" int iic_adam_step(int n, float* const* params, const float* const* grads,
                              float* const* exp_avg, float* const* exp_avg_sq, const long* numel,
                              float lr, float beta1, float beta2, float eps, int step, void* stream) {

@@ -652,7 +652,7 @@ int iic_stem_bwd_fused(const float* x, const float* w, const float* coef, const 
   int grid = (int)(items < STEM_PERSIST_BLOCKS ? items : STEM_PERSIST_BLOCKS);
   *nblocks_out = grid;
   float* g3 = partials + (long)STEM_PERSIST_BLOCKS * 128 * 64;
-  if (hipMemsetAsync(g3, 0, 64 * sizeof(float), (hipStream_t)stream) != hipSuccess) return IIC_ERR_LAUNCH;
+  if (iic_zero_async(g3, 64 * sizeof(float), (hipStream_t)stream) != IIC_OK) return IIC_ERR_LAUNCH;
   hipLaunchKernelGGL(stem_patch_sums_kernel, dim3(512, Cin), dim3(256), 0, (hipStream_t)stream, x, g3, N,
                      Cin, H, W);
   if (g_stem_bwd2 && iic_stem_bwd2_supported(Cin, W))      // register-resident routing (stem_bwd2.hip)

@@ -4,6 +4,12 @@ Drop-in for ``torch.optim.Adam(params, lr=...)`` as the reference uses it
 (/root/reference/code/utils/cluster/general.py:5-9, cluster_sobel.py:149,272): default
 betas (0.9, 0.999), eps 1e-8, no weight decay / amsgrad.  ``param_groups[i]['lr']`` can be
 scaled in place exactly like update_lr() does (general.py:20-23).
+
+``state[p]['step']`` is a Python int (torch.optim.Adam checkpoints, which store it as a tensor,
+are normalised on load and on first use).  ``capturable=True`` keeps the step count in device
+memory instead (one int32 counter shared by all tensors that have always been updated together)
+so that the launch arguments never change and ``step()`` can be captured in a HIP graph
+(iic_amd.graph.CapturedStep); ``state[p]['step']`` then reads that counter.
 """
 import ctypes
 
@@ -13,9 +19,94 @@ from ._lib import check, lib, stream_ptr
 from .archs.cluster import bump_weights_epoch
 
 
+def _as_int(step):
+  if torch.is_tensor(step):
+    return int(round(float(step)))
+  return int(step)
+
+
 class Adam(torch.optim.Optimizer):
-  def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+  def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False,
+               capturable=False):
+    if weight_decay != 0 or amsgrad:
+      raise NotImplementedError("iic_amd.optim.Adam: weight_decay / amsgrad are not used by the "
+                                "reference (general.py:5-9) and are not implemented")
     super(Adam, self).__init__(params, dict(lr=lr, betas=betas, eps=eps))
+    self.capturable = bool(capturable)
+    self._members = {}     # id(counter tensor) -> (counter, set of param ids sharing it)
+
+  # ---- checkpoint compatibility with torch.optim.Adam (step stored as a tensor there) ----
+  def load_state_dict(self, state_dict):
+    super(Adam, self).load_state_dict(state_dict)
+    self._members = {}
+    for st in self.state.values():
+      if "step" in st:
+        st["step"] = _as_int(st["step"])
+      st.pop("_counter", None)
+
+  def state_dict(self):
+    if self.capturable:
+      self._sync_steps_to_host()
+    sd = super(Adam, self).state_dict()
+    # (the per-parameter dicts are the live ones: copy before dropping the private entry)
+    sd["state"] = {k: {n: v for n, v in st.items() if n != "_counter"}
+                   for k, st in sd["state"].items()}
+    return sd
+
+  def _sync_steps_to_host(self):
+    for st in self.state.values():
+      c = st.get("_counter")
+      if c is not None:
+        st["step"] = int(c.item())
+
+  def _init_state(self, p):
+    st = self.state[p]
+    if "exp_avg" not in st:
+      st["step"] = 0
+      st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+      st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+    elif not isinstance(st["step"], int):
+      st["step"] = _as_int(st["step"])
+    assert p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
+    if not p.grad.is_contiguous():
+      p.grad = p.grad.contiguous()
+    return st
+
+  @staticmethod
+  def _tables(grp, state):
+    n = len(grp)
+    VP = ctypes.c_void_p * n
+    LP = ctypes.c_long * n
+    return (n, VP(*[p.data_ptr() for p in grp]), VP(*[p.grad.data_ptr() for p in grp]),
+            VP(*[state[p]["exp_avg"].data_ptr() for p in grp]),
+            VP(*[state[p]["exp_avg_sq"].data_ptr() for p in grp]),
+            LP(*[p.numel() for p in grp]))
+
+  def _counter_groups(self, ps):
+    """Capturable mode: partition `ps` into groups that share one device step counter.  A
+    counter is split (host work, first occurrence of a new update pattern only) when just a
+    part of its tensors receives a gradient -- e.g. head A / head B of a two-head net."""
+    by = {}
+    for p in ps:
+      st = self.state[p]
+      c = st.get("_counter")
+      by.setdefault(("dev", id(c)) if c is not None else ("host", st["step"]), []).append(p)
+    groups = []
+    for key, grp in by.items():
+      if key[0] == "host":
+        c = torch.full((1,), key[1], dtype=torch.int32, device=grp[0].device)
+        self._members[id(c)] = (c, set(id(p) for p in grp))
+      else:
+        c, members = self._members[key[1]]
+        ids = set(id(p) for p in grp)
+        if ids != members:
+          members -= ids
+          c = c.clone()
+          self._members[id(c)] = (c, ids)
+      for p in grp:
+        self.state[p]["_counter"] = c
+      groups.append((c, grp))
+    return groups
 
   @torch.no_grad()
   def step(self, closure=None):
@@ -28,14 +119,14 @@ class Adam(torch.optim.Optimizer):
       if not ps:
         continue
       for p in ps:
-        st = self.state[p]
-        if not st:
-          st["step"] = 0
-          st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-          st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-        assert p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
-        if not p.grad.is_contiguous():
-          p.grad = p.grad.contiguous()
+        self._init_state(p)
+      hyper = (float(group["lr"]), float(group["betas"][0]), float(group["betas"][1]),
+               float(group["eps"]))
+      if self.capturable:
+        for counter, grp in self._counter_groups(ps):
+          check(lib().iic_adam_step_dev(*self._tables(grp, self.state), *hyper,
+                                        counter.data_ptr(), stream_ptr()), "iic_adam_step_dev")
+        continue
       # torch.optim.Adam keeps a step count PER PARAMETER: a two-head net only produces
       # gradients for the head that was used (net5g_two_head.py:62-81), so head-A and head-B
       # parameters advance at different rates.  One fused launch per distinct step count.
@@ -44,15 +135,8 @@ class Adam(torch.optim.Optimizer):
         by_step.setdefault(self.state[p]["step"], []).append(p)
       for step0, grp in by_step.items():
         step = step0 + 1
-        n = len(grp)
-        VP = ctypes.c_void_p * n
-        LP = ctypes.c_long * n
-        check(lib().iic_adam_step(
-          n, VP(*[p.data_ptr() for p in grp]), VP(*[p.grad.data_ptr() for p in grp]),
-          VP(*[self.state[p]["exp_avg"].data_ptr() for p in grp]),
-          VP(*[self.state[p]["exp_avg_sq"].data_ptr() for p in grp]),
-          LP(*[p.numel() for p in grp]), float(group["lr"]), float(group["betas"][0]),
-          float(group["betas"][1]), float(group["eps"]), step, stream_ptr()), "iic_adam_step")
+        check(lib().iic_adam_step(*self._tables(grp, self.state), *hyper, step, stream_ptr()),
+              "iic_adam_step")
         for p in grp:
           self.state[p]["step"] = step
     bump_weights_epoch()

@@ -268,6 +268,13 @@ int iic_colsum_f32(const float* A, float* out, int rows, int cols, int accumulat
 int iic_adam_step(int n, float* const* params, const float* const* grads, float* const* exp_avg,
                   float* const* exp_avg_sq, const long* numel, float lr, float beta1, float beta2,
                   float eps, int step, void* stream);
+/* Same update with the step count kept on the DEVICE: `steps_done` (int32) = updates already
+ * applied to these tensors; the kernel derives the bias corrections from it and a trailing
+ * 1-thread kernel increments it.  No launch argument changes between steps, so the optimiser
+ * step can be part of a captured HIP graph (iic_amd.graph).                                  */
+int iic_adam_step_dev(int n, float* const* params, const float* const* grads, float* const* exp_avg,
+                      float* const* exp_avg_sq, const long* numel, float lr, float beta1, float beta2,
+                      float eps, int* steps_done, void* stream);
 
 /* one-time device probes used by the test-suite (documented in DESIGN.md) */
 int iic_probe_tr16(void* out_u16_64x4, void* stream);
