@@ -47,7 +47,7 @@ def _side_stream(device):
   return st
 
 
-SHARD_INPUTS = [False]  # set by iic_amd.run under torchrun: forward keeps only this rank's rows
+from ..dist import SHARD_INPUTS, shard_batch  # noqa: E402  (set by iic_amd.run under torchrun)
 # Replica de-duplication (opt-in: IIC_DEDUP=<r> or DEDUP[0] = r).  The reference
 # replicates imgs_curr num_dataloaders times in all_imgs (cluster_sobel.py:215-226).  When a training
 # batch consists of r exact copies of its first B/r rows, the trunk runs on those rows only and
@@ -466,10 +466,7 @@ class ClusterNet5gTrunk(nn.Module):
     return nn.Sequential(*layers)
 
   def forward(self, x, penultimate_features=False):
-    if SHARD_INPUTS[0]:
-      from .. import dist as idist
-      lo, hi = idist.shard_rows(x.size(0))
-      x = x[lo:hi]
+    x = shard_batch(x, self)
     r = DEDUP[0]
     if r > 1 and self.training and x.size(0) % r == 0 and x.size(0) >= 2 * r:
       u = x.size(0) // r

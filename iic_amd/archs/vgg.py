@@ -15,6 +15,7 @@ import torch.nn as nn
 
 from .. import geom as G
 from .. import ops
+from ..dist import shard_batch
 from .cluster import _ConvHolder, _HeadsFn, _bn_buffers, _bn_training
 
 __all__ = ["ClusterNet6c", "ClusterNet6cTwoHead"]
@@ -170,6 +171,7 @@ class VGGTrunkHIP(nn.Module):
     self._stages = stages
 
   def run_stages(self, x):
+    x = shard_batch(x, self)          # unchanged scripts under torchrun: this rank's pairs only
     for st in self._stages:
       x = _StageFn.apply(x, st.conv.weight, st.bn.weight, st.bn.bias, st)
     return x

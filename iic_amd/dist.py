@@ -56,6 +56,42 @@ def shard_rows(n_rows, r=None, w=None):
   return lo, min(n_rows, lo + per)
 
 
+# Set by iic_amd.run under torchrun: the unchanged reference scripts build the FULL batch on every
+# rank (their loaders know nothing about ranks), so every architecture's forward keeps only this
+# rank's contiguous rows -- in TRAINING forwards only.  Evaluation (net.eval() / torch.no_grad():
+# cluster_eval._clustering_get_data writes bs rows of predictions per batch) runs the whole
+# batch on every rank.
+SHARD_INPUTS = [False]
+
+
+def shard_batch(x, module):
+  """Rows [lo, hi) of `x` owned by this rank when input sharding is on and `module` is in a
+  training forward; `x` itself otherwise."""
+  if SHARD_INPUTS[0] and enabled() and module.training and torch.is_grad_enabled():
+    lo, hi = shard_rows(x.size(0))
+    return x[lo:hi]
+  return x
+
+
+def shard_like(t, n_local):
+  """Per-sample side inputs of a loss (masks, affine matrices) arrive for the FULL batch from
+  the unchanged script while the network outputs are already sharded: slice them to match."""
+  if SHARD_INPUTS[0] and enabled() and t is not None and t.size(0) != n_local:
+    lo, hi = shard_rows(t.size(0))
+    assert hi - lo == n_local, "side input does not match this rank's shard"
+    return t[lo:hi]
+  return t
+
+
+def broadcast_module_state(module, src=0):
+  """Identical parameters AND buffers on every rank (the scripts seed nothing)."""
+  if not enabled():
+    return
+  with torch.no_grad():
+    for t in list(module.parameters()) + list(module.buffers()):
+      dist.broadcast(t.data, src, group=_STATE["group"])
+
+
 def all_reduce_grads(params, bucket_bytes=64 << 20):
   """SUM all-reduce of .grad over ranks in flat buckets (xGMI ring collectives are per-link
   bound: few large messages, not one per tensor).  Grads are copied into/out of a flat

@@ -5,11 +5,14 @@ The reference's training scripts bind their hot-path operators by name at import
     from code.utils.cluster.IID_losses import IID_loss          (cluster_sobel.py:21)
     from code.utils.cluster.transforms import sobel_process     (cluster_sobel.py:19)
     import code.archs as archs ; archs.__dict__[config.arch](config)   (:17,140)
-``install()`` imports those reference modules (they must be importable, i.e. the reference
-tree is on sys.path and its own dependencies are present) and rebinds exactly these names to
-the MI355X implementations; everything else in the reference keeps running as is.
-``python -m iic_amd.run <reference script module> [args...]`` = py2->py3 shims + install()
-+ run the unchanged script.
+    from code.utils.cluster.general import get_opt ; get_opt("Adam")   (:18,149)
+``install()`` makes the (Python-2) reference tree importable under Python 3
+(``iic_amd.py2compat.enable``), imports those reference modules and rebinds exactly these
+names to the MI355X implementations; everything else in the reference keeps running as is.
+It is STRICT by default: a name that cannot be rebound raises, so a run can never silently
+train on the reference's own PyTorch modules.
+``python -m iic_amd.run <reference script module> [args...]`` = install() + run the unchanged
+script.
 """
 import importlib
 import sys
@@ -37,34 +40,60 @@ PATCHES = [
   ("code.utils.cluster.cluster_eval", "_original_match", "iic_amd.eval_metrics", "_original_match"),
   ("code.utils.cluster.cluster_eval", "_hungarian_match", "iic_amd.eval_metrics", "_hungarian_match"),
   ("code.utils.cluster.cluster_eval", "_acc", "iic_amd.eval_metrics", "_acc"),
+  # cluster_eval.py:10,12 and segmentation_eval.py:9 bind the loss / Sobel by name as well
+  ("code.utils.cluster.cluster_eval", "IID_loss", "iic_amd.losses", "IID_loss"),
+  ("code.utils.cluster.cluster_eval", "sobel_process", "iic_amd.transforms", "sobel_process"),
+  ("code.utils.segmentation.segmentation_eval", "sobel_process", "iic_amd.transforms", "sobel_process"),
   ("code.utils.segmentation.IID_losses", "IID_segmentation_loss", "iic_amd.seg_losses", "IID_segmentation_loss"),
   ("code.utils.segmentation.IID_losses", "IID_segmentation_loss_uncollapsed", "iic_amd.seg_losses",
    "IID_segmentation_loss_uncollapsed"),
+  # optimiser: get_opt("Adam") (general.py:5-9) -> the fused multi-tensor HIP Adam
+  ("code.utils.cluster.general", "Adam", "iic_amd.optim", "Adam"),
 ]
 
 
 def py2_shims():
   """Names the Python-2 reference uses that Python 3 dropped (SURVEY.md §8b last row)."""
-  import builtins
-  import itertools
-  if not hasattr(builtins, "xrange"):
-    builtins.xrange = range
-  if not hasattr(itertools, "izip"):
-    itertools.izip = zip
+  from . import py2compat
+  py2compat.py2_builtins()
 
 
-def install(strict=False):
-  """Rebind the reference's hot-path names. Returns the list of (module, attr) patched."""
+def install(strict=True, reference_root=None, py2=True):
+  """Rebind the reference's hot-path names. Returns the list of (module, attr) patched.
+
+  py2=True first installs the Python-2 import hook for the reference tree (found through
+  `reference_root`, $IIC_REFERENCE or sys.path).  strict=False only reports names that could not
+  be rebound (stderr) instead of raising -- for partial trees in tests."""
+  if py2:
+    from . import py2compat
+    try:
+      py2compat.enable(reference_root)
+    except ImportError:
+      if strict:
+        raise
+      py2compat.py2_builtins()
   done = []
   for ref_mod, attr, our_mod, our_attr in PATCHES:
     try:
       m = importlib.import_module(ref_mod)
+      if not hasattr(m, attr):
+        raise AttributeError("reference module %s has no attribute %s" % (ref_mod, attr))
     except Exception as e:   # reference module (or one of its deps) not importable here
       if strict:
-        raise
+        raise ImportError("iic_amd.install: cannot rebind %s.%s (%s: %s)" %
+                          (ref_mod, attr, type(e).__name__, e)) from e
       sys.stderr.write("[iic_amd.install] skip %s.%s (%s)\n" % (ref_mod, attr, e))
       continue
     ours = getattr(importlib.import_module(our_mod), our_attr)
     setattr(m, attr, ours)
     done.append((ref_mod, attr))
+  # get_opt() looks the class up in a module-level dict (general.py:5-9)
+  gen = sys.modules.get("code.utils.cluster.general")
+  if gen is not None and ("code.utils.cluster.general", "Adam") in done:
+    table = getattr(gen, "_opt_dict", None)
+    if isinstance(table, dict):
+      table["Adam"] = gen.Adam
+      done.append(("code.utils.cluster.general", "_opt_dict['Adam']"))
+    elif strict:
+      raise ImportError("iic_amd.install: code.utils.cluster.general._opt_dict not found")
   return done

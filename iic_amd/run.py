@@ -1,38 +1,103 @@
-"""python -m iic_amd.run code.scripts.cluster.cluster_sobel --model_ind ... : run an
-UNCHANGED reference training script on the HIP hot path (one process per GPU; for N GPUs
-launch under torchrun -- the script's torch.nn.DataParallel degenerates to a plain call with
-one visible device and iic_amd.dist shards the batch by pair)."""
+"""python -m iic_amd.run code.scripts.cluster.cluster_sobel --model_ind ... : run an UNCHANGED
+reference training script (Python-2 source, read where it lies) on the HIP hot path.
+
+  1. iic_amd.py2compat.enable(root): import hook that translates the reference's Python-2
+     modules in memory (root = $IIC_REFERENCE or the sys.path / PYTHONPATH entry holding code/);
+  2. iic_amd.install.install(strict=True): rebind the hot-path names (losses, sobel_process,
+     architectures, evaluation matching, Adam) -- raises if any of them cannot be rebound;
+  3. N > 1 (launched under torchrun, one process per GPU): `setup_distributed()`;
+  4. execute the script module as __main__.
+
+Multi-GPU semantics for the unchanged scripts: every rank's loaders produce
+the full batch; each architecture's TRAINING forward keeps this rank's contiguous rows (pairs
+stay together: both views are sliced identically), evaluation forwards run the whole batch on
+every rank; the losses all-reduce the raw joint; parameter gradients are SUM-all-reduced right
+before every optimiser step; every rank constructs identical initial weights (the scripts seed
+nothing: construction runs under a fixed forked RNG seed, $IIC_INIT_SEED) and only rank 0
+writes checkpoints.  The script's torch.nn.DataParallel degenerates to a plain call with one
+visible device.
+"""
 import os
-import runpy
 import sys
 
+torch_save_orig = None     # torch.save before setup_distributed() replaced it on ranks > 0
 
-def main():
-  if len(sys.argv) < 2:
+ARCH_NAMES = ("ClusterNet5g", "ClusterNet5gTwoHead", "ClusterNet6c", "ClusterNet6cTwoHead",
+              "SegmentationNet10a", "SegmentationNet10aTwoHead")
+
+
+def _seeded_constructor(cls, seed):
+  """Subclass whose construction (weight init) runs under a fixed RNG seed, restoring the
+  global RNG afterwards: identical initial parameters on every rank without communication
+  (parameters are still on the CPU when the script constructs the net, cluster_sobel.py:140)."""
+  import torch
+
+  class Seeded(cls):
+    def __init__(self, *a, **k):
+      with torch.random.fork_rng(devices=[]):
+        torch.manual_seed(seed)
+        super(Seeded, self).__init__(*a, **k)
+  Seeded.__name__ = cls.__name__
+  Seeded.__qualname__ = cls.__qualname__
+  Seeded.__module__ = cls.__module__
+  return Seeded
+
+
+def setup_distributed(backend="nccl", ref_modules=("code.archs", "code.archs.cluster",
+                                                   "code.archs.segmentation")):
+  """Everything `main` does for WORLD_SIZE > 1, callable on its own (the world-size-2 gloo test
+  drives it on CPU stand-ins).  torch.distributed must be initialised; install() must have run
+  if reference modules are to be re-pointed at the seeded constructors."""
+  import torch
+  import torch.distributed as dist
+  from torch.optim.optimizer import register_optimizer_step_pre_hook
+
+  from . import dist as idist
+  assert dist.is_initialized()
+  idist.enable()
+  idist.SHARD_INPUTS[0] = True
+
+  def _allreduce_hook(opt, args, kwargs):
+    idist.all_reduce_grads([p for g in opt.param_groups for p in g["params"]])
+  handle = register_optimizer_step_pre_hook(_allreduce_hook)
+
+  seed = int(os.environ.get("IIC_INIT_SEED", "0"))
+  for mname in ref_modules:
+    m = sys.modules.get(mname)
+    if m is None:
+      continue
+    for n in ARCH_NAMES:
+      cls = getattr(m, n, None)
+      if isinstance(cls, type) and not getattr(cls, "_iic_seeded", False):
+        s = _seeded_constructor(cls, seed)
+        s._iic_seeded = True
+        setattr(m, n, s)
+  global torch_save_orig
+  if torch_save_orig is None:
+    torch_save_orig = torch.save
+  if dist.get_rank() != 0:
+    # identical replicas: one writer is enough (and concurrent writers would corrupt the files)
+    torch.save = lambda *a, **k: None
+  return handle
+
+
+def main(argv=None):
+  argv = list(sys.argv[1:] if argv is None else argv)
+  if not argv:
     sys.exit("usage: python -m iic_amd.run <reference.script.module> [script args...]")
-  from .install import install, py2_shims
-  py2_shims()
+  from . import py2compat
+  from .install import install
+  install(strict=True)
   if int(os.environ.get("WORLD_SIZE", "1")) > 1:
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-    dist.init_process_group("nccl")
-    from . import dist as idist
-    from .archs import cluster as _cl
-    idist.enable()
-    # every rank's data loaders produce the full batch (the scripts are unchanged): keep this
-    # rank's contiguous rows (pairs stay together: both views are sliced identically) ...
-    _cl.SHARD_INPUTS[0] = True
-    # ... and SUM-all-reduce the parameter gradients right before any optimiser step.
-    from torch.optim.optimizer import register_optimizer_step_pre_hook
-
-    def _allreduce_hook(opt, args, kwargs):
-      idist.all_reduce_grads([p for g in opt.param_groups for p in g["params"]])
-    register_optimizer_step_pre_hook(_allreduce_hook)
-  install()
-  target = sys.argv[1]
-  sys.argv = sys.argv[1:]
-  runpy.run_module(target, run_name="__main__", alter_sys=True)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(os.environ.get("IIC_DIST_BACKEND", "nccl"))
+    setup_distributed()
+  target = argv[0]
+  sys.argv = argv
+  py2compat.run_script(target)
 
 
 if __name__ == "__main__":

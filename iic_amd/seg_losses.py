@@ -90,6 +90,9 @@ def _seg_loss(x1_outs, x2_outs, all_affine2_to_1, all_mask_img1, lamb, half_T_si
   if (half_T_side_sparse_min != 0) or (half_T_side_sparse_max != 0):
     raise NotImplementedError("sparse random translation (half_T_side_sparse_*) is off in every "
                               "published run and not implemented on the HIP path")
+  # unchanged scripts under torchrun hand over full-batch masks / affines with sharded outputs
+  all_affine2_to_1 = iic_dist.shard_like(all_affine2_to_1, x1_outs.size(0))
+  all_mask_img1 = iic_dist.shard_like(all_mask_img1, x1_outs.size(0))
   flips = _flips_from_affine(all_affine2_to_1).to(x1_outs.device)
   T = int(half_T_side_dense)
   loss, loss_nl = _SegLossFn.apply(x1_outs, x2_outs, flips, all_mask_img1, lamb, T, collapsed)
