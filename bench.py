@@ -189,6 +189,9 @@ def main():
   ap.add_argument("--no-graph", action="store_true",
                   help="issue every launch of the timed steps from Python (eager) instead of replaying "
                        "the step as one captured HIP graph (iic_amd.graph.CapturedStep; N=1 default)")
+  ap.add_argument("--no-branch", action="store_true",
+                  help="run the two views one after the other on one stream instead of as two "
+                       "concurrent branches of the step graph (iic_amd.ops.branch)")
   ap.add_argument("--no-reference-api", action="store_true",
                   help="skip the second measurement through the reference's own call sequence "
                        "(net(x) -> list, IID_loss per sub-head, torch.optim.Adam; reported in config)")
@@ -218,7 +221,7 @@ def main():
     idist.enable()
   assert args.gpus == world or world == 1, "launch with torchrun --nproc-per-node == --gpus"
 
-  from iic_amd import archs, dist as idist
+  from iic_amd import archs, dist as idist, ops
   from iic_amd.losses import IID_loss_heads
   from iic_amd.optim import Adam
   from iic_amd.transforms import sobel_process
@@ -235,6 +238,9 @@ def main():
   # ~1100 from Python.  N > 1 keeps eager launches (RCCL collectives sit between the kernels).
   use_graph = world == 1 and not args.no_graph and not args.with_augment
   opt = Adam(net.parameters(), lr=1e-4, capturable=use_graph)
+  # the second view (net(all_imgs_tf)) as a parallel graph branch: same kernels and arithmetic,
+  # the tail of one view's launch is filled by the other view's next launch
+  use_branch = use_graph and not args.no_branch
   # weak scaling: every rank owns `pairs` pairs (its shard of the global batch of pairs*world)
   imgs, imgs_tf = make_batch(args.pairs, INPUT_SZ, dev, seed=rank)
   params = list(net.parameters())
@@ -264,10 +270,14 @@ def main():
   def step():
     net.zero_grad(set_to_none=True)
     bi, bt = next_batch() if aug is not None else (imgs, imgs_tf)
-    a = sobel_process(bi, False)
-    b = sobel_process(bt, False)
-    xo = net.forward_packed(a)
-    xt = net.forward_packed(b)
+    if use_branch:
+      with ops.branch():
+        xt = net.forward_packed(sobel_process(bt, False))
+      xo = net.forward_packed(sobel_process(bi, False))
+      ops.join()
+    else:
+      xo = net.forward_packed(sobel_process(bi, False))
+      xt = net.forward_packed(sobel_process(bt, False))
     loss, _ = IID_loss_heads(xo, xt, lamb=1.0)
     loss = loss.mean()
     loss.backward()
@@ -336,7 +346,8 @@ def main():
                              "stem+heads+loss, fused HIP Adam" % args.pairs,
                  "global_batch_pairs": args.pairs * world, "input": "96x96x1 grey -> sobel 2ch",
                  "parallelism": "dp%d" % world, "final_loss": loss_val,
-                 "launch": "hip-graph replay" if use_graph else "eager (python/ctypes)",
+                 "launch": ("hip-graph replay, two view branches" if use_branch else "hip-graph replay")
+                           if use_graph else "eager (python/ctypes)",
                  "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps,
                  "host_cpu_ms_per_step": 1e3 * c_enq / args.steps},
     }

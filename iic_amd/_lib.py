@@ -55,6 +55,9 @@ _SIGNATURES = {
   "iic_conv_igemm_frag": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P, _P, _P, c_int, _P]),
   "iic_weight_prep_frag": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
   "iic_bn_finalize": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_long, c_long, c_float, c_float, c_int, _P]),
+  "iic_stat_bytes": (c_long, [c_int]),
+  "iic_bn_running_update": (c_int, [c_int, POINTER(_P), POINTER(_P), POINTER(_P), POINTER(_P), POINTER(c_int),
+                                    c_float, _P]),
   "iic_bn_apply": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
   "iic_bn_bwd_reduce": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
   "iic_bn_bwd_finalize": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_long, _P]),
@@ -86,9 +89,9 @@ _SIGNATURES = {
   "iic_softmax_fwd": (c_int, [_P, _P, c_int, c_int, _P]),
   "iic_softmax_bwd": (c_int, [_P, _P, _P, c_int, c_int, _P]),
   "iic_colsum_f32": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
-  "iic_adam_step": (c_int, [c_int, POINTER(_P), POINTER(_P), POINTER(_P), POINTER(_P), POINTER(c_long),
+  "iic_adam_step": (c_int, [c_int, POINTER(_P), POINTER(_P), POINTER(_P), POINTER(_P), POINTER(_P), POINTER(c_long),
                             c_float, c_float, c_float, c_float, c_int, _P]),
-  "iic_adam_step_dev": (c_int, [c_int, POINTER(_P), POINTER(_P), POINTER(_P), POINTER(_P), POINTER(c_long),
+  "iic_adam_step_dev": (c_int, [c_int, POINTER(_P), POINTER(_P), POINTER(_P), POINTER(_P), POINTER(_P), POINTER(c_long),
                                 c_float, c_float, c_float, c_float, _P, _P]),
   "iic_probe_tr16": (c_int, [_P, _P]),
 }

@@ -84,16 +84,26 @@ class _ConvHolder(object):
                            conv.stride[0], conv.padding[0], conv.dilation[0])
     self._wkey = None
     self._w = None
+    self._wbranch = {}
     self._geoms = {}
     self._stats = {}
 
   def weights(self):
+    # (one operand set per branch: a side branch must not read operands whose layout kernels
+    # were enqueued on the other stream)
     w = self.conv.weight
+    b = ops.BRANCH[0]
     key = (w.data_ptr(), w._version, _WEIGHTS_EPOCH[0])
-    if key != self._wkey:
-      self._w = ops.PreppedWeights(w.detach())
-      self._wkey = key
-    return self._w
+    if b == 0:
+      if key != self._wkey:
+        self._w = ops.PreppedWeights(w.detach())
+        self._wkey = key
+      return self._w
+    ent = self._wbranch.get(b)
+    if ent is None or ent[0] != key:
+      ent = (key, ops.PreppedWeights(w.detach()))
+      self._wbranch[b] = ent
+    return ent[1]
 
   def geoms(self, N, H, W):
     key = (N, H, W)
@@ -105,7 +115,7 @@ class _ConvHolder(object):
     return g
 
   def stats(self, device, which="fwd"):
-    key = (str(device), which)
+    key = (str(device), which, ops.BRANCH[0])
     s = self._stats.get(key)
     if s is None:
       s = ops.new_stats(self.spec.cout, device)
@@ -154,10 +164,11 @@ class _StemFn(torch.autograd.Function):
     ops.stem_apply_pool(x, wd, coef, out)
     ctx.mod = mod
     ctx.training = training
+    ctx.branch = ops.BRANCH[0]
     ctx.save_for_backward(x, w, gamma, coef, out)
     return out
 
-  @staticmethod
+  @ops.branch_backward
   def backward(ctx, dpool):
     x, w, gamma, coef, out = ctx.saved_tensors
     if not ctx.training:
@@ -229,6 +240,7 @@ class _BlockFn(torch.autograd.Function):
 
     if need_grad:
       ctx.blk = blk
+      ctx.branch = ops.BRANCH[0]
       ctx.dims = (N, H, W, Ho, Wo, Cin, planes)
       ctx.bn_batch = (_bn_training(blk.bn1) and _bn_training(blk.bn2))
       # (set by the trunk for the duration of its sequential forward, see PREMASK)
@@ -239,7 +251,7 @@ class _BlockFn(torch.autograd.Function):
         ops.POOL.release(t)
     return out
 
-  @staticmethod
+  @ops.branch_backward
   def backward(ctx, dout):
     x, y1, a1, y2, out, yd, coef1, coef2, coefd, g1, g2, gd = ctx.saved_tensors
     blk = ctx.blk
@@ -349,10 +361,11 @@ class BasicBlock(nn.Module):
 
   def forward(self, x):
     ds = self.downsample
+    pv = ops.pv
     return _BlockFn.apply(
-      x, self.conv1.weight, self.bn1.weight, self.bn1.bias, self.conv2.weight, self.bn2.weight,
-      self.bn2.bias, ds[0].weight if ds is not None else None,
-      ds[1].weight if ds is not None else None, ds[1].bias if ds is not None else None, self)
+      x, pv(self.conv1.weight), pv(self.bn1.weight), pv(self.bn1.bias), pv(self.conv2.weight),
+      pv(self.bn2.weight), pv(self.bn2.bias), pv(ds[0].weight) if ds is not None else None,
+      pv(ds[1].weight) if ds is not None else None, pv(ds[1].bias) if ds is not None else None, self)
 
 
 # ------------------------------------------------------------------------------------
@@ -363,12 +376,13 @@ class _AvgPoolFn(torch.autograd.Function):
   def forward(ctx, x, premask):
     N, Hp, Wp, C = x.shape
     ctx.dims = (N, Hp - 2, Wp - 2, C)
+    ctx.branch = ops.BRANCH[0]
     ctx.premask = bool(premask)
     if premask:
       ctx.save_for_backward(x)      # its ReLU mask is applied to the gradient here (PREMASK)
     return ops.avgpool_fwd(x, N, Hp - 2, Wp - 2, 1, C)
 
-  @staticmethod
+  @ops.branch_backward
   def backward(ctx, dfeats):
     N, H, W, C = ctx.dims
     dx = ops.pt_alloc(N, H, W, C, 1, dfeats.device)
@@ -422,8 +436,8 @@ class ClusterNet5gHead(nn.Module):
 
   def forward_packed(self, feats):
     """probs [N, H, k] fp32 (all sub-heads, one GEMM)."""
-    Wcat = torch.cat([h[0].weight for h in self.heads], dim=0)
-    bcat = torch.cat([h[0].bias for h in self.heads], dim=0)
+    Wcat = torch.cat([ops.pv(h[0].weight) for h in self.heads], dim=0)
+    bcat = torch.cat([ops.pv(h[0].bias) for h in self.heads], dim=0)
     return _HeadsFn.apply(feats, Wcat, bcat, self.num_sub_heads, self.output_k)
 
   def forward(self, x, kmeans_use_features=False):
@@ -489,7 +503,7 @@ class ClusterNet5gTrunk(nn.Module):
       b._dout_premasked = chain
       b._mask_dx = chain and i > 0        # block 0's input gradient goes to the stem (own masking)
     try:
-      x = _StemFn.apply(x, self.conv1.weight, self.bn1.weight, self.bn1.bias, self)
+      x = _StemFn.apply(x, ops.pv(self.conv1.weight), ops.pv(self.bn1.weight), ops.pv(self.bn1.bias), self)
       x = self.layer1(x)
       x = self.layer2(x)
       x = self.layer3(x)

@@ -39,9 +39,10 @@ class _SegHeadFn(torch.autograd.Function):
     check(L.iic_bilinear_fwd(ptr(probs), ptr(out), N, Hw, Ww, k, S, s), "iic_bilinear_fwd")
     ctx.save_for_backward(Fm, W2, probs)
     ctx.meta = (tuple(x.shape), P, S, Hw, Ww, off, k)
+    ctx.branch = ops.BRANCH[0]
     return out
 
-  @staticmethod
+  @ops.branch_backward
   def backward(ctx, dout):
     Fm, W2, probs = ctx.saved_tensors
     shape, P, S, Hw, Ww, off, k = ctx.meta
@@ -92,7 +93,7 @@ class SegmentationNet10aHead(nn.Module):
     self.input_sz = config.input_sz
 
   def forward(self, x):
-    return [_SegHeadFn.apply(x, self.heads[i][0].weight, SegmentationNet10aTrunk.P, self.input_sz)
+    return [_SegHeadFn.apply(x, ops.pv(self.heads[i][0].weight), SegmentationNet10aTrunk.P, self.input_sz)
             for i in range(self.num_sub_heads)]
 
 

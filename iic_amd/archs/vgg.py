@@ -64,6 +64,7 @@ class _StageFn(torch.autograd.Function):
     need_grad = any(ctx.needs_input_grad)
     if need_grad:
       ctx.st = st
+      ctx.branch = ops.BRANCH[0]
       ctx.dims = (N, H, W, Ho, Wo)
       ctx.training = training
       ctx.save_for_backward(x, w, gamma, y, a, coef, out if st.pool else None)
@@ -73,7 +74,7 @@ class _StageFn(torch.autograd.Function):
         ops.POOL.release(a)
     return out
 
-  @staticmethod
+  @ops.branch_backward
   def backward(ctx, dout):
     x, w, gamma, y, a, coef, pooled = ctx.saved_tensors
     st = ctx.st
@@ -125,9 +126,10 @@ class _FlattenFn(torch.autograd.Function):
   def forward(ctx, x, P):
     N, Hp, Wp, C = x.shape
     ctx.meta = (tuple(x.shape), P)
+    ctx.branch = ops.BRANCH[0]
     return x[:, P:Hp - P, P:Wp - P, :].float().reshape(N, -1)
 
-  @staticmethod
+  @ops.branch_backward
   def backward(ctx, dfeat):
     shape, P = ctx.meta
     N, Hp, Wp, C = shape
@@ -173,7 +175,7 @@ class VGGTrunkHIP(nn.Module):
   def run_stages(self, x):
     x = shard_batch(x, self)          # unchanged scripts under torchrun: this rank's pairs only
     for st in self._stages:
-      x = _StageFn.apply(x, st.conv.weight, st.bn.weight, st.bn.bias, st)
+      x = _StageFn.apply(x, ops.pv(st.conv.weight), ops.pv(st.bn.weight), ops.pv(st.bn.bias), st)
     return x
 
 
@@ -212,9 +214,9 @@ class ClusterNet6cHead(nn.Module):
   def forward_packed(self, feats):
     F_, sp, k = self.num_features, self.sp, self.output_k
     # reference flatten order is (c, h, w) (net6c.py:24-25); ours is (h, w, c)
-    Wcat = torch.cat([h[0].weight.view(k, F_, sp, sp).permute(0, 2, 3, 1).reshape(k, -1)
+    Wcat = torch.cat([ops.pv(h[0].weight).view(k, F_, sp, sp).permute(0, 2, 3, 1).reshape(k, -1)
                       for h in self.heads], dim=0)
-    bcat = torch.cat([h[0].bias for h in self.heads], dim=0)
+    bcat = torch.cat([ops.pv(h[0].bias) for h in self.heads], dim=0)
     return _HeadsFn.apply(feats, Wcat, bcat, self.num_sub_heads, k)
 
   def forward(self, x, kmeans_use_features=False):

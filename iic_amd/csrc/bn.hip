@@ -22,38 +22,35 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
                     pack_bf16x2(f[6], f[7]));
 }
 
-// coef layout: [0]=scale [1]=shift [2]=mean [3]=invstd, each [C]
-__global__ void bn_finalize_kernel(float* __restrict__ stats, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, float* __restrict__ running_mean,
-                                   float* __restrict__ running_var, long long* __restrict__ nbt,
-                                   float* __restrict__ coef, int C, long count, long ucount,
-                                   float eps, float momentum, int training) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && training && nbt) *nbt += 1;
-  if (c >= C) return;
-  float mean, var;
+// coef layout: [0]=scale [1]=shift [2]=mean [3]=invstd [4]=unbiased batch variance, each [C]
+__global__ __launch_bounds__(256) void bn_finalize_kernel(
+    float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ running_mean, float* __restrict__ running_var, long long* __restrict__ nbt,
+    float* __restrict__ coef, int C, long count, long ucount, float eps, float momentum, int training) {
+  // 16 lanes per channel (2 stats x 8 bins of the exact accumulators, common.h); lane16 == 0 writes
+  const int lane16 = threadIdx.x & 15;
+  const int c = blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && training && nbt) *nbt += 1;
+  float mean, var, unbf = 0.f;
   if (training) {
-    double s = 0.0, ss = 0.0;
-    for (int st = 0; st < IIC_STAT_STRIPES; ++st) {
-      float* p = stats + (long)st * 2 * C;
-      s += (double)p[c];
-      ss += (double)p[C + c];
-      p[c] = 0.f;          // self-cleaning: ready for the next accumulation
-      p[C + c] = 0.f;
-    }
+    double s, ss;
+    iic_stat_collect(stats, IIC_STAT_STRIPES, C, c < C ? c : C - 1, lane16, s, ss);
+    if (c >= C || lane16 != 0) return;
     const double m = s / (double)count;
     double v = ss / (double)count - m * m;
     if (v < 0.0) v = 0.0;
     mean = (float)m;
     var = (float)v;
+    // ucount: sample count for the unbiased-variance factor; differs from `count` only when the
+    // batch holds exact replicas that were forwarded once (replica de-duplication)
+    const double unb = ucount > 1 ? v * (double)ucount / (double)(ucount - 1) : v;
+    unbf = (float)unb;
     if (running_mean) {
-      // ucount: sample count for the unbiased-variance factor; differs from `count` only when the
-      // batch holds exact replicas that were forwarded once (replica de-duplication)
-      const double unb = ucount > 1 ? v * (double)ucount / (double)(ucount - 1) : v;
       running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbf;
     }
   } else {
+    if (c >= C || lane16 != 0) return;
     mean = running_mean[c];
     var = running_var[c];
   }
@@ -64,6 +61,28 @@ __global__ void bn_finalize_kernel(float* __restrict__ stats, const float* __res
   coef[C + c] = beta[c] - mean * sc;
   coef[2 * C + c] = mean;
   coef[3 * C + c] = invstd;
+  coef[4 * C + c] = unbf;
+}
+
+// Running-statistic updates that iic_bn_finalize was told to skip (running_mean == nullptr),
+// applied later from the saved coefficients -- same arithmetic, bit for bit.  Multi-tensor.
+#define BNRU_CHUNK 64
+struct BnRunTable {
+  const float* coef[BNRU_CHUNK];
+  float* rm[BNRU_CHUNK];
+  float* rv[BNRU_CHUNK];
+  long long* nbt[BNRU_CHUNK];
+  int C[BNRU_CHUNK];
+};
+__global__ __launch_bounds__(256) void bn_running_update_kernel(const BnRunTable t, float momentum) {
+  const int i = blockIdx.y;
+  const int C = t.C[i];
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && t.nbt[i]) *t.nbt[i] += 1;
+  if (c >= C) return;
+  const float* coef = t.coef[i];
+  t.rm[i][c] = (1.f - momentum) * t.rm[i][c] + momentum * coef[2 * C + c];
+  t.rv[i][c] = (1.f - momentum) * t.rv[i][c] + momentum * coef[4 * C + c];
 }
 
 // out = act( scale*y + shift [+ res] [+ scale2*y2 + shift2] ), grid = (N*H, ceil(W*C/8/256))
@@ -180,32 +199,26 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
       float t = 0.f;
       for (int p = 0; p < PL; ++p) t += s_acc[(p * c8n + (c >> 3)) * 8 + (c & 7)];
       if (which == 0) {
-        atomicAdd(sums + (long)stripe * 2 * C + c, t);
-        if (HAS2) atomicAdd(sums2 + (long)stripe * 2 * C + c, t);
+        iic_stat_add(sums, stripe, C, c, 0, t);
+        if (HAS2) iic_stat_add(sums2, stripe, C, c, 0, t);
       } else if (which == 1) {
-        atomicAdd(sums + (long)stripe * 2 * C + C + c, t);
+        iic_stat_add(sums, stripe, C, c, 1, t);
       } else {
-        atomicAdd(sums2 + (long)stripe * 2 * C + C + c, t);
+        iic_stat_add(sums2, stripe, C, c, 1, t);
       }
     }
   }
 }
 
 // bcoef: [0]=c1 [1]=c2 [2]=c3 ; dy = c1*g + c2*y + c3
-__global__ void bn_bwd_finalize_kernel(float* __restrict__ sums, const float* __restrict__ gamma,
-                                       const float* __restrict__ coef, float* __restrict__ bcoef,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int C,
-                                       long count) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, sy = 0.0;
-  for (int st = 0; st < IIC_STAT_STRIPES; ++st) {
-    float* p = sums + (long)st * 2 * C;
-    s += (double)p[c];
-    sy += (double)p[C + c];
-    p[c] = 0.f;
-    p[C + c] = 0.f;
-  }
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
+    float* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ coef,
+    float* __restrict__ bcoef, float* __restrict__ dgamma, float* __restrict__ dbeta, int C, long count) {
+  const int lane16 = threadIdx.x & 15;
+  const int c = blockIdx.x * 16 + (threadIdx.x >> 4);
+  double s, sy;
+  iic_stat_collect(sums, IIC_STAT_STRIPES, C, c < C ? c : C - 1, lane16, s, sy);
+  if (c >= C || lane16 != 0) return;
   const double mean = coef[2 * C + c], invstd = coef[3 * C + c];
   const double sgx = (sy - mean * s) * invstd;   // sum g * xhat
   const double c1 = (double)gamma[c] * invstd;
@@ -390,12 +403,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce2_kernel(
       float t = 0.f;
       for (int p = 0; p < PL; ++p) t += s_acc[(p * c8n + (c >> 3)) * 8 + (c & 7)];
       if (which == 0) {
-        atomicAdd(sums + (long)stripe * 2 * C + c, t);
-        if (HAS2) atomicAdd(sums2 + (long)stripe * 2 * C + c, t);
+        iic_stat_add(sums, stripe, C, c, 0, t);
+        if (HAS2) iic_stat_add(sums2, stripe, C, c, 0, t);
       } else if (which == 1) {
-        atomicAdd(sums + (long)stripe * 2 * C + C + c, t);
+        iic_stat_add(sums, stripe, C, c, 1, t);
       } else {
-        atomicAdd(sums2 + (long)stripe * 2 * C + C + c, t);
+        iic_stat_add(sums2, stripe, C, c, 1, t);
       }
     }
   }
@@ -506,9 +519,42 @@ int iic_bn_finalize(float* stats, const float* gamma, const float* beta, float* 
   if (!gamma || !beta || !coef || C <= 0) return IIC_ERR_ARG;
   if (training && (!stats || count <= 0)) return IIC_ERR_ARG;
   if (!training && (!running_mean || !running_var)) return IIC_ERR_ARG;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream,
                      stats, gamma, beta, running_mean, running_var, num_batches_tracked, coef, C,
                      count, unbiased_count > 0 ? unbiased_count : count, eps, momentum, training);
+  return iic_launch_status();
+}
+
+long iic_stat_bytes(int C) {
+  return C > 0 ? (long)IIC_STAT_STRIPES * C * 2 * IIC_STAT_BINS * (long)sizeof(iic_stat_t) : 0;
+}
+
+int iic_bn_running_update(int n, const float* const* coef, float* const* running_mean,
+                          float* const* running_var, long long* const* num_batches_tracked,
+                          const int* C, float momentum, void* stream) {
+  if (n <= 0 || !coef || !running_mean || !running_var || !num_batches_tracked || !C) return IIC_ERR_ARG;
+  // one BatchNorm may appear several times (two forwards): chunks run in order on the stream, and
+  // within a chunk duplicates would race -- start a new chunk at a repeated running_mean
+  int base = 0;
+  while (base < n) {
+    BnRunTable t;
+    int cnt = 0, maxC = 0;
+    while (base + cnt < n && cnt < BNRU_CHUNK) {
+      const int j = base + cnt;
+      bool dup = false;
+      for (int k = 0; k < cnt; ++k) dup = dup || t.rm[k] == running_mean[j];
+      if (dup) break;
+      if (!coef[j] || !running_mean[j] || !running_var[j] || C[j] <= 0) return IIC_ERR_ARG;
+      t.coef[cnt] = coef[j]; t.rm[cnt] = running_mean[j]; t.rv[cnt] = running_var[j];
+      t.nbt[cnt] = num_batches_tracked[j]; t.C[cnt] = C[j];
+      if (C[j] > maxC) maxC = C[j];
+      ++cnt;
+    }
+    for (int k = cnt; k < BNRU_CHUNK; ++k) { t.coef[k] = nullptr; t.rm[k] = nullptr; t.rv[k] = nullptr; t.nbt[k] = nullptr; t.C[k] = 0; }
+    hipLaunchKernelGGL(bn_running_update_kernel, dim3((maxC + 255) / 256, cnt), dim3(256), 0,
+                       (hipStream_t)stream, t, momentum);
+    base += cnt;
+  }
   return iic_launch_status();
 }
 
@@ -567,7 +613,7 @@ int iic_bn_bwd_reduce(const void* dout, const void* act, const void* y, const vo
 int iic_bn_bwd_finalize(float* sums, const float* gamma, const float* coef, float* bcoef,
                         float* dgamma, float* dbeta, int C, long count, void* stream) {
   if (!sums || !gamma || !coef || !bcoef || C <= 0 || count <= 0) return IIC_ERR_ARG;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0,
                      (hipStream_t)stream, sums, gamma, coef, bcoef, dgamma, dbeta, C, count);
   return iic_launch_status();
 }

@@ -40,6 +40,65 @@ static inline int iic_zero_async(void* p, size_t bytes, hipStream_t s) {
   return IIC_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Exact, order-independent accumulation of per-channel statistics (BatchNorm sums and their
+// backward counterparts).  Workgroups used to atomicAdd float partial sums into 32 stripes: the
+// result depended on the arrival order, so training was not reproducible run to run (and a
+// 33-BatchNorm net amplifies one flipped ulp into visibly different losses).  Now every partial
+// (a float, computed in a fixed order inside its workgroup) is added EXACTLY as a fixed-point
+// integer: a cell is 7 int64 bins of 24 bits spacing (bin b holds multiples of 2^(LSB0 + 24 b));
+// a 24-bit mantissa shifted by < 24 bits fits one bin with 15 bits of carry headroom, integer
+// atomics are associative, and the finaliser folds stripes and bins in a fixed order.  Covers
+// |x| from 2^-96 (smaller partials lose low bits, deterministically) to 2^72; non-finite or
+// larger partials raise the cell's poison counter (bin 7) and the decoded sum is NaN, so a
+// diverged run still shows up as NaN.  Layout: [stripe][C][2 stats][8] int64 -- one 128-byte
+// line per (stripe, channel).
+// ------------------------------------------------------------------------------------------
+#define IIC_STAT_BINS 8
+#define IIC_STAT_LSB0 (-96)
+#define IIC_STAT_SPACING 24
+typedef long long iic_stat_t;
+__device__ __forceinline__ void iic_stat_add(float* stats, int stripe, int C, int c, int which, float t) {
+  iic_stat_t* cell = reinterpret_cast<iic_stat_t*>(stats) + (((long)stripe * C + c) * 2 + which) * IIC_STAT_BINS;
+  const uint32_t u = __float_as_uint(t);
+  const int e = (int)((u >> 23) & 0xffu);
+  int m = (int)(u & 0x7fffffu) | (e ? 0x800000 : 0);
+  if (e == 0xff) { atomicAdd(reinterpret_cast<unsigned long long*>(cell + 7), 1ull); return; }
+  int pos = (e ? e : 1) - 150 - IIC_STAT_LSB0;       // lsb of the mantissa, relative to bin 0's lsb
+  if (pos < 0) { m = pos > -24 ? (m >> -pos) : 0; pos = 0; }
+  if (m == 0) return;
+  const int b = pos / IIC_STAT_SPACING, sh = pos - b * IIC_STAT_SPACING;
+  if (b > 6) { atomicAdd(reinterpret_cast<unsigned long long*>(cell + 7), 1ull); return; }
+  long long v = (long long)m << sh;
+  if (u >> 31) v = -v;
+  atomicAdd(reinterpret_cast<unsigned long long*>(cell + b), (unsigned long long)v);
+}
+// Finaliser side.  Called by 16 consecutive lanes per channel: lane16 = which * 8 + bin.  Folds the
+// stripes (exact int64 sums), re-zeroes them, and returns in EVERY one of the 16 lanes the decoded
+// sums of stat 0 and stat 1 (double, bins combined from the highest down: a fixed order).
+__device__ __forceinline__ void iic_stat_collect(float* stats, int nstripes, int C, int c, int lane16,
+                                                 double& v0, double& v1) {
+  iic_stat_t* p = reinterpret_cast<iic_stat_t*>(stats) + ((long)c * 2) * IIC_STAT_BINS + lane16;
+  long long S = 0;
+  for (int st = 0; st < nstripes; ++st) {
+    iic_stat_t* q = p + (long)st * C * 2 * IIC_STAT_BINS;
+    S += *q;
+    *q = 0;
+  }
+  const int bin = lane16 & 7;
+  const double term = bin < 7 ? ldexp((double)S, IIC_STAT_LSB0 + IIC_STAT_SPACING * bin) : 0.0;
+  const int lane = threadIdx.x & 63, base = lane & ~15;
+  double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+  for (int b = 6; b >= 0; --b) {
+    a0 += __shfl(term, base + b, 64);
+    a1 += __shfl(term, base + 8 + b, 64);
+  }
+  const long long p0 = __shfl(S, base + 7, 64), p1 = __shfl(S, base + 15, 64);
+  v0 = p0 ? __builtin_nan("") : a0;
+  v1 = p1 ? __builtin_nan("") : a1;
+}
+
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) {
   return __uint_as_float(((uint32_t)v) << 16);
 }

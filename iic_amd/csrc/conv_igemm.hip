@@ -236,15 +236,15 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv_igemm_kernel(
   }
   __syncthreads();   // all waves finished reading sA/sB; s_red complete
   if (stats && tid < BN) {
-    float* st = stats + (long)(blockIdx.x % IIC_STAT_STRIPES) * 2 * g.Cout;
+    const int stripe = blockIdx.x % IIC_STAT_STRIPES;
     float a0 = 0.f, a1 = 0.f;
 #pragma unroll
     for (int q = 0; q < WM; ++q) {
       a0 += s_red[(q * 2 + 0) * BN + tid];
       a1 += s_red[(q * 2 + 1) * BN + tid];
     }
-    atomicAdd(st + n0 + tid, a0);
-    atomicAdd(st + g.Cout + n0 + tid, a1);
+    iic_stat_add(stats, stripe, g.Cout, n0 + tid, 0, a0);
+    iic_stat_add(stats, stripe, g.Cout, n0 + tid, 1, a1);
   }
 #pragma unroll
   for (int ms = 0; ms < 2; ++ms)

@@ -304,9 +304,9 @@ __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
   }
   __syncthreads();   // all waves finished reading sA; s_red complete
   if (stats && tid < BD_BN && !(ABL & 64)) {
-    float* st = stats + (long)(blockIdx.x % IIC_STAT_STRIPES) * 2 * g.Cout;
-    atomicAdd(st + n0 + tid, s_red[0 * BD_BN + tid] + s_red[2 * BD_BN + tid]);
-    atomicAdd(st + g.Cout + n0 + tid, s_red[1 * BD_BN + tid] + s_red[3 * BD_BN + tid]);
+    const int stripe = blockIdx.x % IIC_STAT_STRIPES;
+    iic_stat_add(stats, stripe, g.Cout, n0 + tid, 0, s_red[0 * BD_BN + tid] + s_red[2 * BD_BN + tid]);
+    iic_stat_add(stats, stripe, g.Cout, n0 + tid, 1, s_red[1 * BD_BN + tid] + s_red[3 * BD_BN + tid]);
   }
 #pragma unroll
   for (int ms = 0; ms < 4; ++ms)

@@ -236,9 +236,9 @@ __global__ __launch_bounds__(P64_THREADS) void conv_igemm_p64_kernel(
         a0 += s_red[(q * 2 + 0) * P64_BN + tid];
         a1 += s_red[(q * 2 + 1) * P64_BN + tid];
       }
-      float* st = stats + (long)(blockIdx.x % IIC_STAT_STRIPES) * 2 * P64_BN;
-      atomicAdd(st + tid, a0);
-      atomicAdd(st + P64_BN + tid, a1);
+      const int stripe = blockIdx.x % IIC_STAT_STRIPES;
+      iic_stat_add(stats, stripe, P64_BN, tid, 0, a0);
+      iic_stat_add(stats, stripe, P64_BN, tid, 1, a1);
     }
   }
 }

@@ -11,6 +11,7 @@
 struct AdamTable {
   float* p[ADAM_CHUNK];
   const float* g[ADAM_CHUNK];
+  const float* g2[ADAM_CHUNK];   // second gradient source (nullable): g_total = g + g2
   float* m[ADAM_CHUNK];
   float* v[ADAM_CHUNK];
   long n[ADAM_CHUNK];
@@ -21,11 +22,12 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTable t, float beta
   const int ti = blockIdx.y;
   float* __restrict__ p = t.p[ti];
   const float* __restrict__ g = t.g[ti];
+  const float* __restrict__ g2 = t.g2[ti];
   float* __restrict__ m = t.m[ti];
   float* __restrict__ v = t.v[ti];
   const long n = t.n[ti];
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const float gi = g[i];
+    const float gi = (g ? g[i] : 0.f) + (g2 ? g2[i] : 0.f);
     const float mi = beta1 * m[i] + (1.f - beta1) * gi;
     const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
     m[i] = mi;
@@ -51,11 +53,12 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(const AdamTable t, float 
   const int ti = blockIdx.y;
   float* __restrict__ p = t.p[ti];
   const float* __restrict__ g = t.g[ti];
+  const float* __restrict__ g2 = t.g2[ti];
   float* __restrict__ m = t.m[ti];
   float* __restrict__ v = t.v[ti];
   const long n = t.n[ti];
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const float gi = g[i];
+    const float gi = (g ? g[i] : 0.f) + (g2 ? g2[i] : 0.f);
     const float mi = beta1 * m[i] + (1.f - beta1) * gi;
     const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
     m[i] = mi;
@@ -67,13 +70,14 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(const AdamTable t, float 
 __global__ void adam_count_kernel(int* steps_done) { steps_done[0] += 1; }
 
 static void adam_fill_table(AdamTable& t, int base, int n, float* const* params,
-                            const float* const* grads, float* const* exp_avg,
+                            const float* const* grads, const float* const* grads2, float* const* exp_avg,
                             float* const* exp_avg_sq, const long* numel, int* cnt_out, long* gx_out) {
   const int cnt = (n - base) < ADAM_CHUNK ? (n - base) : ADAM_CHUNK;
   long maxn = 0;
   for (int i = 0; i < ADAM_CHUNK; ++i) {
     const int j = i < cnt ? base + i : base;   // pad with a duplicate of n == 0 work
-    t.p[i] = params[j]; t.g[i] = grads[j]; t.m[i] = exp_avg[j]; t.v[i] = exp_avg_sq[j];
+    t.p[i] = params[j]; t.g[i] = grads[j]; t.g2[i] = grads2 ? grads2[j] : nullptr;
+    t.m[i] = exp_avg[j]; t.v[i] = exp_avg_sq[j];
     t.n[i] = i < cnt ? numel[j] : 0;
     if (t.n[i] > maxn) maxn = t.n[i];
   }
@@ -85,7 +89,7 @@ static void adam_fill_table(AdamTable& t, int base, int n, float* const* params,
 }
 
 extern "C" int iic_adam_step_dev(int n, float* const* params, const float* const* grads,
-                                 float* const* exp_avg, float* const* exp_avg_sq, const long* numel,
+                                 const float* const* grads2, float* const* exp_avg, float* const* exp_avg_sq, const long* numel,
                                  float lr, float beta1, float beta2, float eps, int* steps_done,
                                  void* stream) {
   if (n <= 0 || !params || !grads || !exp_avg || !exp_avg_sq || !numel || !steps_done)
@@ -94,7 +98,7 @@ extern "C" int iic_adam_step_dev(int n, float* const* params, const float* const
     AdamTable t;
     int cnt;
     long gx;
-    adam_fill_table(t, base, n, params, grads, exp_avg, exp_avg_sq, numel, &cnt, &gx);
+    adam_fill_table(t, base, n, params, grads, grads2, exp_avg, exp_avg_sq, numel, &cnt, &gx);
     hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)gx, cnt), dim3(256), 0, (hipStream_t)stream,
                        t, lr, beta1, beta2, eps, (const int*)steps_done);
   }
@@ -103,7 +107,7 @@ extern "C" int iic_adam_step_dev(int n, float* const* params, const float* const
 }
 
 extern "C" int iic_adam_step(int n, float* const* params, const float* const* grads,
-                             float* const* exp_avg, float* const* exp_avg_sq, const long* numel,
+                             const float* const* grads2, float* const* exp_avg, float* const* exp_avg_sq, const long* numel,
                              float lr, float beta1, float beta2, float eps, int step, void* stream) {
   if (n <= 0 || !params || !grads || !exp_avg || !exp_avg_sq || !numel || step < 1)
     return IIC_ERR_ARG;
@@ -113,17 +117,9 @@ extern "C" int iic_adam_step(int n, float* const* params, const float* const* gr
   const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
   for (int base = 0; base < n; base += ADAM_CHUNK) {
     AdamTable t;
-    const int cnt = (n - base) < ADAM_CHUNK ? (n - base) : ADAM_CHUNK;
-    long maxn = 0;
-    for (int i = 0; i < ADAM_CHUNK; ++i) {
-      const int j = i < cnt ? base + i : base;   // pad with a duplicate of n == 0 work
-      t.p[i] = params[j]; t.g[i] = grads[j]; t.m[i] = exp_avg[j]; t.v[i] = exp_avg_sq[j];
-      t.n[i] = i < cnt ? numel[j] : 0;
-      if (t.n[i] > maxn) maxn = t.n[i];
-    }
-    long gx = (maxn + 255) / 256;
-    if (gx > 256) gx = 256;
-    if (gx < 1) gx = 1;
+    int cnt;
+    long gx;
+    adam_fill_table(t, base, n, params, grads, grads2, exp_avg, exp_avg_sq, numel, &cnt, &gx);
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)gx, cnt), dim3(256), 0, (hipStream_t)stream, t,
                        beta1, beta2, eps, step_size, inv_sqrt_bc2);
   }

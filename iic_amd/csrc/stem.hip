@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void stem_stats_kernel(const float* __restrict
     const int which = threadIdx.x >> 6, ch = threadIdx.x & 63;   // 0: sum, 1: sumsq
     float t = 0.f;
     for (int wv = 0; wv < 4; ++wv) t += s_red[wv][ch >> 5][which][ch & 31];
-    atomicAdd(stats + (long)(blockIdx.x % IIC_STAT_STRIPES) * 2 * STEM_CO + which * STEM_CO + ch, t);
+    iic_stat_add(stats, blockIdx.x % IIC_STAT_STRIPES, STEM_CO, ch, which, t);
   }
 }
 
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(512) void stem_bwd_kernel(const float* __restrict__
       const int which = o >> 6, ch = o & 63;
       float t = 0.f;
       for (int th = (ch >> 3); th < (int)blockDim.x; th += 8) t += red[th * 16 + which * 8 + (ch & 7)];
-      atomicAdd(sums + (long)(blockIdx.x % IIC_STAT_STRIPES) * 2 * STEM_CO + which * STEM_CO + ch, t);
+      iic_stat_add(sums, blockIdx.x % IIC_STAT_STRIPES, STEM_CO, ch, which, t);
     }
     __syncthreads();
   }
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(512) void stem_bwd_kernel(const float* __restrict__
 
 // G3[k = (c, kh, kw)] = sum over images and valid conv positions (y, x) of the zero-padded input
 // x[c][y+kh-1][x+kw-1]: every input pixel (yy, xx) counts for tap (kh, kw) iff the conv position
-// (yy-kh+1, xx-kw+1) lies inside the image.  out[k] += ... (zero-initialised by the caller).
+// (yy-kh+1, xx-kw+1) lies inside the image.  out[block][64]: per-block partial sums.
 __global__ __launch_bounds__(256) void stem_patch_sums_kernel(const float* __restrict__ x,
                                                               float* __restrict__ out, int N, int CIN,
                                                               int H, int W) {
@@ -455,7 +455,9 @@ __global__ __launch_bounds__(256) void stem_patch_sums_kernel(const float* __res
     if (kh == 0 && kw == 2) X = red[7][0];   // row H-1, col 0
     if (kh == 2 && kw == 0) X = red[6][0];   // row 0,   col W-1
     if (kh == 2 && kw == 2) X = red[5][0];   // row 0,   col 0
-    atomicAdd(out + c * 9 + threadIdx.x, red[0][0] - R - C + X);
+    // one slot per block (no float atomics: the sum over blocks happens in a fixed order in
+    // stem_wgrad_combine_kernel)
+    out[(long)blockIdx.x * 64 + c * 9 + threadIdx.x] = red[0][0] - R - C + X;
   }
 }
 
@@ -466,27 +468,30 @@ __global__ __launch_bounds__(256) void stem_wgrad_combine_kernel(const float* __
                                                                  const float* __restrict__ bcoef,
                                                                  const float* __restrict__ g3,
                                                                  float* __restrict__ dW) {
-  __shared__ float red[2][256];
+  __shared__ float red[3][256];
   const int idx = blockIdx.x;            // output element co*K + k
   const int co = idx / K, k = idx - co * K;
-  float t1 = 0.f, t2 = 0.f;
+  float t1 = 0.f, t2 = 0.f, t3 = 0.f;
   for (int b = threadIdx.x; b < nblocks; b += 256) {
     const float* pb = part + (long)b * 128 * LD;
     t1 += pb[(long)co * LD + k];
     t2 += pb[(long)(64 + co) * LD + k];
   }
+  for (int b = threadIdx.x; b < 512; b += 256) t3 += g3[(long)b * 64 + k];   // G3 per-block partials
   red[0][threadIdx.x] = t1;
   red[1][threadIdx.x] = t2;
+  red[2][threadIdx.x] = t3;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
     if (threadIdx.x < s) {
       red[0][threadIdx.x] += red[0][threadIdx.x + s];
       red[1][threadIdx.x] += red[1][threadIdx.x + s];
+      red[2][threadIdx.x] += red[2][threadIdx.x + s];
     }
     __syncthreads();
   }
   if (threadIdx.x == 0)
-    dW[idx] = bcoef[co] * red[0][0] + bcoef[STEM_CO + co] * red[1][0] + bcoef[2 * STEM_CO + co] * g3[k];
+    dW[idx] = bcoef[co] * red[0][0] + bcoef[STEM_CO + co] * red[1][0] + bcoef[2 * STEM_CO + co] * red[2][0];
 }
 
 // dW[co][k] = sum_b part[b][co][k]  (k < K), fp32 OIHW flatten.  One block per output
@@ -636,11 +641,12 @@ int iic_stem_bwd_reduce(const float* x, const float* w, const float* coef, const
   return iic_launch_status();
 }
 
-long iic_stem_wgrad_partial_floats(void) { return (long)STEM_PERSIST_BLOCKS * 128 * 64 + 64; }
+#define STEM_G3_BLOCKS 512
+long iic_stem_wgrad_partial_floats(void) { return (long)STEM_PERSIST_BLOCKS * 128 * 64 + STEM_G3_BLOCKS * 64; }
 
 /* One recompute pass: sums (as iic_stem_bwd_reduce) AND the coefficient-free weight-gradient
- * GEMMs G1 = sum g*patch, G2 = sum y*patch into partials [blocks][128][LD] (+ G3 = sum patch in
- * the last 64 floats of the partials buffer); *nblocks_out = blocks written. */
+ * GEMMs G1 = sum g*patch, G2 = sum y*patch into partials [blocks][128][LD] (+ G3 = sum patch as
+ * [512][64] per-block partials at the end of the partials buffer); *nblocks_out = blocks written. */
 int iic_stem_bwd_fused(const float* x, const float* w, const float* coef, const void* dpool_pt,
                        float* sums, float* partials, int* nblocks_out, int N, int Cin, int H, int W,
                        void* stream) {
@@ -652,9 +658,8 @@ int iic_stem_bwd_fused(const float* x, const float* w, const float* coef, const 
   int grid = (int)(items < STEM_PERSIST_BLOCKS ? items : STEM_PERSIST_BLOCKS);
   *nblocks_out = grid;
   float* g3 = partials + (long)STEM_PERSIST_BLOCKS * 128 * 64;
-  if (iic_zero_async(g3, 64 * sizeof(float), (hipStream_t)stream) != IIC_OK) return IIC_ERR_LAUNCH;
-  hipLaunchKernelGGL(stem_patch_sums_kernel, dim3(512, Cin), dim3(256), 0, (hipStream_t)stream, x, g3, N,
-                     Cin, H, W);
+  hipLaunchKernelGGL(stem_patch_sums_kernel, dim3(STEM_G3_BLOCKS, Cin), dim3(256), 0, (hipStream_t)stream,
+                     x, g3, N, Cin, H, W);
   if (g_stem_bwd2 && iic_stem_bwd2_supported(Cin, W))      // register-resident routing (stem_bwd2.hip)
     return iic_stem_bwd2_launch(x, w, coef, dpool_pt, sums, partials, nblocks_out, N, Cin, H, W, stream);
   const size_t lds = stem_bwd_lds(Cin, W, nseg, 2);

@@ -257,15 +257,21 @@ __global__ __launch_bounds__(512) void stem_bwd2_kernel(const float* __restrict_
   // ---- block reduction: partial [128][32] = G1 rows 0..63, G2 rows 64..127; sums via atomics ----
   for (int i = threadIdx.x; i < 128 * 33; i += blockDim.x) sRed[i] = 0.f;
   __syncthreads();
+  // waves take turns in index order: a fixed summation order (LDS float atomics would add the
+  // waves' accumulators in arrival order and make the partial -- hence dW -- irreproducible)
+  for (int wv = 0; wv < nwaves; ++wv) {
+    if (wave == wv) {
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+      for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = h * 32 + mfma32_row(r, lane);
-      atomicAdd(&sRed[row * 33 + l31], dg[h][r]);
-      atomicAdd(&sRed[(64 + row) * 33 + l31], dy[h][r]);
+        for (int r = 0; r < 16; ++r) {
+          const int row = h * 32 + mfma32_row(r, lane);
+          sRed[row * 33 + l31] += dg[h][r];
+          sRed[(64 + row) * 33 + l31] += dy[h][r];
+        }
     }
-  __syncthreads();
+    __syncthreads();
+  }
   float* pout = partials + (long)blockIdx.x * 128 * 32;
   for (int i = threadIdx.x; i < 128 * 32; i += blockDim.x) pout[i] = sRed[(i >> 5) * 33 + (i & 31)];
   __syncthreads();
@@ -288,7 +294,7 @@ __global__ __launch_bounds__(512) void stem_bwd2_kernel(const float* __restrict_
     const int which = o >> 6, ch = o & 63;
     float t = 0.f;
     for (int wv = 0; wv < nwaves; ++wv) t += sS[(wv * 2 + which) * 64 + ch];
-    atomicAdd(sums + (long)(blockIdx.x % IIC_STAT_STRIPES) * 2 * STEM_CO + which * STEM_CO + ch, t);
+    iic_stat_add(sums, blockIdx.x % IIC_STAT_STRIPES, STEM_CO, ch, which, t);
   }
 }
 

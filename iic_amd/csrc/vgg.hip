@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void firstconv_fwd_kernel(const float* __restr
       const int which = threadIdx.x >> 6, ch = threadIdx.x & 63;
       float t = 0.f;
       for (int wv = 0; wv < 4; ++wv) t += s_red[wv][ch >> 5][which][ch & 31];
-      atomicAdd(stats + (long)(blockIdx.x % IIC_STAT_STRIPES) * 2 * FC_CO + which * FC_CO + ch, t);
+      iic_stat_add(stats, blockIdx.x % IIC_STAT_STRIPES, FC_CO, ch, which, t);
     }
   }
 }

@@ -14,6 +14,7 @@ import sys
 import torch
 
 from . import dist as iic_dist
+from . import ops
 from ._lib import check, lib, ptr, stream_ptr
 
 F32 = torch.float32
@@ -32,6 +33,7 @@ class _IIDLossFn(torch.autograd.Function):
   @staticmethod
   def forward(ctx, z, zt, lamb, eps):
     assert z.is_cuda and zt.is_cuda, "IID_loss: HIP path needs device tensors (no CPU fallback)"
+    ops.join()      # (no-op unless a view was forked onto a side stream: iic_amd.ops.branch)
     assert z.dtype == F32 and zt.dtype == F32 and z.shape == zt.shape and z.dim() == 3
     H, bn, k = z.shape
     # logical [H, bn, k]; physical either head-major [H][bn][k] or sample-major [bn][H][k]

@@ -16,37 +16,165 @@ F32 = torch.float32
 
 
 # ------------------------------------------------------------------------------------
+# Branches: two independent forwards of a step (net(all_imgs), net(all_imgs_tf):
+# cluster_sobel.py:238-239) can run on two HIP streams -- as two parallel branches of the captured
+# step graph -- so that the tail of one view's kernel is filled by the other view's next kernel
+# (measured: 42.6 -> 38.2 ms for the two forward+backward passes, tools/dual_branch_probe.py).
+# Everything the kernels share through HBM is therefore keyed by the branch index: PT buffers,
+# BatchNorm statistic accumulators, split-K / stem scratch, the bf16 weight operands.  A branch's
+# autograd Functions remember their branch (ctx.branch) and restore it in backward, where the
+# engine already runs them on the stream they were recorded on.
+#   with ops.branch():            # fork: side stream waits for the current one
+#     xt = net(all_imgs_tf)       # enqueued on the side stream
+#   xo = net(all_imgs)            # main stream, concurrently
+#   ops.join()                    # the current stream waits for the side stream (the losses and
+#                                 # the optimiser call it themselves if it is still pending)
+# Inside a branch: parameters are seen through per-branch leaf aliases (`pv`), so that gradient
+# accumulation of shared parameters never synchronises the branches (the optimiser adds the two
+# gradient sets, iic_amd.optim.Adam); BatchNorm running statistics are updated at the join in
+# the order a sequential run would have used (bn_finalize -> _DEFERRED_RUNNING).
+# ------------------------------------------------------------------------------------
+BRANCH = [0]
+_BRANCH_STREAM = {}
+_PROXIES = {}             # id(param) -> (param, {branch: leaf alias sharing its storage})
+_DEFERRED_RUNNING = []    # (coef, running_mean, running_var, num_batches_tracked, C) of a branch
+_PENDING_JOIN = []        # (main stream, side stream) of branches not joined yet
+
+
+def pv(p):
+  """Parameter as seen by the current branch (the parameter itself on the main branch)."""
+  b = BRANCH[0]
+  if b == 0 or p is None or not p.requires_grad:
+    return p
+  ent = _PROXIES.get(id(p))
+  if ent is None or ent[0] is not p:
+    ent = (p, {})
+    _PROXIES[id(p)] = ent
+  q = ent[1].get(b)
+  if q is None or q.data_ptr() != p.data_ptr():
+    q = p.detach().requires_grad_(True)
+    ent[1][b] = q
+  return q
+
+
+def branch_grads(p):
+  """Gradients the side branches accumulated for parameter p (list, possibly empty)."""
+  ent = _PROXIES.get(id(p))
+  if ent is None or ent[0] is not p:
+    return []
+  return [q.grad for q in ent[1].values() if q.grad is not None]
+
+
+def clear_branch_grads():
+  for _, d in _PROXIES.values():
+    for q in d.values():
+      q.grad = None
+
+
+class branch(object):
+  """Fork the enclosed forward onto a side stream / graph branch (see above).  Not re-entrant."""
+
+  def __init__(self, index=1):
+    assert index >= 1
+    self.index = index
+
+  def __enter__(self):
+    assert BRANCH[0] == 0, "branches do not nest"
+    dev = torch.cuda.current_device()
+    key = (dev, self.index)
+    st = _BRANCH_STREAM.get(key)
+    if st is None:
+      st = torch.cuda.Stream()
+      _BRANCH_STREAM[key] = st
+    self.main = torch.cuda.current_stream()
+    self.side = st
+    st.wait_stream(self.main)                       # fork
+    for _, d in _PROXIES.values():                  # last step's branch gradients are consumed
+      q = d.get(self.index)
+      if q is not None:
+        q.grad = None
+    self.ctx = torch.cuda.stream(st)
+    self.ctx.__enter__()
+    BRANCH[0] = self.index
+    return self
+
+  def __exit__(self, *exc):
+    BRANCH[0] = 0
+    self.ctx.__exit__(*exc)
+    _PENDING_JOIN.append((self.main, self.side))    # joined later: the main view runs meanwhile
+    return False
+
+
+def join():
+  """Main stream waits for the side branches forked since the last join, then applies their
+  postponed running-statistic updates (after the main view's own: sequential order)."""
+  while _PENDING_JOIN:
+    main, side = _PENDING_JOIN.pop()
+    main.wait_stream(side)
+  flush_deferred_running()
+
+
+def flush_deferred_running():
+  """Apply the running-statistic updates the branch forwards postponed (one launch)."""
+  if not _DEFERRED_RUNNING:
+    return
+  items = list(_DEFERRED_RUNNING)
+  del _DEFERRED_RUNNING[:]
+  n = len(items)
+  VP = ctypes.c_void_p * n
+  IP = ctypes.c_int * n
+  check(lib().iic_bn_running_update(
+    n, VP(*[ptr(c) for c, _, _, _, _ in items]), VP(*[ptr(rm) for _, rm, _, _, _ in items]),
+    VP(*[ptr(rv) for _, _, rv, _, _ in items]), VP(*[ptr(nb) for _, _, _, nb, _ in items]),
+    IP(*[C for _, _, _, _, C in items]), BN_MOMENTUM, stream_ptr()), "iic_bn_running_update")
+
+
+def branch_backward(fn):
+  """Decorator for autograd Function.backward: run under the branch the forward recorded."""
+  def wrapped(ctx, *grads):
+    prev = BRANCH[0]
+    BRANCH[0] = getattr(ctx, "branch", 0)
+    try:
+      return fn(ctx, *grads)
+    finally:
+      BRANCH[0] = prev
+  wrapped.__name__ = getattr(fn, "__name__", "backward")
+  return staticmethod(wrapped)
+
+
+# ------------------------------------------------------------------------------------
 # PT ("padded tile") activation buffers: bf16 [N, H+2P, W+2P, C], zero border.
 # Kernels write interiors only, so buffers are zeroed ONCE and recycled through a pool
 # (no per-step memset traffic).  A buffer is handed out by `alloc`, and returned with
 # `release` once every kernel that reads it has been enqueued (stream-ordered reuse).
 # ------------------------------------------------------------------------------------
 class PTPool(object):
-  """Buffers are keyed by (shape, border P, device): a recycled buffer is only valid for a
-  tensor with the SAME interior/border split (its border must still be zero)."""
+  """Buffers are keyed by (shape, border P, device, branch): a recycled buffer is only valid for
+  a tensor with the SAME interior/border split (its border must still be zero), and only on the
+  stream (branch) whose kernels used it last."""
 
   def __init__(self):
     self.free = {}
-    self.border = {}          # data_ptr -> P of every buffer this pool created
+    self.border = {}          # data_ptr -> (P, branch) of every buffer this pool created
     self.allocated_bytes = 0
 
   def alloc(self, shape, device, P=1):
-    key = (tuple(shape), int(P), str(device))
+    key = (tuple(shape), int(P), str(device), BRANCH[0])
     lst = self.free.get(key)
     if lst:
       return lst.pop()
     t = torch.zeros(shape, dtype=BF16, device=device)
-    self.border[t.data_ptr()] = int(P)
+    self.border[t.data_ptr()] = (int(P), BRANCH[0])
     self.allocated_bytes += t.numel() * 2
     return t
 
   def release(self, t):
     if t is None:
       return
-    P = self.border.get(t.data_ptr())
-    if P is None:
+    ent = self.border.get(t.data_ptr())
+    if ent is None:
       return                  # not one of ours (e.g. a user tensor): never recycle it
-    key = (tuple(t.shape), P, str(t.device))
+    key = (tuple(t.shape), ent[0], str(t.device), ent[1])
     self.free.setdefault(key, []).append(t)
 
   def clear(self):
@@ -75,7 +203,37 @@ def pt_to_nchw(x, P):
 
 
 def new_stats(C, device):
-  return torch.zeros((IIC_STAT_STRIPES, 2, C), dtype=F32, device=device)
+  """Zeroed statistics accumulator for C channels (opaque exact fixed-point cells, see
+  include/iic_hip.h: iic_stat_bytes)."""
+  return torch.zeros(lib().iic_stat_bytes(C) // 8, dtype=torch.int64, device=device)
+
+
+STAT_BINS, STAT_LSB0, STAT_SPACING = 8, -96, 24      # csrc/common.h
+
+
+def stats_decode(st, C):
+  """(test / debug helper, non-destructive) accumulator -> float64 [2, C] sums."""
+  cells = st.view(IIC_STAT_STRIPES, C, 2, STAT_BINS).sum(0)          # exact int64
+  val = torch.zeros((C, 2), dtype=torch.float64, device=st.device)
+  for b in range(STAT_BINS - 2, -1, -1):
+    val += torch.ldexp(cells[..., b].double(), torch.tensor(STAT_LSB0 + STAT_SPACING * b, device=st.device))
+  val[cells[..., STAT_BINS - 1] != 0] = float("nan")
+  return val.t().contiguous()
+
+
+def stats_encode(st, C, values):
+  """(test helper) overwrite the accumulator with the float32 sums `values` [2, C]."""
+  st.zero_()
+  v = values.to(st.device).float().t().contiguous().double()          # [C, 2]
+  mant, exp = torch.frexp(v)
+  m = torch.round(mant * (1 << 24)).long()
+  pos = exp.long() - 24 - STAT_LSB0
+  neg = pos < 0
+  m = torch.where(neg, m >> (-pos).clamp(0, 62), m)
+  pos = pos.clamp(min=0)
+  b, sh = pos // STAT_SPACING, pos % STAT_SPACING
+  cells = st.view(IIC_STAT_STRIPES, C, 2, STAT_BINS)
+  cells[0].scatter_(2, b.clamp(max=STAT_BINS - 2).unsqueeze(-1), (m << sh).unsqueeze(-1))
 
 
 # ------------------------------------------------------------------------------------
@@ -173,7 +331,7 @@ def conv_wgrad(g, x_pt, dy_pt, wtaps, use_tr=True, out=None, accumulate=False, n
   split-K factor (tests: few splits = many K-tiles per workgroup)."""
   ns = int(nsplit) if nsplit else lib().iic_conv_wgrad_nsplit(ctypes.byref(g))
   need = ns * g.ntaps * g.Cout * g.Cin
-  key = str(x_pt.device)
+  key = (str(x_pt.device), BRANCH[0])
   part = _WG_PART.get(key)
   if part is None or part.numel() < need:
     part = torch.empty(max(need, 1 << 22), dtype=F32, device=x_pt.device)
@@ -201,7 +359,13 @@ BN_REPLICAS = [1]
 
 
 def bn_finalize(stats, gamma, beta, running_mean, running_var, nbt, C, count, training):
-  coef = torch.empty((4, C), dtype=F32, device=gamma.device)
+  """coef [5][C]: scale, shift, mean, invstd, unbiased batch variance."""
+  coef = torch.empty((5, C), dtype=F32, device=gamma.device)
+  if training and BRANCH[0] != 0 and running_mean is not None:
+    # side branch: the main branch updates the same running statistics concurrently -- postpone
+    # this view's update to the join (same order as a sequential run: main view first)
+    _DEFERRED_RUNNING.append((coef, running_mean, running_var, nbt, C))
+    running_mean = running_var = nbt = None
   check(lib().iic_bn_finalize(ptr(stats), ptr(gamma), ptr(beta), ptr(running_mean),
                               ptr(running_var), ptr(nbt), ptr(coef), C, count,
                               count * BN_REPLICAS[0], BN_EPS, BN_MOMENTUM, 1 if training else 0,
@@ -282,7 +446,7 @@ def stem_bwd_wgrad(x, w, coef, bcoef, dpool):
 
 
 def _stem_partials(device):
-  key = str(device)
+  key = (str(device), BRANCH[0])
   part = _STEM_PART.get(key)
   if part is None:
     part = torch.empty(lib().iic_stem_wgrad_partial_floats(), dtype=F32, device=device)
@@ -369,7 +533,7 @@ _FC_PART = {}
 
 def firstconv_wgrad(x, dy_pt, w_shape, K, pad, P):
   n, c, h, wd = x.shape
-  key = str(x.device)
+  key = (str(x.device), BRANCH[0])
   part = _FC_PART.get(key)
   if part is None:
     part = torch.empty(lib().iic_firstconv_wgrad_partial_floats(), dtype=F32, device=x.device)

@@ -15,6 +15,7 @@ import ctypes
 
 import torch
 
+from . import ops
 from ._lib import check, lib, stream_ptr
 from .archs.cluster import bump_weights_epoch
 
@@ -68,16 +69,29 @@ class Adam(torch.optim.Optimizer):
     elif not isinstance(st["step"], int):
       st["step"] = _as_int(st["step"])
     assert p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
-    if not p.grad.is_contiguous():
+    if p.grad is not None and not p.grad.is_contiguous():
       p.grad = p.grad.contiguous()
     return st
+
+  @staticmethod
+  def _branch_grad(p):
+    """Gradient a side branch (iic_amd.ops.branch) accumulated for p through its leaf alias."""
+    gs = ops.branch_grads(p)
+    if not gs:
+      return None
+    assert len(gs) == 1, "one side branch per step"
+    return gs[0] if gs[0].is_contiguous() else gs[0].contiguous()
 
   @staticmethod
   def _tables(grp, state):
     n = len(grp)
     VP = ctypes.c_void_p * n
     LP = ctypes.c_long * n
-    return (n, VP(*[p.data_ptr() for p in grp]), VP(*[p.grad.data_ptr() for p in grp]),
+    g2 = [Adam._branch_grad(p) for p in grp]
+    keep = [t for t in g2 if t is not None]       # (alive until the launch is enqueued)
+    return (n, VP(*[p.data_ptr() for p in grp]),
+            VP(*[p.grad.data_ptr() if p.grad is not None else None for p in grp]),
+            VP(*[t.data_ptr() if t is not None else None for t in g2]) if keep else None,
             VP(*[state[p]["exp_avg"].data_ptr() for p in grp]),
             VP(*[state[p]["exp_avg_sq"].data_ptr() for p in grp]),
             LP(*[p.numel() for p in grp]))
@@ -115,7 +129,7 @@ class Adam(torch.optim.Optimizer):
       with torch.enable_grad():
         loss = closure()
     for group in self.param_groups:
-      ps = [p for p in group["params"] if p.grad is not None]
+      ps = [p for p in group["params"] if p.grad is not None or ops.branch_grads(p)]
       if not ps:
         continue
       for p in ps:

@@ -15,6 +15,7 @@ from sys import float_info
 import torch
 
 from . import dist as iic_dist
+from . import ops
 from ._lib import check, lib, ptr, stream_ptr
 
 EPS = float_info.epsilon
@@ -38,6 +39,7 @@ class _SegLossFn(torch.autograd.Function):
   @staticmethod
   def forward(ctx, x1, x2, flips, mask, lamb, T, collapsed):
     assert x1.is_cuda and x1.dtype == F32 and x1.shape == x2.shape and x1.dim() == 4
+    ops.join()      # (no-op unless a view was forked onto a side stream: iic_amd.ops.branch)
     x1, x2, mask = x1.contiguous(), x2.contiguous(), mask.contiguous().float()
     bn, k, h, w = x1.shape
     L, s = lib(), stream_ptr()

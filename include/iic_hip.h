@@ -108,8 +108,12 @@ typedef struct {
 
 long iic_conv_lds_bytes(const iic_conv_geom* g, int BN);
 /* out[pout(m)][co] = sum_t sum_ci in[pin(m)+tap_off[t]][ci] * w[tap_w[t]][co][ci]
- * w: bf16 [wtaps][Cout][Cin].  stats (nullable): fp32 [IIC_STAT_STRIPES][2][Cout],
- * += per-channel sum / sum of squares of the fp32 accumulators (BatchNorm batch stats).
+ * w: bf16 [wtaps][Cout][Cin].  stats (nullable): a statistics accumulator of iic_stat_bytes(Cout)
+ * bytes, zero-initialised once by the caller (the finalisers re-zero it); += per-channel sum /
+ * sum of squares of the fp32 accumulators (BatchNorm batch stats).  The accumulator is opaque:
+ * [IIC_STAT_STRIPES][Cout][2][8] int64 fixed-point bins, added to with integer atomics, so the
+ * result is exact and independent of the order in which workgroups arrive -- bit-reproducible
+ * training (csrc/common.h).  `float*` in the signatures below is that opaque buffer.
  * res_grad/res_act (nullable, PT like out): out += res_grad where res_act > 0 (fused
  * ReLU-masked residual gradient).  accumulate is a flag word: IIC_ACC_ADD: out += previous
  * contents; IIC_ACC_PREMASK changes the meaning of res_grad / res_act (each nullable on its
@@ -117,6 +121,7 @@ long iic_conv_lds_bytes(const iic_conv_geom* g, int BN);
  * launch hands its gradient over already multiplied by the ReLU mask of the activation it
  * belongs to (res_act = the conv's input activation, archs/cluster.py PREMASK).           */
 #define IIC_STAT_STRIPES 32
+long iic_stat_bytes(int C);
 #define IIC_ACC_ADD 1
 #define IIC_ACC_PREMASK 2
 int iic_conv_igemm(const iic_conv_geom* g, const void* in, const void* w, void* out,
@@ -155,7 +160,7 @@ int iic_weight_prep_frag(const float* w_oihw, void* w_frag, int Cout, int Cin, i
  * `out += residual` in residual.py:20-41,56-57, vgg.py:28-30.
  * Statistics: stats stripes produced by iic_conv_igemm; finalised per channel here.
  * ------------------------------------------------------------------------------- */
-/* coef[0..3][C]: scale, shift, mean, invstd.  use_running: eval() with
+/* coef[0..4][C]: scale, shift, mean, invstd, unbiased batch variance.  use_running: eval() with
  * track_running_stats.  running_* nullable (track_running_stats=False).  Re-zeroes stats.
  * unbiased_count (0 = count): sample count of the unbiased running_var factor n/(n-1); differs
  * from `count` only under replica de-duplication (cluster_sobel.py:215-226 replicates imgs_curr
@@ -165,6 +170,15 @@ int iic_bn_finalize(float* stats, const float* gamma, const float* beta, float* 
                     float* running_var, long long* num_batches_tracked, float* coef, int C,
                     long count, long unbiased_count, float eps, float momentum, int training,
                     void* stream);
+/* Deferred running-statistic update: what iic_bn_finalize does to running_mean / running_var /
+ * num_batches_tracked (torch.nn.BatchNorm2d, momentum 0.1, unbiased variance; residual.py:20,23)
+ * when it is given them, applied later from the coefficients it saved (coef row 2 = batch mean,
+ * row 4 = unbiased batch variance).  Used when two forwards of one step run concurrently on two
+ * streams and must not read-modify-write the same running statistics.  n BatchNorms per call;
+ * the pointer arrays are HOST arrays of device pointers.                                     */
+int iic_bn_running_update(int n, const float* const* coef, float* const* running_mean,
+                          float* const* running_var, long long* const* num_batches_tracked,
+                          const int* C, float momentum, void* stream);
 /* out = relu( scale*y+shift  [+ res]  [+ scale2*y2+shift2] ) on PT interiors.            */
 int iic_bn_apply(const void* y, const float* coef, const void* res, const void* y2,
                  const float* coef2, void* out, int N, int H, int W, int P, int C, int relu,
@@ -265,16 +279,21 @@ int iic_colsum_f32(const float* A, float* out, int rows, int cols, int accumulat
  * (betas (0.9,0.999), eps 1e-8, no weight decay, no amsgrad).  Multi-tensor: `n` tensors.
  * ptrs are HOST arrays of device pointers.
  * ------------------------------------------------------------------------------- */
-int iic_adam_step(int n, float* const* params, const float* const* grads, float* const* exp_avg,
-                  float* const* exp_avg_sq, const long* numel, float lr, float beta1, float beta2,
-                  float eps, int step, void* stream);
+/* grads2: optional second gradient source (NULL, or a host array whose entries may be NULL): the
+ * update uses grads[i] + grads2[i] -- the two views of a step may accumulate their parameter
+ * gradients separately (iic_amd.ops.branch) and are summed here instead of by extra kernels;
+ * grads[i] may then be NULL as well (a tensor that only the second view touched).           */
+int iic_adam_step(int n, float* const* params, const float* const* grads, const float* const* grads2,
+                  float* const* exp_avg, float* const* exp_avg_sq, const long* numel, float lr,
+                  float beta1, float beta2, float eps, int step, void* stream);
 /* Same update with the step count kept on the DEVICE: `steps_done` (int32) = updates already
  * applied to these tensors; the kernel derives the bias corrections from it and a trailing
  * 1-thread kernel increments it.  No launch argument changes between steps, so the optimiser
  * step can be part of a captured HIP graph (iic_amd.graph).                                  */
-int iic_adam_step_dev(int n, float* const* params, const float* const* grads, float* const* exp_avg,
-                      float* const* exp_avg_sq, const long* numel, float lr, float beta1, float beta2,
-                      float eps, int* steps_done, void* stream);
+int iic_adam_step_dev(int n, float* const* params, const float* const* grads,
+                      const float* const* grads2, float* const* exp_avg, float* const* exp_avg_sq,
+                      const long* numel, float lr, float beta1, float beta2, float eps,
+                      int* steps_done, void* stream);
 
 /* one-time device probes used by the test-suite (documented in DESIGN.md) */
 int iic_probe_tr16(void* out_u16_64x4, void* stream);

@@ -220,7 +220,7 @@ def _conv_forward_and_stats(case, frag=False):
   assert (got - ref).abs().max().item() <= 1e-2 * scale, (got - ref).abs().max().item() / scale
   o = out.float().cpu()
   assert o[:, 0].abs().max() == 0 and o[:, :, 0].abs().max() == 0 and o[:, -1].abs().max() == 0
-  st = stats.sum(0).cpu()
+  st = ops.stats_decode(stats, cout).float().cpu()
   cnt = N * Ho * Ho
   assert torch.allclose(st[0] / cnt, ref.mean((0, 2, 3)), atol=2e-3 * scale)
   assert torch.allclose(st[1] / cnt, (ref * ref).mean((0, 2, 3)), rtol=2e-3, atol=1e-4 * scale * scale)
@@ -262,7 +262,7 @@ def test_conv_large_images_padded_row_numbering(cin, cout, d, frag):
   assert (got - ref.detach()).abs().max().item() <= 1e-2 * scale
   o = out.float()
   assert float(o[:, :P].abs().max()) == 0 and float(o[:, :, -P:].abs().max()) == 0
-  st = stats.sum(0).cpu()
+  st = ops.stats_decode(stats, cout).float().cpu()
   cnt = N * Ho * Ho
   assert torch.allclose(st[0] / cnt, ref.detach().mean((0, 2, 3)), atol=2e-3 * scale)
   assert torch.allclose(st[1] / cnt, (ref.detach() ** 2).mean((0, 2, 3)), rtol=2e-3, atol=1e-4 * scale * scale)
@@ -422,8 +422,7 @@ def test_bn_forward_backward_kernels():
 
   def stats_of(t):
     st = ops.new_stats(C, d)
-    st[0, 0] = t.sum((0, 2, 3)).to(d)
-    st[0, 1] = (t * t).sum((0, 2, 3)).to(d)
+    ops.stats_encode(st, C, torch.stack([t.sum((0, 2, 3)), (t * t).sum((0, 2, 3))]))
     return st
   rm, rv = torch.zeros(C, device=d), torch.ones(C, device=d)
   nbt = torch.zeros((), dtype=torch.long, device=d)
@@ -480,7 +479,7 @@ def test_bn_forward_backward_kernels():
   ops.bn_bwd_reduce(dp, a_plain, yp, s_a, N, H, H, 1, C)
   ops.bn_bwd_reduce(dp, None, yp, s_m, N, H, H, 1, C, mask_coef=coef)
   torch.cuda.synchronize()
-  assert torch.allclose(s_a.sum(0), s_m.sum(0), rtol=1e-5, atol=1e-4)
+  assert torch.allclose(ops.stats_decode(s_a, C), ops.stats_decode(s_m, C), rtol=1e-5, atol=1e-4)
   bc_a, _, _ = ops.bn_bwd_finalize(s_a, gamma.to(d), coef, C, cnt)
   dy_a, dy_m = torch.zeros_like(yp), torch.zeros_like(yp)
   ops.bn_bwd_apply(dp, a_plain, yp, bc_a, dy_a, N, H, H, 1, C)
@@ -529,7 +528,7 @@ def test_bn_backward_kernel_generations_agree(N, H, W, P, C):
           ops.bn_bwd_apply(dout, a, y, bcoef, dy, N, H, W, P, C, y2=y2 if has2 else None,
                            bcoef2=bcoef2 if has2 else None, dy2=dy2 if has2 else None, mask_coef=mc)
           torch.cuda.synchronize()
-          res[gen] = (s1.sum(0), s2.sum(0), dy, dy2)
+          res[gen] = (ops.stats_decode(s1, C), ops.stats_decode(s2, C), dy, dy2)
         for k in (0, 1):
           ref, got = res[0][k], res[2][k]
           assert (ref - got).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item()) , (mode, has2, k)
@@ -572,7 +571,7 @@ def test_stem_forward_backward(cin, S):
   ops.stem_stats(xd, wd, st)
   torch.cuda.synchronize()
   cnt = N * S * S
-  ssum = st.sum(0).cpu()
+  ssum = ops.stats_decode(st, 64).float().cpu()
   assert torch.allclose(ssum[0] / cnt, y.detach().mean((0, 2, 3)), atol=1e-4)
   assert torch.allclose(ssum[1] / cnt, (y.detach() ** 2).mean((0, 2, 3)), rtol=1e-4, atol=1e-4)
   coef = ops.bn_finalize(st, gamma.to(d), beta.to(d), None, None, None, 64, cnt, True)
@@ -728,7 +727,7 @@ def test_full_size_kernel_generations_agree(cin, cout, H):
     finally:
       L.iic_debug_enable_wgrad_dma(1)
     torch.cuda.synchronize()
-    return y.float(), dx.float(), st.sum(0), dW
+    return y.float(), dx.float(), ops.stats_decode(st, cout), dW
 
   y1, dx1, st1, dW1 = run(True)
   y0, dx0, st0, dW0 = run(False)

@@ -41,7 +41,7 @@ def test_firstconv_forward_and_wgrad(cin, K, S, N):
   assert float((got - y.detach()).abs().max()) <= 1e-2 * scale
   assert out[:, :P].abs().max() == 0 and out[:, :, -P:].abs().max() == 0
   cnt = N * S * S
-  ssum = st.sum(0).cpu()
+  ssum = ops.stats_decode(st, 64).float().cpu()
   assert torch.allclose(ssum[0] / cnt, y.detach().mean((0, 2, 3)), atol=1e-4 * scale)
   assert torch.allclose(ssum[1] / cnt, (y.detach() ** 2).mean((0, 2, 3)), rtol=1e-4, atol=1e-5)
   dy = torch.from_numpy(rng.standard_normal(tuple(y.shape)).astype(np.float32)).to(torch.bfloat16).float()
