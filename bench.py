@@ -267,19 +267,18 @@ def main():
     base, tfs = aug.paired_batch(idx, 3)
     return base.repeat(3, 1, 1, 1), torch.cat(tfs, 0)
 
-  def step():
-    net.zero_grad(set_to_none=True)
-    bi, bt = next_batch() if aug is not None else (imgs, imgs_tf)
-    if use_branch:
-      with ops.branch():
-        xt = net.forward_packed(sobel_process(bt, False))
-      xo = net.forward_packed(sobel_process(bi, False))
-      ops.join()
-    else:
-      xo = net.forward_packed(sobel_process(bi, False))
-      xt = net.forward_packed(sobel_process(bt, False))
+  def loss_fn(xo, xt):
     loss, _ = IID_loss_heads(xo, xt, lamb=1.0)
-    loss = loss.mean()
+    return loss.mean()
+
+  def step():
+    # one stream, one view after the other (the eager path; N > 1; the instrumented steps)
+    net.zero_grad(set_to_none=True)
+    ops.clear_branch_grads()
+    bi, bt = next_batch() if aug is not None else (imgs, imgs_tf)
+    xo = net.forward_packed(sobel_process(bi, False))
+    xt = net.forward_packed(sobel_process(bt, False))
+    loss = loss_fn(xo, xt)
     loss.backward()
     if reducer is not None:
       reducer.finish()
@@ -295,9 +294,15 @@ def main():
     torch.cuda.synchronize()
 
   run = step
-  if use_graph:
+  if use_branch:
+    from iic_amd.graph import CapturedPairStep
+    run = CapturedPairStep(lambda: net.forward_packed(sobel_process(imgs, False)),
+                           lambda: net.forward_packed(sobel_process(imgs_tf, False)),
+                           loss_fn, opt.step, lambda: net.zero_grad(set_to_none=True),
+                           warmup=max(1, args.warmup))       # warm-up steps are real steps
+  elif use_graph:
     from iic_amd.graph import CapturedStep
-    run = CapturedStep(step, warmup=max(1, args.warmup))    # warm-up steps are real steps
+    run = CapturedStep(step, warmup=max(1, args.warmup))
   else:
     for _ in range(args.warmup):
       last = step()
@@ -346,8 +351,8 @@ def main():
                              "stem+heads+loss, fused HIP Adam" % args.pairs,
                  "global_batch_pairs": args.pairs * world, "input": "96x96x1 grey -> sobel 2ch",
                  "parallelism": "dp%d" % world, "final_loss": loss_val,
-                 "launch": ("hip-graph replay, two view branches" if use_branch else "hip-graph replay")
-                           if use_graph else "eager (python/ctypes)",
+                 "launch": ("hip-graph replay: 6 linear graphs, the two views on two streams" if use_branch
+                            else "hip-graph replay") if use_graph else "eager (python/ctypes)",
                  "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps,
                  "host_cpu_ms_per_step": 1e3 * c_enq / args.steps},
     }

@@ -51,3 +51,111 @@ class CapturedStep(object):
     # after a replay (evaluation, an un-captured step) must re-derive its bf16 weight operands
     bump_weights_epoch()
     return self.out
+
+
+class CapturedPairStep(object):
+  """The paired step as FIVE linear graphs on two streams:
+
+      [ view A forward ]  ||  [ view B forward ]        (stream 1 || stream 2)
+                 loss forward + backward                 (stream 1)
+      [ view A backward ] ||  [ view B backward ]
+                 optimiser                               (stream 1)
+
+  The two views of a step (net(all_imgs), net(all_imgs_tf): cluster_sobel.py:238-239) are
+  independent until the loss, so they can overlap on the GPU: the tail of one view's launch is
+  filled by the other view's next launch, and its HBM-bound BatchNorm passes run beside the other
+  view's MFMA-bound convolutions (iic_amd.ops.branch).  A single captured graph with two branches
+  does that too, but ROCm 7.0 launches a branched graph node by node (measured 20 ms of host time
+  per replay for this step); a LINEAR graph is launched as one pre-built packet list (0.3 ms).  So
+  each view's forward and backward is captured as its own linear graph, and the host orders the
+  six replays with stream waits -- same kernels, same arithmetic, bit-identical results.
+
+  view_a(), view_b(): forward of one view -> output tensor (view_b runs as branch 1);
+  loss_fn(xa, xb) -> scalar loss; finish(): optimiser step; zero_grad(): drop all gradients
+  (set_to_none).  Inputs are persistent tensors, as for CapturedStep."""
+
+  def __init__(self, view_a, view_b, loss_fn, finish, zero_grad, warmup=2):
+    from . import ops
+    assert torch.cuda.is_available(), "CapturedPairStep needs a device"
+    self.fns = (view_a, view_b, loss_fn, finish, zero_grad)
+    cur = torch.cuda.current_stream()
+    self.s1, self.s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    s1, s2 = self.s1, self.s2
+    s1.wait_stream(cur)
+    for _ in range(max(1, warmup)):
+      self._eager_step()
+    torch.cuda.synchronize()
+    zero_grad()
+    ops.clear_branch_grads()
+    pool_a, pool_b = torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle()
+    G = torch.cuda.CUDAGraph
+    self.g_fa, self.g_fb, self.g_l, self.g_ba, self.g_bb, self.g_opt = G(), G(), G(), G(), G(), G()
+    with torch.cuda.graph(self.g_fa, pool=pool_a, stream=s1):
+      xa = view_a()
+    with torch.cuda.graph(self.g_fb, pool=pool_b, stream=s2):
+      with ops.on_branch(1, s2):
+        xb = view_b()
+    with torch.cuda.graph(self.g_l, pool=pool_a, stream=s1):
+      ops.flush_deferred_running()
+      xa_d, xb_d = xa.detach().requires_grad_(True), xb.detach().requires_grad_(True)
+      loss = loss_fn(xa_d, xb_d)
+      loss.backward()
+      ga, gb = xa_d.grad, xb_d.grad
+      self.out = loss.detach()
+    with torch.cuda.graph(self.g_ba, pool=pool_a, stream=s1):
+      xa.backward(ga)
+    with torch.cuda.graph(self.g_bb, pool=pool_b, stream=s2):
+      xb.backward(gb)
+    with torch.cuda.graph(self.g_opt, pool=pool_a, stream=s1):
+      finish()
+    self._keep = (xa, xb, xa_d, xb_d, ga, gb)     # buffers that cross graph boundaries
+    cur.wait_stream(s1)
+    self.replays = 0
+
+  def _eager_step(self):
+    from . import ops
+    view_a, view_b, loss_fn, finish, zero_grad = self.fns
+    s1, s2 = self.s1, self.s2
+    zero_grad()
+    ops.clear_branch_grads()
+    s2.wait_stream(s1)
+    with ops.on_branch(1, s2):
+      xb = view_b()
+    with torch.cuda.stream(s1):
+      xa = view_a()
+      s1.wait_stream(s2)
+      ops.flush_deferred_running()
+      xa_d, xb_d = xa.detach().requires_grad_(True), xb.detach().requires_grad_(True)
+      loss = loss_fn(xa_d, xb_d)
+      loss.backward()
+    s2.wait_stream(s1)
+    with torch.cuda.stream(s2):
+      xb.backward(xb_d.grad)
+    with torch.cuda.stream(s1):
+      xa.backward(xa_d.grad)
+      s1.wait_stream(s2)
+      finish()
+    return loss.detach()
+
+  def __call__(self):
+    s1, s2 = self.s1, self.s2
+    cur = torch.cuda.current_stream()
+    s1.wait_stream(cur)
+    s2.wait_stream(s1)
+    with torch.cuda.stream(s2):
+      self.g_fb.replay()
+    with torch.cuda.stream(s1):
+      self.g_fa.replay()
+      s1.wait_stream(s2)
+      self.g_l.replay()
+    s2.wait_stream(s1)
+    with torch.cuda.stream(s2):
+      self.g_bb.replay()
+    with torch.cuda.stream(s1):
+      self.g_ba.replay()
+      s1.wait_stream(s2)
+      self.g_opt.replay()
+    cur.wait_stream(s1)
+    self.replays += 1
+    bump_weights_epoch()
+    return self.out

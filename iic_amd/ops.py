@@ -105,6 +105,26 @@ class branch(object):
     return False
 
 
+class on_branch(object):
+  """Low-level: run the enclosed code as branch `index` on `stream` WITHOUT any fork / join
+  synchronisation (iic_amd.graph.CapturedPairStep orders its per-view graphs itself)."""
+
+  def __init__(self, index, stream):
+    self.index, self.stream = index, stream
+
+  def __enter__(self):
+    assert BRANCH[0] == 0, "branches do not nest"
+    self.ctx = torch.cuda.stream(self.stream)
+    self.ctx.__enter__()
+    BRANCH[0] = self.index
+    return self
+
+  def __exit__(self, *exc):
+    BRANCH[0] = 0
+    self.ctx.__exit__(*exc)
+    return False
+
+
 def join():
   """Main stream waits for the side branches forked since the last join, then applies their
   postponed running-statistic updates (after the main view's own: sequential order)."""

@@ -99,7 +99,7 @@ def test_adam_second_gradient_source():
   ops.clear_branch_grads()
 
 
-@pytest.mark.parametrize("mode", ["graph", "branch", "graph+branch"])
+@pytest.mark.parametrize("mode", ["graph", "branch", "graph+branch", "pair"])
 def test_captured_and_branched_steps_track_the_eager_step(mode):
   from iic_amd.graph import CapturedStep
   from iic_amd.optim import Adam
@@ -108,10 +108,19 @@ def test_captured_and_branched_steps_track_the_eager_step(mode):
   for name in ("eager", mode):
     net = _net()
     graph, branch = "graph" in name, "branch" in name
-    opt = Adam(net.parameters(), lr=2e-4, capturable=graph)
+    opt = Adam(net.parameters(), lr=2e-4, capturable=graph or name == "pair")
     step = _make_step(net, opt, imgs, imgs_tf, branch)
-    run = CapturedStep(step, warmup=2) if graph else step
-    if not graph:
+    if name == "pair":       # five linear graphs on two streams
+      from iic_amd.graph import CapturedPairStep
+      from iic_amd.losses import IID_loss_heads
+      from iic_amd.transforms import sobel_process
+      run = CapturedPairStep(lambda: net.forward_packed(sobel_process(imgs, False)),
+                             lambda: net.forward_packed(sobel_process(imgs_tf, False)),
+                             lambda a, b: IID_loss_heads(a, b, lamb=1.0)[0].mean(), opt.step,
+                             lambda: net.zero_grad(set_to_none=True), warmup=2)
+    else:
+      run = CapturedStep(step, warmup=2) if graph else step
+    if not graph and name != "pair":
       step(); step()
     losses = [float(run()) for _ in range(6)]
     torch.cuda.synchronize()
