@@ -502,9 +502,14 @@ static int g_bn_v2 = 1;
 static int g_bn_v2_blocks = 1024;
 
 // chunk of pixels per block: a multiple of 2*PL so that every thread's pair loop stays aligned
-static void bn_v2_grid(long npx, int C, long& per, int& grid) {
+// reduce != 0: the reduction kernels end with 2C (3C) integer atomics per block into the exact
+// statistic accumulators -- at C >= 256 a 1024-block grid spends more time in those than in its
+// HBM stream (measured at 7x7x512: 48.8 us with 1024 blocks, 21.7 us with 256; tools/bn_perf.py)
+static void bn_v2_grid(long npx, int C, long& per, int& grid, int reduce = 0) {
   const int PL = 256 / (C >> 3);
-  long p = (npx + g_bn_v2_blocks - 1) / g_bn_v2_blocks;
+  int blocks = g_bn_v2_blocks;
+  if (reduce && g_bn_v2_blocks == 1024) blocks = C <= 128 ? 512 : 256;
+  long p = (npx + blocks - 1) / blocks;
   p = (p + 2 * PL - 1) / (2 * PL) * (2 * PL);
   per = p;
   grid = (int)((npx + p - 1) / p);
@@ -583,7 +588,7 @@ int iic_bn_bwd_reduce(const void* dout, const void* act, const void* y, const vo
   if (g_bn_v2) {
     long per;
     int grid2;
-    bn_v2_grid((long)N * H * W, C, per, grid2);
+    bn_v2_grid((long)N * H * W, C, per, grid2, 1);
 #define BN_RED2_LAUNCH(M_, H2_)                                                                 \
   hipLaunchKernelGGL((bn_bwd_reduce2_kernel<M_, H2_>), dim3(grid2), dim3(256), 0,               \
                      (hipStream_t)stream, (const bf16_t*)dout, (const bf16_t*)act,              \
