@@ -134,6 +134,50 @@ def cpu_baseline(n_pairs=96, steps=3, budget_s=90.0):
                     % (n_pairs, len(times) - 1)}
 
 
+def cpu_baseline_mnist(batch=700, budget_s=40.0):
+  """BASELINE.json configs[0] -- the reference's own CPU-runnable case: MNIST 24x24,
+  ClusterNet6cTwoHead (k_A 50 overclustering / k_B 10), batch 700, 5 sub-heads
+  (cluster_greyscale_twohead.py; examples/commands.txt:30) -- one head-A step + one head-B step
+  of the oracle restatement on the host cores, FULL batch.  Reported beside the north-star CPU
+  baseline."""
+  from oracle import iid_oracle, net_oracle
+  torch.set_num_threads(min(os.cpu_count() or 1, 32))
+  params = net_oracle.make_net6c_params(1, 24, num_sub_heads=SUB_HEADS, batchnorm_track=True, seed=0,
+                                        heads=("head_A", "head_B"), output_ks=[50, 10])
+  leaves = []
+  for k, v in params.items():
+    if v.dtype.is_floating_point and "running" not in k:
+      v.requires_grad_(True)
+      leaves.append(v)
+  opt = torch.optim.Adam(leaves, lr=1e-4)
+  imgs, imgs_tf = net_oracle.make_paired_batch(batch - batch % 5, 24, 5, seed=0)
+
+  def one(head):
+    opt.zero_grad()
+    xo = net_oracle.net6c_forward(params, imgs, True, head, SUB_HEADS)
+    xt = net_oracle.net6c_forward(params, imgs_tf, True, head, SUB_HEADS)
+    tot = None
+    for i in range(SUB_HEADS):
+      l, _ = iid_oracle.IID_loss(xo[i], xt[i], lamb=1.0)
+      tot = l if tot is None else tot + l
+    (tot / SUB_HEADS).backward()
+    opt.step()
+  times, t_start = [], time.time()
+  for s in range(4):
+    if s >= 2 and time.time() - t_start > budget_s:
+      break
+    t0 = time.time()
+    one("head_A")
+    one("head_B")
+    times.append(time.time() - t0)
+  t = sorted(times[1:])[len(times[1:]) // 2]
+  return {"value": imgs.size(0) / t, "unit": "paired-images/sec (one head-A + one head-B step per batch)",
+          "cores": torch.get_num_threads(), "kind": "port",
+          "sample": "BASELINE configs[0]: MNIST 24x24 ClusterNet6cTwoHead k_A 50 / k_B 10, batch %d, 5 "
+                    "sub-heads, %d timed A+B step pairs (+1 warm-up), fp32 torch-CPU restatement"
+                    % (imgs.size(0), len(times) - 1)}
+
+
 def reference_api_rate(cfg, dev, imgs, imgs_tf, pairs, steps):
   """The same step through the reference's OWN call sequence (cluster_sobel.py:235-272 as the
   unchanged script issues it): net(x) -> python list of sub-head tensors, IID_loss once per
@@ -375,6 +419,7 @@ def main():
       out["config"]["reference_api"] = ref_api
     if world == 1 and not args.no_cpu_baseline:
       out["cpu_baseline"] = cpu_baseline()
+      out["cpu_baseline"]["configs0_mnist"] = cpu_baseline_mnist()
     print(json.dumps(out))
   if world > 1:
     torch.distributed.destroy_process_group()

@@ -45,6 +45,8 @@ _SIGNATURES = {
   "iic_seg_joint_raw": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
   "iic_seg_loss_from_joint": (c_int, [_P, c_int, c_int, c_int, c_double, c_double, _P, _P, _P, _P, _P, c_int, _P]),
   "iic_seg_grad": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+  "iic_affine_warp_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+  "iic_affine_warp_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
   "iic_conv_lds_bytes": (c_long, [POINTER(ConvGeom), c_int]),
   "iic_conv_igemm": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P, _P, _P, c_int, _P]),
   "iic_conv_wgrad_nsplit": (c_int, [POINTER(ConvGeom)]),

@@ -57,6 +57,27 @@ from ..dist import SHARD_INPUTS, shard_batch  # noqa: E402  (set by iic_amd.run 
 # running_var factor uses the true batch size.  Removes 1/3 of view 1's conv work at r = 3.
 # NOT used by bench.py (it would change the FLOP accounting of the metric).
 DEDUP = [int(os.environ.get("IIC_DEDUP", "1"))]
+_ASSERTED_REPLICAS = [1]
+
+
+class replicated(object):
+  """``with replicated(r): out = net(all_imgs)`` -- the CALLER asserts that the batch is r exact
+  copies of its first B/r rows (it built it that way: cluster_sobel.py:215-226), so the trunk
+  de-duplicates without comparing the rows.  The IIC_DEDUP / DEDUP[0] switch serves unchanged
+  scripts, which cannot say which of their two forwards carries the replicated batch: there the
+  rows are compared on the device and the verdict is read back (one host sync per forward)."""
+
+  def __init__(self, r):
+    self.r = int(r)
+
+  def __enter__(self):
+    self.prev = _ASSERTED_REPLICAS[0]
+    _ASSERTED_REPLICAS[0] = self.r
+    return self
+
+  def __exit__(self, *exc):
+    _ASSERTED_REPLICAS[0] = self.prev
+    return False
 # Pre-masked gradient chain through the residual trunk (IIC_PREMASK=0 disables it).  Every block
 # hands its input gradient over already multiplied by the ReLU mask of that input (the conv
 # backward-data epilogue applies it: IIC_ACC_PREMASK), and the average-pool backward does the same
@@ -481,10 +502,11 @@ class ClusterNet5gTrunk(nn.Module):
 
   def forward(self, x, penultimate_features=False):
     x = shard_batch(x, self)
-    r = DEDUP[0]
+    asserted = _ASSERTED_REPLICAS[0] > 1
+    r = _ASSERTED_REPLICAS[0] if asserted else DEDUP[0]
     if r > 1 and self.training and x.size(0) % r == 0 and x.size(0) >= 2 * r:
       u = x.size(0) // r
-      if all(bool(torch.equal(x[:u], x[i * u:(i + 1) * u])) for i in range(1, r)):
+      if asserted or all(bool(torch.equal(x[:u], x[i * u:(i + 1) * u])) for i in range(1, r)):
         ops.BN_REPLICAS[0] = r
         try:
           f = self._run(x[:u], penultimate_features)

@@ -3,10 +3,11 @@
 
 Mirrors /root/reference/code/utils/segmentation/IID_losses.py:14-159 -- same keyword
 signature, same asserts (inputs require grad; affine / mask do not), returns
-(loss, loss_no_lamb) 0-d tensors.  Supported transforms: identity and axis flips (what
+(loss, loss_no_lamb) 0-d tensors.  Identity and axis-flip affine2_to_1 matrices (what
 potsdam.py:189-202 / cocostuff.py produce unless --use_random_affine, which no published run
-sets); the sparse random shift (half_T_side_sparse_*) must be 0 as in every published run.
-Anything else raises NotImplementedError -- there is no silent fallback.
+sets) are folded into the kernels' index arithmetic; general matrices (perform_affine_tf,
+transforms.py:131-143) and the sparse random translation (IID_losses.py:101-104,
+transforms.py:145-165) go through an explicit warp of the second view (csrc/warp.hip).
 
 Data-parallel: the raw per-shift joints are all-reduced (SUM) like the clustering loss.
 """
@@ -22,17 +23,85 @@ EPS = float_info.epsilon
 F32 = torch.float32
 
 
+# F.affine_grid / F.grid_sample convention of perform_affine_tf.  False = what the reference's code
+# does on the torch of this image (>= 1.3 default; the goldens were produced that way); True = the
+# behaviour of the reference's pinned torch 0.4.1.  Identity / flip matrices are exact under both.
+ALIGN_CORNERS = [False]
+
+
 def _flips_from_affine(aff):
-  """[bn, 2, 3] -> int32 [bn, 2] (flip x, flip y); raises on anything but identity / flips."""
+  """[bn, 2, 3] (host) -> int32 [bn, 2] (flip x, flip y), or None for anything but identity /
+  axis flips (the general warp kernel handles those)."""
   a = aff.detach().float().cpu()
   lin, tr = a[:, :, :2], a[:, :, 2]
   ok = (tr.abs() < 1e-6).all() and (lin[:, 0, 1].abs() < 1e-6).all() and \
        (lin[:, 1, 0].abs() < 1e-6).all() and ((lin[:, 0, 0].abs() - 1).abs() < 1e-6).all() and \
        ((lin[:, 1, 1].abs() - 1).abs() < 1e-6).all()
   if not bool(ok):
-    raise NotImplementedError("HIP IID_segmentation_loss supports identity / axis-flip "
-                              "affine2_to_1 only (general warps: SURVEY.md §8a A7)")
+    return None
   return torch.stack([(lin[:, 0, 0] < 0), (lin[:, 1, 1] < 0)], dim=1).to(torch.int32)
+
+
+def _pixel_matrices(aff, H, W):
+  """theta [bn, 2, 3] in normalised coordinates (F.affine_grid) -> [bn, 6] pixel-space rows:
+  source pixel (ix, iy) = M (ox, oy, 1), for the grid_sample un-normalisation in use."""
+  t = aff.detach().double().cpu()
+  M = torch.empty((t.size(0), 6), dtype=torch.float64)
+  if ALIGN_CORNERS[0]:
+    # xn = 2 ox / (W-1) - 1 ; ix = (xs + 1) (W-1) / 2
+    ax, ay = (W - 1) / 2.0, (H - 1) / 2.0
+    M[:, 0] = t[:, 0, 0]
+    M[:, 1] = t[:, 0, 1] * ax / ay if H > 1 else 0.0
+    M[:, 2] = ax * (-t[:, 0, 0] - t[:, 0, 1] + t[:, 0, 2] + 1.0)
+    M[:, 3] = t[:, 1, 0] * ay / ax if W > 1 else 0.0
+    M[:, 4] = t[:, 1, 1]
+    M[:, 5] = ay * (-t[:, 1, 0] - t[:, 1, 1] + t[:, 1, 2] + 1.0)
+  else:
+    # xn = (2 ox + 1) / W - 1 ; ix = ((xs + 1) W - 1) / 2
+    M[:, 0] = t[:, 0, 0]
+    M[:, 1] = t[:, 0, 1] * W / H
+    M[:, 2] = (W / 2.0) * (t[:, 0, 0] / W - t[:, 0, 0] + t[:, 0, 1] / H - t[:, 0, 1] + t[:, 0, 2] + 1.0) - 0.5
+    M[:, 3] = t[:, 1, 0] * H / W
+    M[:, 4] = t[:, 1, 1]
+    M[:, 5] = (H / 2.0) * (t[:, 1, 0] / W - t[:, 1, 0] + t[:, 1, 1] / H - t[:, 1, 1] + t[:, 1, 2] + 1.0) - 0.5
+  return M.float()
+
+
+class _AffineWarpFn(torch.autograd.Function):
+  """perform_affine_tf + random_translation_multiple of the second view (csrc/warp.hip)."""
+
+  @staticmethod
+  def forward(ctx, x, mats, sx, sy):
+    assert x.is_cuda and x.dtype == F32 and x.dim() == 4
+    x = x.contiguous()
+    n, k, h, w = x.shape
+    out = torch.empty_like(x)
+    check(lib().iic_affine_warp_fwd(ptr(x), ptr(mats), ptr(out), n, k, h, w, int(sx), int(sy),
+                                    stream_ptr()), "iic_affine_warp_fwd")
+    ctx.save_for_backward(mats)
+    ctx.meta = (n, k, h, w, int(sx), int(sy))
+    return out
+
+  @staticmethod
+  def backward(ctx, dout):
+    mats, = ctx.saved_tensors
+    n, k, h, w, sx, sy = ctx.meta
+    dout = dout.contiguous()
+    dx = torch.empty_like(dout)
+    check(lib().iic_affine_warp_bwd(ptr(dout), ptr(mats), ptr(dx), n, k, h, w, sx, sy, stream_ptr()),
+          "iic_affine_warp_bwd")
+    return dx, None, None, None
+
+
+def _draw_sparse_shift(half_side_min, half_side_max):
+  """The displacement random_translation_multiple draws (transforms.py:155-161), from numpy's
+  global RNG with the reference's own sequence of calls; returns (shift_x, shift_y) such that
+  out[y][x] = in[y + shift_y][x + shift_x]."""
+  import numpy as np
+  t = np.random.randint(half_side_min, half_side_max + 1, size=(2,))
+  polarities = np.random.choice([-1, 1], size=(2,), replace=True)
+  t *= polarities
+  return int(t[0]), int(t[1])
 
 
 class _SegLossFn(torch.autograd.Function):
@@ -89,13 +158,20 @@ def _seg_loss(x1_outs, x2_outs, all_affine2_to_1, all_mask_img1, lamb, half_T_si
   assert not all_affine2_to_1.requires_grad
   assert not all_mask_img1.requires_grad
   assert x1_outs.shape == x2_outs.shape
-  if (half_T_side_sparse_min != 0) or (half_T_side_sparse_max != 0):
-    raise NotImplementedError("sparse random translation (half_T_side_sparse_*) is off in every "
-                              "published run and not implemented on the HIP path")
   # unchanged scripts under torchrun hand over full-batch masks / affines with sharded outputs
   all_affine2_to_1 = iic_dist.shard_like(all_affine2_to_1, x1_outs.size(0))
   all_mask_img1 = iic_dist.shard_like(all_mask_img1, x1_outs.size(0))
-  flips = _flips_from_affine(all_affine2_to_1).to(x1_outs.device)
+  sparse = (half_T_side_sparse_min != 0) or (half_T_side_sparse_max != 0)
+  flips = _flips_from_affine(all_affine2_to_1)
+  if flips is None or sparse:
+    # general matrices (--use_random_affine) and / or the sparse random translation
+    # (IID_losses.py:101-104): warp the second view explicitly, then the flip-free loss kernels
+    bn, _, h, w = x2_outs.shape
+    sx, sy = _draw_sparse_shift(half_T_side_sparse_min, half_T_side_sparse_max) if sparse else (0, 0)
+    mats = _pixel_matrices(all_affine2_to_1, h, w).to(x2_outs.device)
+    x2_outs = _AffineWarpFn.apply(x2_outs, mats, sx, sy)
+    flips = torch.zeros((bn, 2), dtype=torch.int32)
+  flips = flips.to(x1_outs.device)
   T = int(half_T_side_dense)
   loss, loss_nl = _SegLossFn.apply(x1_outs, x2_outs, flips, all_mask_img1, lamb, T, collapsed)
   if collapsed:

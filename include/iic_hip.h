@@ -78,6 +78,18 @@ int iic_seg_grad(const float* src, const float* mask, const int* flips, const fl
                  const float* dR_loss_no_lamb, const float* g_loss, const float* g_loss_no_lamb,
                  float* out, int bn, int k, int h, int w, int T, int which, int collapsed,
                  void* stream);
+/* General case of the second view's warp -- perform_affine_tf (code/utils/segmentation/
+ * transforms.py:131-143: affine_grid + grid_sample, bilinear, zero padding) followed by the
+ * whole-batch integer shift of random_translation_multiple (transforms.py:145-165; IID_losses.py:
+ * 101-104).  x, out, dout, dx: fp32 NCHW [N][K][H][W]; pixel_mats: fp32 [N][6], source pixel
+ * (ix, iy) = M * (ox + shift_x, oy + shift_y, 1) (the host derives M from theta in normalised
+ * coordinates); output pixels whose shifted position leaves the image are 0.  Identity / flip
+ * matrices without shift never come here: they are index arithmetic inside iic_seg_joint_raw /
+ * iic_seg_grad (flips).  iic_affine_warp_bwd overwrites dx.                                 */
+int iic_affine_warp_fwd(const float* x, const float* pixel_mats, float* out, int N, int K, int H, int W,
+                        int shift_x, int shift_y, void* stream);
+int iic_affine_warp_bwd(const float* dout, const float* pixel_mats, float* dx, int N, int K, int H, int W,
+                        int shift_x, int shift_y, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * Convolution as an im2col-free implicit GEMM on bf16 MFMA (fp32 accumulate).

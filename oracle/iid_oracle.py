@@ -130,10 +130,26 @@ def perform_affine_tf(data, tf_matrices):
   return F.grid_sample(data, grid, padding_mode="zeros", align_corners=False)
 
 
-def _seg_joint(x1_outs, x2_outs, all_affine2_to_1, all_mask_img1, half_T_side_dense):
-  """segmentation/IID_losses.py:27-56 / 99-126 (sparse shift off, as in all
-  published runs): returns p_i_j [k, k, 2T+1, 2T+1]."""
+def random_translation_multiple(data, half_side_min, half_side_max):
+  """segmentation/transforms.py:145-165: ONE random (x, y) displacement for the whole batch, drawn
+  from numpy's global RNG exactly as the reference draws it (magnitude in [min, max] per axis,
+  random sign per axis), applied by zero padding + cropping."""
+  n, c, h, w = data.shape
+  data = F.pad(data, (half_side_max, half_side_max, half_side_max, half_side_max), "constant", 0)
+  t = np.random.randint(half_side_min, half_side_max + 1, size=(2,))
+  polarities = np.random.choice([-1, 1], size=(2,), replace=True)
+  t *= polarities
+  t += half_side_max
+  return data[:, :, t[1]:(t[1] + h), t[0]:(t[0] + w)]
+
+
+def _seg_joint(x1_outs, x2_outs, all_affine2_to_1, all_mask_img1, half_T_side_dense,
+               half_T_side_sparse_min=0, half_T_side_sparse_max=0):
+  """segmentation/IID_losses.py:27-56 / 99-126: returns p_i_j [k, k, 2T+1, 2T+1]."""
   x2_outs_inv = perform_affine_tf(x2_outs, all_affine2_to_1)
+  if (half_T_side_sparse_min != 0) or (half_T_side_sparse_max != 0):      # :101-104
+    x2_outs_inv = random_translation_multiple(x2_outs_inv, half_side_min=half_T_side_sparse_min,
+                                              half_side_max=half_T_side_sparse_max)
   bn, k, h, w = x1_outs.shape
   m = all_mask_img1.view(bn, 1, h, w)
   x1 = (x1_outs * m).permute(1, 0, 2, 3).contiguous()
@@ -145,9 +161,9 @@ def IID_segmentation_loss(x1_outs, x2_outs, all_affine2_to_1=None, all_mask_img1
                           lamb=1.0, half_T_side_dense=None,
                           half_T_side_sparse_min=0, half_T_side_sparse_max=0):
   """segmentation/IID_losses.py:14-83 (collapsed; normaliser detached :60)."""
-  assert half_T_side_sparse_min == 0 and half_T_side_sparse_max == 0
   k = x1_outs.shape[1]
-  p_i_j = _seg_joint(x1_outs, x2_outs, all_affine2_to_1, all_mask_img1, half_T_side_dense)
+  p_i_j = _seg_joint(x1_outs, x2_outs, all_affine2_to_1, all_mask_img1, half_T_side_dense,
+                     half_T_side_sparse_min or 0, half_T_side_sparse_max or 0)
   p_i_j = p_i_j.sum(dim=2, keepdim=False).sum(dim=2, keepdim=False)  # k, k
   current_norm = float(p_i_j.sum())
   p_i_j = p_i_j / current_norm
@@ -169,9 +185,9 @@ def IID_segmentation_loss_uncollapsed(x1_outs, x2_outs, all_affine2_to_1=None,
                                       all_mask_img1=None, lamb=1.0, half_T_side_dense=None,
                                       half_T_side_sparse_min=0, half_T_side_sparse_max=0):
   """segmentation/IID_losses.py:86-159."""
-  assert half_T_side_sparse_min == 0 and half_T_side_sparse_max == 0
   k = x1_outs.shape[1]
-  p_i_j = _seg_joint(x1_outs, x2_outs, all_affine2_to_1, all_mask_img1, half_T_side_dense)
+  p_i_j = _seg_joint(x1_outs, x2_outs, all_affine2_to_1, all_mask_img1, half_T_side_dense,
+                     half_T_side_sparse_min or 0, half_T_side_sparse_max or 0)
   T_side_dense = half_T_side_dense * 2 + 1
   p_i_j = p_i_j.permute(2, 3, 0, 1)
   p_i_j = p_i_j / p_i_j.sum(dim=3, keepdim=True).sum(dim=2, keepdim=True)

@@ -167,3 +167,31 @@ def test_eval_metrics_oracle_matches_reference():
       for a, b in hm:
         re[p == a] = b
       assert abs(eval_oracle.acc(re, t) - float(g["c%d/acc" % i][0])) < 1e-12
+
+
+# ---- second segmentation fixture: BASELINE shapes, general affine, sparse shift ------------
+from oracle.gen_golden_seg2 import SEG2_CASES, case_inputs  # noqa: E402
+
+
+@pytest.mark.parametrize("case", SEG2_CASES, ids=[c[0] for c in SEG2_CASES])
+def test_seg_loss_oracle_matches_reference_fixture2(case):
+  g = np.load(os.path.join(G, "iid_seg_loss2.npz"))
+  name, bn, k, h, w, T, lamb, ff, mp, seed, affine, smin, smax, np_seed = case
+  x1, x2, aff, mask = case_inputs(case)
+  for vname, fn in (("unc", iid_oracle.IID_segmentation_loss_uncollapsed),
+                    ("col", iid_oracle.IID_segmentation_loss)):
+    for tag, dt, tol in (("f32", torch.float32, 1e-5), ("f64", torch.float64, 1e-11)):
+      a = torch.from_numpy(x1).to(dt).requires_grad_(True)
+      b = torch.from_numpy(x2).to(dt).requires_grad_(True)
+      np.random.seed(np_seed)
+      l, ln = fn(a, b, all_affine2_to_1=torch.from_numpy(aff).to(dt),
+                 all_mask_img1=torch.from_numpy(mask).to(dt), lamb=lamb, half_T_side_dense=T,
+                 half_T_side_sparse_min=smin, half_T_side_sparse_max=smax)
+      l.backward()
+      ref = g["%s_%s_loss_%s" % (name, vname, tag)]
+      assert abs(float(l) - ref[0]) <= tol * max(1.0, abs(ref[0]))
+      assert abs(float(ln) - ref[1]) <= tol * max(1.0, abs(ref[1]))
+      if tag == "f64":
+        for t, key in ((a, "dx1"), (b, "dx2")):
+          gref = g["%s_%s_%s" % (name, vname, key)]
+          assert np.abs(t.grad.numpy() - gref).max() <= 1e-6 * max(1e-6, np.abs(gref).max())
