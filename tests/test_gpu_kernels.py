@@ -739,6 +739,77 @@ def test_full_size_kernel_generations_agree(cin, cout, H):
   assert float((dW1 - dW0).abs().max()) <= 1e-4 * float(dW0.abs().max())
 
 
+@pytest.mark.parametrize("cin,cout,H", [(64, 64, 49), (128, 128, 25), (256, 256, 13), (512, 512, 7)])
+def test_full_size_kernels_vs_independent_reference(cin, cout, H):
+  """The full-batch (660 images) launches of the second-generation kernels -- 256-row tiles,
+  XCD-remapped order, persistent 64->64 kernel, DMA weight gradient -- against an INDEPENDENT
+  reference, not against the first kernel generation:
+    * forward / backward-data: F.conv2d / conv_transpose2d in fp64 on the CPU, same bf16-rounded
+      operands, on a strided sample of images that includes the first and last image, the images
+      around a 256-row tile boundary and the last (partial) tile;
+    * BatchNorm statistics: sum / sum of squares of the kernel's own full output tensor;
+    * weight gradient: the FULL 660-image contraction by torch on the device in fp32
+      (an einsum over the unfolded input: independent of libiic_hip)."""
+  import torch.nn.functional as F
+  from iic_amd import geom, ops
+  N = 660
+  g0 = torch.Generator(device="cpu").manual_seed(3 * cin + H)
+  x = torch.randn(N, H + 2, H + 2, cin, generator=g0).to(torch.bfloat16)
+  x[:, 0] = 0; x[:, -1] = 0; x[:, :, 0] = 0; x[:, :, -1] = 0
+  dy = torch.randn(N, H + 2, H + 2, cout, generator=g0).to(torch.bfloat16)
+  dy[:, 0] = 0; dy[:, -1] = 0; dy[:, :, 0] = 0; dy[:, :, -1] = 0
+  w = torch.randn(cout, cin, 3, 3, generator=g0) / math.sqrt(cin * 9)
+  xd, dyd, wd = x.to(dev()), dy.to(dev()), w.to(dev())
+  spec = geom.ConvSpec(cin, cout, 3, 1, 1)
+  gf = geom.fwd_geom(spec, N, H, H, 1, 1)
+  gb = geom.bwd_data_geoms(spec, N, H, H, 1, 1)
+  pw = ops.PreppedWeights(wd)
+  assert ops.frag_supported(gf) and all(ops.frag_supported(g) for g in gb)
+  y = torch.zeros(N, H + 2, H + 2, cout, dtype=torch.bfloat16, device=dev())
+  dx = torch.zeros(N, H + 2, H + 2, cin, dtype=torch.bfloat16, device=dev())
+  st = ops.new_stats(cout, dev())
+  ops.conv_igemm(gf, xd, pw[0], y, stats=st)
+  for g in gb:
+    ops.conv_igemm(g, dyd, pw[1], dx)
+  dW = ops.conv_wgrad(gf, xd, dyd, 9, use_tr=True).view(cout, cin, 3, 3).clone()
+  torch.cuda.synchronize()
+  # ---- sampled images: ends, a stride through the batch, both sides of 256-row tile boundaries
+  per = H * H
+  edge = sorted(set(t * 256 // per for t in (1, 2, 97, 1000, (N * per) // 256)) |
+                set(t * 256 // per - 1 for t in (1, 97, 1000)))
+  sample = sorted(set([0, 1, N - 2, N - 1] + list(range(5, N, 83)) + [i for i in edge if 0 <= i < N]))
+  wq = w.to(torch.bfloat16).double()
+  xs = x[sample, 1:-1, 1:-1, :].double().permute(0, 3, 1, 2)
+  ds = dy[sample, 1:-1, 1:-1, :].double().permute(0, 3, 1, 2)
+  y_ref = F.conv2d(xs, wq, padding=1)
+  dx_ref = F.conv_transpose2d(ds, wq, padding=1)
+  y_k = y[sample, 1:-1, 1:-1, :].double().cpu().permute(0, 3, 1, 2)
+  dx_k = dx[sample, 1:-1, 1:-1, :].double().cpu().permute(0, 3, 1, 2)
+  for k_, r_ in ((y_k, y_ref), (dx_k, dx_ref)):
+    # fp32 accumulation + one bf16 rounding of the stored value
+    assert float((k_ - r_).abs().max()) <= 2 ** -7 * float(r_.abs().max()), float((k_ - r_).abs().max())
+    assert float((k_ - r_).abs().mean()) <= 2 ** -9 * float(r_.abs().mean())
+  # borders stay zero (kernels write interiors only)
+  assert float(y[:, 0].abs().max()) == 0 and float(y[:, :, -1].abs().max()) == 0
+  # ---- statistics of the stored tensor (the kernel sums its fp32 accumulators before rounding)
+  yi = y[:, 1:-1, 1:-1, :].double()
+  s_ref = torch.stack([yi.sum((0, 1, 2)), (yi * yi).sum((0, 1, 2))])
+  s_k = ops.stats_decode(st, cout)
+  cnt = N * per
+  assert float(((s_k[0] - s_ref[0]) / cnt).abs().max()) <= 2e-4 * float(yi.abs().mean())
+  assert torch.allclose(s_k[1], s_ref[1], rtol=2e-4)
+  # ---- full weight gradient by torch on the device (fp32 accumulate of bf16 operands)
+  xi = xd[:, :, :, :].float()
+  dyi = dyd[:, 1:-1, 1:-1, :].float()
+  dW_ref = torch.empty(cout, cin, 3, 3, device=dev())
+  for kh in range(3):
+    for kw in range(3):
+      patch = xi[:, kh:kh + H, kw:kw + H, :]
+      dW_ref[:, :, kh, kw] = torch.einsum("nyxo,nyxi->oi", dyi, patch)
+  err = float((dW - dW_ref).abs().max()) / float(dW_ref.abs().max())
+  assert err <= 2e-4, err
+
+
 def test_eval_matching_against_reference_golden():
   """iic_amd.eval_metrics (one contingency kernel) vs the reference's own matching functions
   (tests/golden/eval.npz) -- integer work, exact; plus a large random case vs the oracle."""
