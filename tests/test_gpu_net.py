@@ -111,8 +111,10 @@ def test_net5g_small_vs_reference_golden(use_tr):
   # run-to-run the loss takes a few discrete values (-0.01492 ... -0.01590 over 16 runs: the order
   # of the fp32 atomics behind the BN statistics differs, one pooling arg-max / ReLU flips, and the
   # 24-image batch-stat net amplifies it): 10 % like the criterion against the fp32 reference
-  assert abs(report["loss"] - report["loss_bf16emu"]) < 1e-1 * abs(report["loss_bf16emu"]) + 1e-4, report
-  assert abs(report["loss"] - report["loss_fp32_reference"]) < 1e-1 * abs(report["loss_fp32_reference"]), report
+  # (round 2: statistics are accumulated exactly, the run is bit-reproducible: measured 2.3 % from
+  # the emulation and 1.8 % from the fp32 reference, every run)
+  assert abs(report["loss"] - report["loss_bf16emu"]) < 5e-2 * abs(report["loss_bf16emu"]), report
+  assert abs(report["loss"] - report["loss_fp32_reference"]) < 5e-2 * abs(report["loss_fp32_reference"]), report
   # gradients vs the bf16-emulating oracle (straight-through rounding)
   table = []
   for n, p in net.named_parameters():
@@ -140,7 +142,7 @@ def test_net5g_small_vs_reference_golden(use_tr):
   # cosine 0.96 (layer4) -> 0.82 (layer1), median 0.87, min 0.76.  The HIP path must be in
   # that class w.r.t. the emulation; tight gradient parity is the teacher-forced block test.
   cs = np.array([c for _, c, _ in table])
-  assert np.median(cs) >= 0.8 and cs.min() >= 0.6, (float(np.median(cs)), float(cs.min()))
+  assert np.median(cs) >= 0.85 and cs.min() >= 0.75, (float(np.median(cs)), float(cs.min()))
   # stem parameters: feed OUR upstream gradient into an fp32 CPU reference of the stem
   # (conv3x3 + BN + ReLU + maxpool) -- isolates the stem kernels from upstream bf16 noise.
   import torch.nn.functional as F
@@ -435,6 +437,75 @@ def test_basic_block_teacher_forced(layer, bidx, cin, planes, stride, H):
     assert c >= 0.998 and abs(r - 1) < 2e-2, (n, c, r)
   assert torch.allclose(blk.bn1.running_mean.cpu(), params[pre + ".bn1.running_mean"], atol=1e-3)
   assert torch.allclose(blk.bn2.running_var.cpu(), params[pre + ".bn2.running_var"], rtol=1e-2, atol=1e-3)
+
+
+@pytest.mark.parametrize("layer,nblk,cin,planes,stride,H", [
+  (1, 3, 64, 64, 1, 17), (2, 4, 64, 128, 2, 17), (3, 6, 128, 256, 2, 9), (4, 3, 256, 512, 2, 9)])
+def test_residual_layer_teacher_forced(layer, nblk, cin, planes, stride, H):
+  """A whole residual LAYER (3-6 BasicBlocks through the trunk's own pre-masked gradient chain)
+  against the bf16-emulating oracle on the same input / upstream gradient: the tight tier between
+  the single-block test and the whole (chaotic) net -- nothing but accumulation order separates
+  the two sides, over up to 12 convolutions and 13 BatchNorms."""
+  from iic_amd import ops
+  from iic_amd.archs import cluster as cl
+  from oracle import net_oracle
+  N = 16
+  rng = np.random.default_rng(100 + layer)
+  full = net_oracle.make_net5g_params(2, 10, 2, True, seed=3, randomize_bn=True)
+  cfg = _cfg(input_sz=32, num_sub_heads=2, output_k=10)
+  from iic_amd import archs
+  net = archs.ClusterNet5g(cfg)
+  net.load_state_dict(full, strict=True)
+  net.to(dev()).train()
+  blocks = list(getattr(net.trunk, "layer%d" % layer))
+  assert len(blocks) == nblk
+  pres = ["trunk.layer%d.%d" % (layer, i) for i in range(nblk)]
+  params = {k: v.clone() for k, v in full.items() if any(k.startswith(p + ".") for p in pres)}
+  for k, v in params.items():
+    if v.dtype.is_floating_point and "running" not in k:
+      v.requires_grad_(True)
+  x = torch.from_numpy(rng.standard_normal((N, cin, H, H)).astype(np.float32)).relu().to(torch.bfloat16).float()
+  Ho = (H + 2 - 3) // stride + 1
+  dout = torch.from_numpy(rng.standard_normal((N, planes, Ho, Ho)).astype(np.float32)).to(torch.bfloat16).float()
+  # oracle: blocks in sequence, each storing its output in bf16
+  xe = x.clone().requires_grad_(True)
+  cur = xe
+  for i, pre in enumerate(pres):
+    cur = net_oracle.block_bf16emu(params, pre, cur, stride if i == 0 else 1, True)
+  oe = cur
+  # the consumer of the layer output masks the gradient it hands back (PREMASK contract)
+  oe.backward(dout * (oe.detach() > 0).float())
+  # HIP: same blocks, pre-masked chain as the trunk's forward sets it up
+  for i, b in enumerate(blocks):
+    b._dout_premasked = True
+    b._mask_dx = i > 0
+  try:
+    xp = ops.pt_from_nchw(x.to(dev()), 1).requires_grad_(True)
+    cur = xp
+    for b in blocks:
+      cur = b(cur)
+    got = ops.pt_to_nchw(cur.detach(), 1).cpu()
+    gmask = (got > 0).float()
+    cur.backward(ops.pt_from_nchw((dout * gmask).to(dev()), 1))
+  finally:
+    for b in blocks:
+      b._dout_premasked = b._mask_dx = False
+  torch.cuda.synchronize()
+  scale = float(oe.abs().max())
+  err = (got - oe.detach()).abs()
+  # a flipped ReLU / rounding boundary a few blocks up moves isolated elements by a few bf16 ulps
+  assert float(err.max()) <= 6e-2 * scale, float(err.max()) / scale
+  assert float(err.mean()) <= 2e-3 * scale, float(err.mean()) / scale
+  gx = ops.pt_to_nchw(xp.grad, 1).cpu()
+  assert _cos(gx, xe.grad) >= 0.99 and abs(float(gx.norm() / xe.grad.norm()) - 1) < 3e-2, _cos(gx, xe.grad)
+  worst = 1.0
+  for i, (b, pre) in enumerate(zip(blocks, pres)):
+    for n, p in b.named_parameters():
+      ref = params[pre + "." + n].grad
+      c = _cos(p.grad.cpu(), ref)
+      r = float(p.grad.norm().cpu() / ref.norm())
+      worst = min(worst, c)
+      assert c >= 0.99 and abs(r - 1) < 4e-2, (pre, n, c, r)
 
 
 def test_premasked_gradient_chain_matches_self_masking_blocks():
