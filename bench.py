@@ -222,8 +222,118 @@ def reference_api_rate(cfg, dev, imgs, imgs_tf, pairs, steps):
                   "every step, eager launches -- the unchanged script's call sequence"}
 
 
+SEG_CONFIGS = {
+  # BASELINE.json configs[3]: Potsdam-3 200x200 SegmentationNet10aTwoHead, batch 75, in_ch 4,
+  # k_A 24 / k_B 3 (commands.txt:83); BASELINE asks T = 1, the reference's own setting is T = 10
+  "potsdam3": dict(bn=75, sz=200, in_ch=4, k_A=24, k_B=3, T=1, mask_p=1.0),
+  # configs[4]: COCO-Stuff-3 128x128, RGB + Sobel = 5 channels, batch 120, k_A 15 / k_B 3, T = 10,
+  # stuff mask (commands.txt:74)
+  "coco3": dict(bn=120, sz=128, in_ch=5, k_A=15, k_B=3, T=10, mask_p=0.6),
+}
+FP32_MFMA_PEAK_TFLOPS = 157.3
+
+
+def bench_segmentation(args):
+  """`--config potsdam3|coco3`: the two-head segmentation train step
+  (segmentation_twohead.py:300-345: head A step + head B step = forward x2,
+  IID_segmentation_loss_uncollapsed, backward, Adam each), one GPU, synthetic resident inputs.
+  `roofline` is the P-matrix contraction (seg_joint_kernel forward + the two seg_grad_kernel
+  launches of its backward, fp32 MFMA 16x16x4) of head A, timed with HIP events on the launch
+  stream in the timed steps themselves; `roofline_conv` is the implicit-GEMM conv family."""
+  from iic_amd import archs, ops
+  from iic_amd.optim import Adam
+  from iic_amd.seg_losses import IID_segmentation_loss_uncollapsed
+  c = dict(SEG_CONFIGS[args.config])
+  if args.T is not None:
+    c["T"] = args.T
+  dev = torch.device("cuda", 0)
+  torch.cuda.set_device(0)
+  torch.manual_seed(0)
+  cfg = types.SimpleNamespace(in_channels=c["in_ch"], input_sz=c["sz"], batchnorm_track=True, num_sub_heads=1,
+                              output_k_A=c["k_A"], output_k_B=c["k_B"])
+  net = archs.SegmentationNet10aTwoHead(cfg).to(dev).train()
+  opt = Adam(net.parameters(), lr=1e-4)
+  g = torch.Generator().manual_seed(0)
+  bn, sz, T = c["bn"], c["sz"], c["T"]
+  x = torch.rand(bn, c["in_ch"], sz, sz, generator=g).to(dev)
+  xt = (torch.flip(x, dims=[3]) * 0.9 + 0.05).contiguous()
+  aff = torch.zeros(bn, 2, 3, device=dev)
+  aff[:, 0, 0] = -1.0
+  aff[:, 1, 1] = 1.0
+  mask = (torch.rand(bn, sz, sz, generator=g) < c["mask_p"]).float().to(dev)
+  ev = []
+
+  def step(timed=False):
+    for head in ("A", "B"):
+      net.zero_grad(set_to_none=True)
+      a = net(x, head=head)[0]
+      b = net(xt, head=head)[0]
+      a_d, b_d = a.detach().requires_grad_(True), b.detach().requires_grad_(True)
+      e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+      e[0].record()
+      loss, _ = IID_segmentation_loss_uncollapsed(a_d, b_d, all_affine2_to_1=aff, all_mask_img1=mask, lamb=1.0,
+                                                  half_T_side_dense=T, half_T_side_sparse_min=0,
+                                                  half_T_side_sparse_max=0)
+      e[1].record()
+      loss.backward()
+      e[2].record()
+      if timed and head == "A":
+        ev.append(e)
+      torch.autograd.backward([a, b], [a_d.grad, b_d.grad])
+      opt.step()
+    return loss
+  for _ in range(args.warmup):
+    step()
+  torch.cuda.synchronize()
+  conv = ConvTimer()
+  conv.install()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    last = step(True)
+  torch.cuda.synchronize()
+  dt = (time.perf_counter() - t0) / args.steps
+  conv.uninstall()
+  kA = c["k_A"]
+  f_joint = 2.0 * kA * kA * (2 * T + 1) ** 2 * bn * sz * sz          # SURVEY 8d: 2 k^2 (2T+1)^2 bn h w
+  ms_f = sum(e[0].elapsed_time(e[1]) for e in ev) / len(ev)
+  ms_b = sum(e[1].elapsed_time(e[2]) for e in ev) / len(ev)
+  tf = 3.0 * f_joint / ((ms_f + ms_b) * 1e-3) / 1e12
+  # read-once algorithmic bytes of the contraction: the two fp32 softmax maps, forward + 2 backward
+  # passes, + the two gradient maps written
+  abytes = (3 * 2 + 2) * 4.0 * bn * kA * sz * sz
+  cs = conv.summary()
+  out = {
+    "metric": "paired-images/sec, %s SegmentationNet10aTwoHead + IID_segmentation_loss_uncollapsed" % args.config,
+    "value": bn / dt, "unit": "paired-images/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+    "ms_per_step": 1e3 * dt, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+    "dtype": "bf16", "data": "synthetic",
+    "config": {"workload": "%s %dx%dx%d SegmentationNet10aTwoHead k_A %d / k_B %d, batch %d, T=%d, "
+                           "mask density %.1f, one head-A step + one head-B step per batch pair "
+                           "(segmentation_twohead.py train step), bf16 MFMA convs / fp32 head + loss"
+                           % (args.config, sz, sz, c["in_ch"], kA, c["k_B"], bn, T, c["mask_p"]),
+               "launch": "eager (python/ctypes)", "final_loss": float(last.detach())},
+    "roofline": {"bound": "mfma", "kernel": "seg_joint_kernel + 2x seg_grad_kernel (P = sum x1(u+t) x2(u)^T over "
+                                            "(2T+1)^2 shifts and its gradient; fp32 MFMA 16x16x4)",
+                 "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS,
+                 "traffic": None, "algorithmic_flops_per_launch": f_joint,
+                 "algorithmic_bytes": abytes, "arithmetic_intensity_flop_per_byte": 3.0 * f_joint / abytes,
+                 "joint_fwd_ms": ms_f, "grad_bwd_ms": ms_b,
+                 "hbm_floor_ms": abytes / 8e12 * 1e3, "mfma_floor_ms": 3.0 * f_joint / (FP32_MFMA_PEAK_TFLOPS * 1e12) * 1e3},
+  }
+  if cs:
+    out["roofline_conv"] = {"bound": "mfma", "kernel": "conv_igemm family (fwd + bwd-data), bf16 MFMA",
+                            "achieved": cs["tflops"], "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": cs["tflops"] / BF16_PEAK_TFLOPS, "launches_timed": cs["launches"],
+                            "kernel_ms_per_step": cs["total_ms"] / args.steps}
+  print(json.dumps(out))
+
+
 def main():
   ap = argparse.ArgumentParser()
+  ap.add_argument("--config", default="stl10_5g", choices=["stl10_5g"] + sorted(SEG_CONFIGS),
+                  help="stl10_5g = the BASELINE metric (default); potsdam3 / coco3 = secondary "
+                       "measurements of the segmentation configs with their own roofline object")
+  ap.add_argument("--T", type=int, default=None, help="half_T_side_dense override for the segmentation configs")
   ap.add_argument("--gpus", type=int, default=1)
   ap.add_argument("--steps", type=int, default=10)
   ap.add_argument("--warmup", type=int, default=3)
@@ -245,6 +355,10 @@ def main():
                        "dataset, as cluster_sobel.py:205-232 does from its dataloaders; the default "
                        "(off) is the metric's own timed region, which excludes data loading")
   args = ap.parse_args()
+  if args.config != "stl10_5g":
+    if args.steps == 10 and args.warmup == 3:
+      args.steps, args.warmup = 3, 1
+    return bench_segmentation(args)
 
   world = int(os.environ.get("WORLD_SIZE", "1"))
   rank = int(os.environ.get("RANK", "0"))
