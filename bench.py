@@ -61,11 +61,11 @@ class ConvTimer(object):
     timer = self
 
     def timed(g, x_pt, w_t, out_pt, stats=None, res_grad=None, res_act=None, accumulate=False,
-              premask=False):
+              premask=False, red=None):
       e0 = torch.cuda.Event(enable_timing=True)
       e1 = torch.cuda.Event(enable_timing=True)
       e0.record()
-      r = timer._orig(g, x_pt, w_t, out_pt, stats, res_grad, res_act, accumulate, premask)
+      r = timer._orig(g, x_pt, w_t, out_pt, stats, res_grad, res_act, accumulate, premask, red)
       e1.record()
       flops = 2.0 * g.N * g.MY * g.MX * g.Cout * g.Cin * g.ntaps
       # algorithmic HBM bytes: read the input rows once, write (or read-modify-write) the

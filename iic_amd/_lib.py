@@ -55,6 +55,8 @@ _SIGNATURES = {
   "iic_weight_prep": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
   "iic_conv_igemm_frag_supported": (c_int, [POINTER(ConvGeom)]),
   "iic_conv_igemm_frag": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P, _P, _P, c_int, _P]),
+  "iic_conv_igemm_red_supported": (c_int, [POINTER(ConvGeom)]),
+  "iic_conv_igemm_frag_red": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P]),
   "iic_weight_prep_frag": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
   "iic_bn_finalize": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_long, c_long, c_float, c_float, c_int, _P]),
   "iic_stat_bytes": (c_long, [c_int]),

@@ -87,6 +87,25 @@ class replicated(object):
 # bf16 rounding of the stored gradient).  Only valid where a block output has exactly one
 # consumer, i.e. the trunk's own sequential forward; standalone blocks keep masking themselves.
 PREMASK = [os.environ.get("IIC_PREMASK", "1") != "0"]
+# Fused BatchNorm-backward reductions (IIC_FUSE_RED=0 disables them).  The two sums every BatchNorm
+# backward needs (sum g, sum g*y) used to be a separate HBM-bound pass over the gradient g and the
+# BatchNorm input y.  The gradient is produced by a backward-data convolution -- MFMA-bound, with
+# HBM to spare -- so that launch takes the sums in its epilogue (iic_conv_igemm_frag_red) and only
+# y is read in addition:
+#   * a block's conv2 backward-data produces da1 -> sums of that block's bn1;
+#   * a stride-1 block's conv1 backward-data produces the (pre-masked) gradient of its INPUT, which
+#     is the output gradient of the PREVIOUS block -> sums of the previous block's bn2 (and of its
+#     downsample BatchNorm).  The trunk links consecutive blocks through a _Chain object at
+#     forward time; the previous block then skips its own reduction (ctx.dout_prereduced).
+FUSE_RED = [os.environ.get("IIC_FUSE_RED", "1") != "0"]
+
+
+class _Chain(object):
+  """Per trunk forward: what the next block needs to know about the block before it."""
+  __slots__ = ("ctx", "y2", "yd", "blk")
+
+  def __init__(self):
+    self.ctx = self.y2 = self.yd = self.blk = None
 
 _WEIGHTS_EPOCH = [0]   # bumped by iic_amd.optim.Adam (raw-pointer updates do not bump _version)
 
@@ -216,7 +235,7 @@ class _StemFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------
 class _BlockFn(torch.autograd.Function):
   @staticmethod
-  def forward(ctx, x, w1, g1, b1, w2, g2, b2, wd, gd, bd, blk):
+  def forward(ctx, x, w1, g1, b1, w2, g2, b2, wd, gd, bd, blk, chain=None):
     N, Hp, Wp, Cin = x.shape
     H, W = Hp - 2, Wp - 2
     dev = x.device
@@ -266,8 +285,23 @@ class _BlockFn(torch.autograd.Function):
       ctx.bn_batch = (_bn_training(blk.bn1) and _bn_training(blk.bn2))
       # (set by the trunk for the duration of its sequential forward, see PREMASK)
       ctx.dout_premasked, ctx.mask_dx = blk._dout_premasked, blk._mask_dx
+      # fused reduction of the PREVIOUS block's bn2 in this block's conv1 backward-data
+      ctx.dout_prereduced = False
+      ctx.red_prev = None
+      if chain is not None:
+        _, gb1f = h1.geoms(N, H, W)
+        if (chain.ctx is not None and FUSE_RED[0] and hd is None and blk._mask_dx and len(gb1f) == 1
+            and ops.red_supported(gb1f[0], h1.weights()[1]) and ctx.bn_batch):
+          ctx.red_prev = (chain.y2, chain.yd, chain.blk)
+          chain.ctx.dout_prereduced = True
+        if blk._dout_premasked and ctx.bn_batch:
+          chain.ctx, chain.y2, chain.yd, chain.blk = ctx, y2, yd, blk
+        else:
+          chain.ctx = None
       ctx.save_for_backward(x, y1, a1, y2, out, yd, coef1, coef2, coefd, g1, g2, gd)
     else:
+      if chain is not None:
+        chain.ctx = None
       for t in (y1, a1, y2, yd):
         ops.POOL.release(t)
     return out
@@ -293,7 +327,8 @@ class _BlockFn(torch.autograd.Function):
     m_out = None if pre else out
     s2 = h2.stats(dev, "bwd")
     sd = hd.stats(dev, "bwd") if hd is not None else None
-    ops.bn_bwd_reduce(dout, m_out, y2, s2, N, Ho, Wo, 1, planes, y2=yd, sums2=sd)
+    if not ctx.dout_prereduced:      # else: the next block's conv1 backward-data took these sums
+      ops.bn_bwd_reduce(dout, m_out, y2, s2, N, Ho, Wo, 1, planes, y2=yd, sums2=sd)
     bc2, dg2, db2 = ops.bn_bwd_finalize(s2, g2.detach(), coef2, planes, cnt)
     dy2 = ops.pt_alloc(N, Ho, Wo, planes, 1, dev)
     bcd = dgd = dbd = dyd = None
@@ -323,14 +358,18 @@ class _BlockFn(torch.autograd.Function):
       gfd, _ = hd.geoms(N, H, W)
       dWd = on_side(lambda: ops.conv_wgrad(gfd, x, dyd, 1, use_tr)).view(planes, Cin, 1, 1)
     da1 = ops.pt_alloc(N, Ho, Wo, planes, 1, dev)
-    for g in gb2:
-      ops.conv_igemm(g, dy2, h2.weights()[1], da1)
-
     # ---- bn1 backward; g1 = da1 * (a1 > 0)
     s1 = h1.stats(dev, "bwd")
     # a1 = relu(bn1(y1)) exactly: the ReLU mask comes from (y1, coef1), a1 is not read
     m_act, m_coef = (None, coef1) if BN_MASK_FROM_Y[0] else (a1, None)
-    ops.bn_bwd_reduce(da1, m_act, y1, s1, N, Ho, Wo, 1, planes, mask_coef=m_coef)
+    w2b = h2.weights()[1]
+    if FUSE_RED[0] and m_coef is not None and len(gb2) == 1 and ops.red_supported(gb2[0], w2b):
+      # the conv2 backward-data launch takes bn1's sums in its epilogue (reads y1 beside da1)
+      ops.conv_igemm(gb2[0], dy2, w2b, da1, red=(y1, coef1, s1, None, None))
+    else:
+      for g in gb2:
+        ops.conv_igemm(g, dy2, w2b, da1)
+      ops.bn_bwd_reduce(da1, m_act, y1, s1, N, Ho, Wo, 1, planes, mask_coef=m_coef)
     bc1, dg1, db1 = ops.bn_bwd_finalize(s1, g1.detach(), coef1, planes, cnt)
     dy1 = ops.pt_alloc(N, Ho, Wo, planes, 1, dev)
     ops.bn_bwd_apply(da1, m_act, y1, bc1, dy1, N, Ho, Wo, 1, planes, mask_coef=m_coef)
@@ -340,11 +379,17 @@ class _BlockFn(torch.autograd.Function):
     dx = ops.pt_alloc(N, H, W, Cin, 1, dev)
     # dx = bwd-data(conv1) + identity-branch gradient [, times the ReLU mask of x: mask_dx]
     mx = x if mask_dx else None
+    red_prev = None
+    if ctx.red_prev is not None:
+      py2, pyd, pblk = ctx.red_prev
+      red_prev = (py2, None, pblk._h2.stats(dev, "bwd"), pyd,
+                  pblk._hd.stats(dev, "bwd") if pyd is not None else None)
     if hd is None:
       for g in gb1:
         if pre or mask_dx:
           assert pre, "a block that pre-masks its input gradient needs a pre-masked output gradient"
-          ops.conv_igemm(g, dy1, h1.weights()[1], dx, res_grad=dout, res_act=mx, premask=True)
+          ops.conv_igemm(g, dy1, h1.weights()[1], dx, res_grad=dout, res_act=mx, premask=True,
+                         red=red_prev)
         else:
           ops.conv_igemm(g, dy1, h1.weights()[1], dx, res_grad=dout, res_act=out)
     else:
@@ -358,7 +403,7 @@ class _BlockFn(torch.autograd.Function):
 
     for t in (dout, dy2, dyd, da1, dy1, y1, a1, y2, yd, out):
       ops.POOL.release(t)
-    return dx, dW1, dg1, db1, dW2, dg2, db2, dWd, dgd, dbd, None
+    return dx, dW1, dg1, db1, dW2, dg2, db2, dWd, dgd, dbd, None, None
 
 
 class BasicBlock(nn.Module):
@@ -379,14 +424,17 @@ class BasicBlock(nn.Module):
     self._use_tr = True
     self._dout_premasked = False      # see PREMASK; only the trunk's forward turns these on
     self._mask_dx = False
+    self._chain = None                # see FUSE_RED
 
-  def forward(self, x):
+  def forward(self, x, chain=None):
+    chain = self._chain if chain is None else chain
     ds = self.downsample
     pv = ops.pv
     return _BlockFn.apply(
       x, pv(self.conv1.weight), pv(self.bn1.weight), pv(self.bn1.bias), pv(self.conv2.weight),
       pv(self.bn2.weight), pv(self.bn2.bias), pv(ds[0].weight) if ds is not None else None,
-      pv(ds[1].weight) if ds is not None else None, pv(ds[1].bias) if ds is not None else None, self)
+      pv(ds[1].weight) if ds is not None else None, pv(ds[1].bias) if ds is not None else None, self,
+      chain)
 
 
 # ------------------------------------------------------------------------------------
@@ -521,9 +569,11 @@ class ClusterNet5gTrunk(nn.Module):
     # path taps layer3's output with torch ops and keeps the self-masking blocks
     blocks = [b for layer in (self.layer1, self.layer2, self.layer3, self.layer4) for b in layer]
     chain = PREMASK[0] and not penultimate_features
+    link = _Chain() if chain else None    # consecutive blocks of the pre-masked chain (FUSE_RED)
     for i, b in enumerate(blocks):
       b._dout_premasked = chain
       b._mask_dx = chain and i > 0        # block 0's input gradient goes to the stem (own masking)
+      b._chain = link
     try:
       x = _StemFn.apply(x, ops.pv(self.conv1.weight), ops.pv(self.bn1.weight), ops.pv(self.bn1.bias), self)
       x = self.layer1(x)
@@ -536,6 +586,7 @@ class ClusterNet5gTrunk(nn.Module):
     finally:
       for b in blocks:
         b._dout_premasked = b._mask_dx = False
+        b._chain = None
 
 
 def _initialize_weights(net):

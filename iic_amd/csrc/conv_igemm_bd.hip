@@ -24,6 +24,9 @@
 #define BD_BM 256
 #define BD_BN 128
 #define BD_THREADS 256
+#ifndef BD_STORE_UB
+#define BD_STORE_UB 8      // rows per thread whose epilogue loads are in flight together (16 per tile)
+#endif
 #ifndef BD_RELOAD_NB
 #define BD_RELOAD_NB 4     // 16-B patch pieces in flight per thread at a chunk boundary (8 spills)
 #endif
@@ -43,18 +46,24 @@
 // banks, whereas a key on the raw row index collided across every row end (SQ_LDS_BANK_CONFLICT
 // was 51 % of the LDS cycles at 13- and 25-pixel rows).  !DMA: register-staged loads into
 // 144-byte-pitch rows (first version).
-template <bool GATHER, int ABL, bool DMA>
-__global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
+// MS: 32-row MFMA sub-tiles per wave: 4 = 256-row workgroup tile (2 workgroups per CU), 2 = 128-row
+// tile (half the patch and accumulators: 3 workgroups per CU -- more tiles in flight to hide the
+// per-tile prologue / epilogue where the K loop is short, i.e. few input channels).
+// RED: fused BatchNorm-backward reduction over the stored tile (conv_tile.h), 0 = off.
+template <bool GATHER, int ABL, bool DMA, int MS, int RED>
+__global__ __launch_bounds__(BD_THREADS, (MS == 4 ? 2 : 3)) void conv_igemm_bd_kernel(
     const iic_conv_geom g, const bf16_t* __restrict__ in, const unsigned char* __restrict__ wfrag,
     bf16_t* __restrict__ out, float* __restrict__ stats, const bf16_t* __restrict__ res_grad,
     const bf16_t* __restrict__ res_act, int accumulate, int num_mtiles, int lds_a_bytes,
-    int dense_key) {
+    int dense_key, const bf16_t* __restrict__ red_y, const float* __restrict__ red_coef,
+    const bf16_t* __restrict__ red_y2, float* __restrict__ red_stats, float* __restrict__ red_stats2) {
   constexpr int CLD = BD_BN + 8;
+  constexpr int BM = MS * 64, WR = MS * 32;     // workgroup tile rows, rows per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned char* sA = smem_raw;                                   // [NP256][ROWB]
   int* s_pin = reinterpret_cast<int*>(smem_raw + lds_a_bytes);     // [256]
-  int* s_pout = s_pin + BD_BM;                                     // [256]
-  float* s_red = reinterpret_cast<float*>(s_pout + BD_BM);         // [2 wm][2][128]
+  int* s_pout = s_pin + BM;                                     // [256]
+  float* s_red = reinterpret_cast<float*>(s_pout + BM);         // [2 wm][2][128]
   unsigned char* s_key = reinterpret_cast<unsigned char*>(s_red + 4 * BD_BN);   // DMA: [npix] swizzle keys
   bf16_t* sC = reinterpret_cast<bf16_t*>(smem_raw);                // epilogue reuse of sA
 
@@ -67,13 +76,13 @@ __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
   const int tix = xcd_tile_index(blockIdx.x, num_mtiles * nt);
   const int mtile = tix / nt, ntile = tix - mtile * nt;
   const int n0 = ntile * BD_BN;
-  const int m0 = mtile * BD_BM;
+  const int m0 = mtile * BM;
   const int in_pixels = g.N * g.in_Hp * g.in_Wp;
 
   const int v_tapoff = g.tap_off[lane & (IIC_MAX_TAPS - 1)];
   const int v_tapw = g.tap_w[lane & (IIC_MAX_TAPS - 1)];
 
-  {
+  if (tid < BM) {
     int pin, pout;
     igemm_row_pixels(g, m0 + tid, pin, pout);
     s_pin[tid] = pin;
@@ -81,16 +90,16 @@ __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
   }
   __syncthreads();
   const int p_lo = s_pin[0];
-  const int npix = GATHER ? BD_BM : g.NP256;
+  const int npix = GATHER ? BM : (MS == 4 ? g.NP256 : g.NP);
   // swizzle key of a pixel (see the header): D = p - J * (p / in_Wp); J must be even so that D keeps
   // the row parity (the 128-B half of the 256-B bank window is the physical row parity)
   const int jskip = (dense_key && !GATHER && g.sx == 1 && ((g.in_Wp - g.MX) & 1) == 0) ? g.in_Wp - g.MX : 0;
   auto dense_of = [&](int p) { return p - jskip * (p / g.in_Wp); };
-  int arow[4];     // !DMA: byte offset of the lane's row (tap 0) + k-chunk; DMA: patch row index
-  int drow[4];     // DMA: D of the lane's row at tap offset 0
+  int arow[MS];     // !DMA: byte offset of the lane's row (tap 0) + k-chunk; DMA: patch row index
+  int drow[MS];     // DMA: D of the lane's row at tap offset 0
 #pragma unroll
-  for (int ms = 0; ms < 4; ++ms) {
-    const int row = wm * 128 + ms * 32 + l31;
+  for (int ms = 0; ms < MS; ++ms) {
+    const int row = wm * WR + ms * 32 + l31;
     const int pr = GATHER ? row : (s_pin[row] - p_lo);
     arow[ms] = DMA ? pr : pr * ROWB + g5 * 16;
     drow[ms] = (DMA && !GATHER) ? dense_of(s_pin[row]) : pr;
@@ -111,7 +120,7 @@ __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
       const int ls = (q & 7) ^ (GATHER ? ((r >> 1) & 7)
                                        : (jskip != 0 ? (int)s_key[r < npix ? r : npix - 1]
                                                      : (((p_lo + r) >> 1) & 7)));
-      long p = GATHER ? (long)s_pin[r < BD_BM ? r : BD_BM - 1] : (long)p_lo + r;
+      long p = GATHER ? (long)s_pin[r < BM ? r : BM - 1] : (long)p_lo + r;
       p = p < in_pixels ? p : in_pixels - 1;
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)(in + (p * g.Cin + c0 + ls * 8)),
@@ -124,9 +133,9 @@ __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
   auto a_base = [&](int R, int D) { return R * 128 + (((g5 ^ (D >> 1)) & 1) << 4); };
   auto a_kk = [&](int D) { return ((D >> 2) & 3) << 5; };
 
-  f32x16 acc[4][2];
+  f32x16 acc[MS][2];
 #pragma unroll
-  for (int ms = 0; ms < 4; ++ms)
+  for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
     for (int ns = 0; ns < 2; ++ns)
 #pragma unroll
@@ -170,10 +179,10 @@ __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
   // sched_barrier(0) pins each group: without it the scheduler sinks all 8 loads to the end of
   // the iteration and recycles the B registers as A temporaries (=> vmcnt(0) every iteration).
   int tap = 0, chunk = 0;
-  bf16x8 a[2][4];
-  int pcur[4], kcur[4];       // kcur: DMA only (k-step XOR term of the row's swizzle)
+  bf16x8 a[2][MS];
+  int pcur[MS], kcur[MS];       // kcur: DMA only (k-step XOR term of the row's swizzle)
 #pragma unroll
-  for (int ms = 0; ms < 4; ++ms) {
+  for (int ms = 0; ms < MS; ++ms) {
     const int t0 = GATHER ? 0 : __builtin_amdgcn_readlane(v_tapoff, 0);
     if (DMA) {
       const int R = arow[ms] + t0;
@@ -195,9 +204,9 @@ __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
     const unsigned char* nb = (ABL & 2) ? frag_ptr(0, 0) : frag_ptr(tn, cn);
     const int toffn = GATHER ? 0 : __builtin_amdgcn_readlane(v_tapoff, tn);
     const int tdn = GATHER ? 0 : __builtin_amdgcn_readlane(v_tapd, tn);
-    int pnext[4], knext[4];
+    int pnext[MS], knext[MS];
 #pragma unroll
-    for (int ms = 0; ms < 4; ++ms) {
+    for (int ms = 0; ms < MS; ++ms) {
       if (DMA) {
         const int R = arow[ms] + toffn;
         const int D = drow[ms] + tdn;
@@ -212,7 +221,7 @@ __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
     for (int ks = 0; ks < 4; ++ks) {
       const int cur = ks & 1, nxt = cur ^ 1;
 #pragma unroll
-      for (int ms = 0; ms < 4; ++ms)
+      for (int ms = 0; ms < MS; ++ms)
         if (!(ABL & 16)) {
           if (DMA)
             a[nxt][ms] = (ks < 3) ? *reinterpret_cast<const bf16x8*>(sA + pcur[ms] + (((ks + 1) << 5) ^ kcur[ms]))
@@ -227,7 +236,7 @@ __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
       const bf16x8 b0 = __builtin_bit_cast(bf16x8, Bc[ks][0]);
       const bf16x8 b1 = __builtin_bit_cast(bf16x8, Bc[ks][1]);
 #pragma unroll
-      for (int ms = 0; ms < 4; ++ms) {
+      for (int ms = 0; ms < MS; ++ms) {
         acc[ms][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][ms], b0, acc[ms][0], 0, 0, 0);
         acc[ms][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][ms], b1, acc[ms][1], 0, 0, 0);
       }
@@ -236,7 +245,7 @@ __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int ms = 0; ms < 4; ++ms) {
+    for (int ms = 0; ms < MS; ++ms) {
       pcur[ms] = pnext[ms];
       kcur[ms] = knext[ms];
     }
@@ -250,7 +259,7 @@ __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
       }
       __syncthreads();
 #pragma unroll
-      for (int ms = 0; ms < 4; ++ms)
+      for (int ms = 0; ms < MS; ++ms)
         a[0][ms] = *reinterpret_cast<const bf16x8*>(sA + pcur[ms] + (DMA ? kcur[ms] : 0));
     }
     tap = tn;
@@ -261,7 +270,7 @@ __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
   if (ABL & 4) {
     float t = 0.f;   // keep every accumulator live
 #pragma unroll
-    for (int ms = 0; ms < 4; ++ms)
+    for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
       for (int ns = 0; ns < 2; ++ns)
 #pragma unroll
@@ -269,14 +278,14 @@ __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
     if (t == 123.f) out[0] = 1;
     return;
   }
-  const bool tail = igemm_tile_has_invalid(g, m0, BD_BM);
+  const bool tail = igemm_tile_has_invalid(g, m0, BM);
   if (stats && !(ABL & 64)) {
     if (tail) {       // rows past the end / in the row padding do not count
 #pragma unroll
-      for (int ms = 0; ms < 4; ++ms)
+      for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          if (s_pout[wm * 128 + ms * 32 + mfma32_row(r, lane)] < 0) {
+          if (s_pout[wm * WR + ms * 32 + mfma32_row(r, lane)] < 0) {
             acc[ms][0][r] = 0.f;
             acc[ms][1][r] = 0.f;
           }
@@ -285,7 +294,7 @@ __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
     for (int ns = 0; ns < 2; ++ns) {
       f32x2 s2 = {0.f, 0.f}, ss2 = {0.f, 0.f};      // packed fp32 adds / fmas: half the VALU count
 #pragma unroll
-      for (int ms = 0; ms < 4; ++ms)
+      for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
           const f32x2 v = {acc[ms][ns][r], acc[ms][ns][r + 1]};
@@ -309,19 +318,24 @@ __global__ __launch_bounds__(BD_THREADS, 2) void conv_igemm_bd_kernel(
     iic_stat_add(stats, stripe, g.Cout, n0 + tid, 1, s_red[1 * BD_BN + tid] + s_red[3 * BD_BN + tid]);
   }
 #pragma unroll
-  for (int ms = 0; ms < 4; ++ms)
+  for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
     for (int ns = 0; ns < 2; ++ns)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = wm * 128 + ms * 32 + mfma32_row(r, lane);
+        const int row = wm * WR + ms * 32 + mfma32_row(r, lane);
         const int col = wn * 64 + ns * 32 + l31;
         sC[row * CLD + col] = f32_to_bf16(acc[ms][ns][r]);
       }
   __syncthreads();
+  TileRed tr;
+  if (RED) tile_red_zero(tr);
   if (!(ABL & 32))
-    igemm_store_tile<BD_BN, BD_BM, BD_THREADS>(sC, s_pout, out, res_grad, res_act, accumulate, g.Cout,
-                                               n0, tid);
+    igemm_store_tile<BD_BN, BM, BD_THREADS, 8, RED, (MS == 4 ? BD_STORE_UB : 4)>(sC, s_pout, out, res_grad, res_act, accumulate,
+                                                                 g.Cout, n0, tid, red_y, red_coef, red_y2, &tr);
+  if (RED)
+    igemm_red_finish<BD_BN, BD_THREADS, RED>(tr, reinterpret_cast<float*>(smem_raw), red_stats, red_stats2,
+                                             g.Cout, n0, tid);
 }
 
 // fp32 OIHW -> bf16 MFMA-B-fragment order.  mode 0 (forward operand): GEMM N = Cout, K = Cin;
@@ -349,31 +363,50 @@ extern "C" int iic_debug_get_ablate(void);
 // conv_igemm_p64.hip: persistent DMA-fed kernel for the 64 -> 64 channel 3x3 layers
 int iic_p64_supported(const iic_conv_geom* g);
 int iic_p64_launch(const iic_conv_geom* g, const void* in, const void* wfrag, void* out, float* stats,
-                   const void* res_grad, const void* res_act, int accumulate, void* stream);
+                   const void* res_grad, const void* res_act, int accumulate, const void* red_y,
+                   const float* red_coef, const void* red_y2, float* red_stats, float* red_stats2,
+                   void* stream);
 static int g_bd_one_wg = 1;      // also take LDS footprints that leave room for only one workgroup per CU
                                  // (large-image segmentation layers: still 15-20 % faster than conv_igemm_kernel)
 extern "C" void iic_debug_bd_one_wg(int v) { g_bd_one_wg = v; }
 static int g_p64_enabled = 1;
 extern "C" void iic_debug_enable_p64(int v) { g_p64_enabled = v; }
+static int g_p64_red = 0;        // 1: allow the fused reduction in the persistent kernel (tests, A/B)
+extern "C" void iic_debug_p64_red(int v) { g_p64_red = v; }
 
 extern "C" {
 
 static int g_bd_dma = 1;        // 1: LDS-DMA patch loads (128-B swizzled rows), 0: register-staged (144-B rows)
 extern "C" void iic_debug_bd_dma(int v) { g_bd_dma = v; }
 
-static long bd_lds_a(const iic_conv_geom* g) {
-  const long npix = g->ntaps == 1 ? BD_BM : g->NP256;
+// ms: 4 = 256-row tiles, 2 = 128-row tiles (the kernel's MS)
+static long bd_lds_a(const iic_conv_geom* g, int ms) {
+  const long bm = ms * 64;
+  const long npix = g->ntaps == 1 ? bm : (ms == 4 ? g->NP256 : g->NP);
   long a = g_bd_dma ? ((npix * 128 + 1023) & ~1023L) : npix * ROWB;
-  long c = (long)BD_BM * (BD_BN + 8) * 2;
+  long c = bm * (BD_BN + 8) * 2;
   long m = a > c ? a : c;
   return (m + 15) & ~15L;
 }
 
 static int g_bd_dense_key = 1;  // 0: swizzle key from the raw pixel index (A/B: conflicts at row ends)
 extern "C" void iic_debug_bd_dense_key(int v) { g_bd_dense_key = v; }
-static long bd_key_bytes(const iic_conv_geom* g) {    // swizzle-key table of the DMA patch (1 B / row)
+static long bd_key_bytes(const iic_conv_geom* g, int ms) {    // swizzle-key table of the DMA patch (1 B / row)
   const int jskip = (g_bd_dense_key && g->ntaps > 1 && g->sx == 1 && ((g->in_Wp - g->MX) & 1) == 0) ? g->in_Wp - g->MX : 0;
-  return (g_bd_dma && jskip != 0) ? (((long)g->NP256 + 15) & ~15L) : 0;
+  return (g_bd_dma && jskip != 0) ? (((long)(ms == 4 ? g->NP256 : g->NP) + 15) & ~15L) : 0;
+}
+static long bd_lds_total(const iic_conv_geom* g, int ms) {
+  return bd_lds_a(g, ms) + 2L * ms * 64 * 4 + 4L * BD_BN * 4 + bd_key_bytes(g, ms);
+}
+// Tile height per geometry.  g_bd_ms: 0 = heuristic, 2 / 4 = forced (A/B runs, tests).
+static int g_bd_ms = 0;
+extern "C" void iic_debug_bd_ms(int v) { g_bd_ms = v; }
+static int bd_pick_ms(const iic_conv_geom* g) {
+  const bool ok4 = (g->ntaps == 1 || g->NP256 > 0) && bd_lds_total(g, 4) <= (g_bd_one_wg ? 160 : 80) * 1024;
+  const bool ok2 = (g->ntaps == 1 || g->NP > 0) && bd_lds_total(g, 2) <= 160 * 1024;
+  if (g_bd_ms == 4) return ok4 ? 4 : (ok2 ? 2 : 0);
+  if (g_bd_ms == 2) return ok2 ? 2 : (ok4 ? 4 : 0);
+  return ok4 ? 4 : (ok2 ? 2 : 0);
 }
 
 /* 1 if iic_conv_igemm_frag can run this geometry (else use iic_conv_igemm). */
@@ -381,40 +414,84 @@ int iic_conv_igemm_frag_supported(const iic_conv_geom* g) {
   if (!g) return 0;
   if (g_p64_enabled && iic_p64_supported(g)) return 1;
   if (g->Cin % 64 != 0 || g->Cout % BD_BN != 0 || g->ntaps < 1 || g->ntaps > IIC_MAX_TAPS) return 0;
-  if (g->ntaps > 1 && g->NP256 <= 0) return 0;
-  const long lds = bd_lds_a(g) + 2L * BD_BM * 4 + 4L * BD_BN * 4 + bd_key_bytes(g);
-  return lds <= (g_bd_one_wg ? 160 : 80) * 1024;      // two workgroups per CU, or one
+  return bd_pick_ms(g) != 0;
+}
+
+int iic_conv_igemm_frag_red(const iic_conv_geom* g, const void* in, const void* wfrag, void* out,
+                            float* stats, const void* res_grad, const void* res_act, int accumulate,
+                            const void* red_y, const float* red_coef, const void* red_y2,
+                            float* red_stats, float* red_stats2, void* stream);
+
+/* 1 if iic_conv_igemm_frag_red can fuse a reduction into this geometry's launch. */
+int iic_conv_igemm_red_supported(const iic_conv_geom* g) {
+  if (!g || !iic_conv_igemm_frag_supported(g)) return 0;
+  if (g_p64_enabled && iic_p64_supported(g)) return g_p64_red;
+  return g->ntaps > 1;
 }
 
 int iic_conv_igemm_frag(const iic_conv_geom* g, const void* in, const void* wfrag, void* out,
                         float* stats, const void* res_grad, const void* res_act, int accumulate,
                         void* stream) {
+  return iic_conv_igemm_frag_red(g, in, wfrag, out, stats, res_grad, res_act, accumulate, nullptr, nullptr,
+                                 nullptr, nullptr, nullptr, stream);
+}
+
+int iic_conv_igemm_frag_red(const iic_conv_geom* g, const void* in, const void* wfrag, void* out,
+                            float* stats, const void* res_grad, const void* res_act, int accumulate,
+                            const void* red_y, const float* red_coef, const void* red_y2,
+                            float* red_stats, float* red_stats2, void* stream) {
   if (!g || !in || !wfrag || !out) return IIC_ERR_ARG;
+  if ((red_y == nullptr) != (red_stats == nullptr) || (red_y2 == nullptr) != (red_stats2 == nullptr) ||
+      (red_y2 && !red_y) || (red_coef && !red_y))
+    return IIC_ERR_ARG;
+  const int red = red_y ? (red_y2 ? 2 : 1) : 0;
   if (!(accumulate & IIC_ACC_PREMASK) && (res_grad == nullptr) != (res_act == nullptr)) return IIC_ERR_ARG;
   if (!iic_conv_igemm_frag_supported(g)) return IIC_ERR_UNSUPPORTED;
-  if (g_p64_enabled && iic_p64_supported(g))
-    return iic_p64_launch(g, in, wfrag, out, stats, res_grad, res_act, accumulate, stream);
+  if (g_p64_enabled && iic_p64_supported(g)) {
+    // the persistent kernel stores tile t-1 right before tile t's MFMA loop: loads of y there
+    // stall every wave once per tile (measured +120 us per launch) -- callers keep the separate
+    // reduction pass for the 64 -> 64 layers (iic_conv_igemm_red_supported)
+    if (red && !g_p64_red) return IIC_ERR_UNSUPPORTED;
+    return iic_p64_launch(g, in, wfrag, out, stats, res_grad, res_act, accumulate, red_y, red_coef, red_y2,
+                          red_stats, red_stats2, stream);
+  }
   const long M = igemm_rows_host(g);
   if (M <= 0) return IIC_ERR_ARG;
   if (M >= (1L << 31) || (long)g->N * g->in_Hp * g->in_Wp >= (1L << 31)) return IIC_ERR_UNSUPPORTED;
-  const int mt = (int)((M + BD_BM - 1) / BD_BM);
+  const int ms = bd_pick_ms(g);
+  const int bm = ms * 64;
+  const int mt = (int)((M + bm - 1) / bm);
   const int grid = mt * (g->Cout / BD_BN);
-  const int la = (int)bd_lds_a(g);
-  const long lds = la + 2L * BD_BM * 4 + 4L * BD_BN * 4 + bd_key_bytes(g);
+  const int la = (int)bd_lds_a(g, ms);
+  const long lds = bd_lds_total(g, ms);
   hipStream_t s = (hipStream_t)stream;
-#define BD_LAUNCH2(GA_, AB_, DM_)                                                                 \
+#define BD_LAUNCH4(GA_, AB_, DM_, MS_, RD_)                                                       \
   do {                                                                                           \
     static bool attr = false;                                                                    \
     if (!attr) {                                                                                 \
       (void)hipFuncSetAttribute(                                                                 \
-          reinterpret_cast<const void*>(&conv_igemm_bd_kernel<GA_, AB_, DM_>),                   \
+          reinterpret_cast<const void*>(&conv_igemm_bd_kernel<GA_, AB_, DM_, MS_, RD_>),         \
           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                               \
       attr = true;                                                                               \
     }                                                                                            \
-    hipLaunchKernelGGL((conv_igemm_bd_kernel<GA_, AB_, DM_>), dim3(grid), dim3(BD_THREADS), lds, \
-                       s, *g, (const bf16_t*)in, (const unsigned char*)wfrag, (bf16_t*)out,      \
-                       stats, (const bf16_t*)res_grad, (const bf16_t*)res_act, accumulate, mt,   \
-                       la, g_bd_dense_key);                                                      \
+    hipLaunchKernelGGL((conv_igemm_bd_kernel<GA_, AB_, DM_, MS_, RD_>), dim3(grid),              \
+                       dim3(BD_THREADS), lds, s, *g, (const bf16_t*)in,                          \
+                       (const unsigned char*)wfrag, (bf16_t*)out, stats, (const bf16_t*)res_grad, \
+                       (const bf16_t*)res_act, accumulate, mt, la, g_bd_dense_key,               \
+                       (const bf16_t*)red_y, red_coef, (const bf16_t*)red_y2, red_stats,         \
+                       red_stats2);                                                              \
+  } while (0)
+#define BD_LAUNCH3(GA_, AB_, DM_, MS_)                                                            \
+  do {                                                                                           \
+    if (AB_ != 0 || GA_ || red == 0) {                                                           \
+      if (red != 0) return IIC_ERR_UNSUPPORTED;                                                  \
+      BD_LAUNCH4(GA_, AB_, DM_, MS_, 0);                                                         \
+    } else if (red == 1) BD_LAUNCH4(false, 0, DM_, MS_, 1);                                      \
+    else BD_LAUNCH4(false, 0, DM_, MS_, 2);                                                      \
+  } while (0)
+#define BD_LAUNCH2(GA_, AB_, DM_)                                                                 \
+  do {                                                                                           \
+    if (ms == 4) BD_LAUNCH3(GA_, AB_, DM_, 4); else BD_LAUNCH3(GA_, AB_, DM_, 2);                \
   } while (0)
 #define BD_LAUNCH(GA_, AB_)                                                                       \
   do {                                                                                           \

@@ -56,11 +56,15 @@ __device__ __forceinline__ void p64_walk_pixels(const P64Walk& w, const iic_conv
 
 // ABL: timing-ablation build (WRONG results): 1 = only the first patch is fetched, 2 = no output
 // stores, 4 = one tap instead of nine.
-template <int ABL>
+// RED: fused BatchNorm-backward reduction over the stored rows (conv_tile.h); the partial sums
+// stay in registers across all tiles of the workgroup.
+template <int ABL, int RED>
 __global__ __launch_bounds__(P64_THREADS) void conv_igemm_p64_kernel(
     const iic_conv_geom g, const bf16_t* __restrict__ in, const unsigned char* __restrict__ wfrag,
     bf16_t* __restrict__ out, float* __restrict__ stats, const bf16_t* __restrict__ res_grad,
-    const bf16_t* __restrict__ res_act, int accumulate, int num_tiles, int pb_bytes, int max_tap_off) {
+    const bf16_t* __restrict__ res_act, int accumulate, int num_tiles, int pb_bytes, int max_tap_off,
+    const bf16_t* __restrict__ red_y, const float* __restrict__ red_coef,
+    const bf16_t* __restrict__ red_y2, float* __restrict__ red_stats, float* __restrict__ red_stats2) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned char* const sP0 = smem_raw;                    // patch buffer 0  [rows][128 B]
   unsigned char* const sP1 = smem_raw + pb_bytes;         // patch buffer 1
@@ -143,6 +147,8 @@ __global__ __launch_bounds__(P64_THREADS) void conv_igemm_p64_kernel(
     for (int ks = 0; ks < 4; ++ks) Bw[tap][ks] = *reinterpret_cast<const u32x4*>(p + ks * 1024);
   }
   f32x2 st_s = {0.f, 0.f}, st_ss = {0.f, 0.f};   // BN statistics of column wn*32 + l31
+  TileRed tr;
+  if (RED) tile_red_zero(tr);
 
   for (int t = t0; t < t1; ++t) {
     const int par = (t - t0) & 1;
@@ -150,8 +156,9 @@ __global__ __launch_bounds__(P64_THREADS) void conv_igemm_p64_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of patch t has landed
     __syncthreads();                                    // A: patch t + tile t-1 in sC are complete
     if (t > t0 && !(ABL & 2))
-      igemm_store_tile<P64_BN, P64_BM, P64_THREADS, 0>(sC, s_pout + ((t - 1) & (P64_NTAB - 1)) * P64_BM, out,
-                                                       res_grad, res_act, accumulate, P64_BN, 0, tid);
+      igemm_store_tile<P64_BN, P64_BM, P64_THREADS, 0, RED, 1>(sC, s_pout + ((t - 1) & (P64_NTAB - 1)) * P64_BM,
+                                                            out, res_grad, res_act, accumulate, P64_BN, 0, tid,
+                                                            red_y, red_coef, red_y2, &tr);
     // queue: [2] = tile t + 1 (tabulated one iteration ago)
     if (t + 1 < t1 && !(ABL & 1)) dma_issue(par ? sP0 : sP1, plo_q[2], nblk_q[2]);
     tabulate(t + 2);
@@ -217,8 +224,12 @@ __global__ __launch_bounds__(P64_THREADS) void conv_igemm_p64_kernel(
   // ---- drain: last tile's rows, then the statistics -------------------------------------------
   __syncthreads();
   if (!(ABL & 2))
-    igemm_store_tile<P64_BN, P64_BM, P64_THREADS, 0>(sC, s_pout + ((t1 - 1) & (P64_NTAB - 1)) * P64_BM, out,
-                                                     res_grad, res_act, accumulate, P64_BN, 0, tid);
+    igemm_store_tile<P64_BN, P64_BM, P64_THREADS, 0, RED, 1>(sC, s_pout + ((t1 - 1) & (P64_NTAB - 1)) * P64_BM, out,
+                                                          res_grad, res_act, accumulate, P64_BN, 0, tid,
+                                                          red_y, red_coef, red_y2, &tr);
+  if (RED)
+    igemm_red_finish<P64_BN, P64_THREADS, RED>(tr, reinterpret_cast<float*>(sC), red_stats, red_stats2, P64_BN,
+                                               0, tid);
   if (stats) {
     __syncthreads();
     float s1 = st_s[0] + st_s[1], s2 = st_ss[0] + st_ss[1];
@@ -273,7 +284,10 @@ int iic_p64_supported(const iic_conv_geom* g) {
 }
 
 int iic_p64_launch(const iic_conv_geom* g, const void* in, const void* wfrag, void* out, float* stats,
-                   const void* res_grad, const void* res_act, int accumulate, void* stream) {
+                   const void* res_grad, const void* res_act, int accumulate, const void* red_y,
+                   const float* red_coef, const void* red_y2, float* red_stats, float* red_stats2,
+                   void* stream) {
+  const int red = red_y ? (red_y2 ? 2 : 1) : 0;
   const long M = (long)g->N * g->MY * g->MX;
   if (M <= 0) return IIC_ERR_ARG;
   if (M >= (1L << 31) - P64_BM || (long)g->N * g->in_Hp * g->in_Wp >= (1L << 31)) return IIC_ERR_UNSUPPORTED;
@@ -284,19 +298,23 @@ int iic_p64_launch(const iic_conv_geom* g, const void* in, const void* wfrag, vo
   for (int i = 0; i < g->ntaps; ++i) mto = g->tap_off[i] > mto ? g->tap_off[i] : mto;
   const int ncu = p64_num_cus();
   const int grid = nt < ncu ? nt : ncu;
-#define P64_LAUNCH(AB_)                                                                           \
+#define P64_LAUNCH2(AB_, RD_)                                                                     \
   do {                                                                                           \
     static bool attr = false;                                                                    \
     if (!attr) {                                                                                 \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_p64_kernel<AB_>),      \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_p64_kernel<AB_, RD_>), \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);         \
       attr = true;                                                                               \
     }                                                                                            \
-    hipLaunchKernelGGL(conv_igemm_p64_kernel<AB_>, dim3(grid), dim3(P64_THREADS), lds,           \
+    hipLaunchKernelGGL((conv_igemm_p64_kernel<AB_, RD_>), dim3(grid), dim3(P64_THREADS), lds,    \
                        (hipStream_t)stream, *g, (const bf16_t*)in, (const unsigned char*)wfrag,  \
                        (bf16_t*)out, stats, (const bf16_t*)res_grad, (const bf16_t*)res_act,     \
-                       accumulate, nt, pb, mto);                                                 \
+                       accumulate, nt, pb, mto, (const bf16_t*)red_y, red_coef,                  \
+                       (const bf16_t*)red_y2, red_stats, red_stats2);                            \
   } while (0)
+#define P64_LAUNCH(AB_) P64_LAUNCH2(AB_, 0)
+  if (red == 1) { P64_LAUNCH2(0, 1); return iic_launch_status(); }
+  if (red == 2) { P64_LAUNCH2(0, 2); return iic_launch_status(); }
   switch (iic_debug_get_ablate()) {
     case 1: P64_LAUNCH(1); break;
     case 2: P64_LAUNCH(2); break;

@@ -80,60 +80,186 @@ __device__ __forceinline__ void igemm_load_patch(unsigned char* sA, const bf16_t
 // with IIC_ACC_PREMASK: out = (value [+ previous] [+ res_grad]) where res_act > 0, else 0 -- the
 // gradient leaves already multiplied by the ReLU mask of the activation it belongs to (res_act =
 // this conv's INPUT activation), so its consumers do not read that activation again.
-template <int BN, int BM, int NTHREADS, int PAD = 8>
+//
+// RED (fused BatchNorm-backward reduction, include/iic_hip.h iic_conv_igemm_frag_red): the tile
+// being stored is a gradient g that a BatchNorm backward consumes next; its two reductions
+//   sum g   and   sum g * y      (y = that BatchNorm's input, a PT tensor shaped like `out`;
+//                                 RED == 2: also sum g * y2 for the downsample branch's BatchNorm)
+// are taken here from the values as they are stored (bf16-rounded), masked by
+// (scale*y + shift > 0) when red_coef != nullptr (the ReLU between that BatchNorm and this conv,
+// recomputed from y exactly as bn_bwd_reduce does).  The y tile rides along with an MFMA-bound
+// kernel instead of costing a separate HBM-bound pass over g and y.  A thread always owns the same
+// 8 channels (NTHREADS % (BN/8) == 0), so the partial sums live in registers (TileRed) across
+// rows and -- persistent kernels -- across tiles; igemm_red_finish folds them.
+struct TileRed {
+  float s[8], sy[8], sy2[8];
+};
+__device__ __forceinline__ void tile_red_zero(TileRed& r) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.s[i] = r.sy[i] = r.sy2[i] = 0.f;
+}
+
+template <int BN, int BM, int NTHREADS, int PAD = 8, int RED = 0, int UB = 4>
 __device__ __forceinline__ void igemm_store_tile(const bf16_t* sC, const int* s_pout,
                                                  bf16_t* __restrict__ out,
                                                  const bf16_t* __restrict__ res_grad,
                                                  const bf16_t* __restrict__ res_act, int accumulate,
-                                                 int Cout, int n0, int tid) {
+                                                 int Cout, int n0, int tid,
+                                                 const bf16_t* __restrict__ red_y = nullptr,
+                                                 const float* __restrict__ red_coef = nullptr,
+                                                 const bf16_t* __restrict__ red_y2 = nullptr,
+                                                 TileRed* red = nullptr) {
   constexpr int CLD = BN + PAD;
+  constexpr int CH = BN / 8;
+  constexpr int ITERS = (BM * CH + NTHREADS - 1) / NTHREADS;
+  constexpr int U = ITERS < UB ? ITERS : UB;    // rows whose global loads are in flight together
+  static_assert(NTHREADS % CH == 0, "a thread must keep its channel chunk");
   const bool add_prev = accumulate & IIC_ACC_ADD, premask = accumulate & IIC_ACC_PREMASK;
-  for (int idx = tid; idx < BM * (BN / 8); idx += NTHREADS) {
-    const int row = idx / (BN / 8), ch = idx - row * (BN / 8);
-    const int po = s_pout[row];
-    if (po < 0) continue;
-    uint4 v = *reinterpret_cast<const uint4*>(sC + row * CLD + ch * 8);
-    const long o = (long)po * Cout + n0 + ch * 8;
-    if (add_prev || res_grad || res_act) {
-      uint32_t vv[4] = {v.x, v.y, v.z, v.w};
-      float f[8];
+  const bool any_in = add_prev || res_grad || res_act;
+  const int ch = tid % CH;
+  // the ReLU-mask coefficients of the fused reduction: this thread's 8 channels, loaded once
+  float msc[RED ? 8 : 1], msh[RED ? 8 : 1];
+  if (RED && red_coef) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { f[2 * i] = bf16lo(vv[i]); f[2 * i + 1] = bf16hi(vv[i]); }
-      if (add_prev) {
-        const uint4 ov = *reinterpret_cast<const uint4*>(out + o);
-        const uint32_t oo[4] = {ov.x, ov.y, ov.z, ov.w};
+    for (int i = 0; i < 8; ++i) {
+      msc[RED ? i : 0] = red_coef[n0 + ch * 8 + i];
+      msh[RED ? i : 0] = red_coef[Cout + n0 + ch * 8 + i];
+    }
+  }
+  // Rows are processed U at a time: first ALL global loads of the batch are issued (previous
+  // contents, residual gradient, mask activation, the reduction's y / y2), then the batch is
+  // computed and stored -- one memory latency per batch instead of one per row (the loop used to
+  // wait for each row's loads in turn: ~16 exposed latencies per tile in the backward-data epilogue).
+  for (int b0 = 0; b0 < ITERS; b0 += U) {
+    long o[U];
+    uint4 pv[U], gv[U], av[U], yv[U], zv[U];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { f[2 * i] += bf16lo(oo[i]); f[2 * i + 1] += bf16hi(oo[i]); }
+    for (int u = 0; u < U; ++u) {
+      const int idx = tid + (b0 + u) * NTHREADS;
+      const int row = idx / CH;
+      const int po = (idx < BM * CH) ? s_pout[row] : -1;
+      o[u] = po < 0 ? -1 : (long)po * Cout + n0 + ch * 8;
+      if (o[u] >= 0) {
+        if (add_prev) pv[u] = *reinterpret_cast<const uint4*>(out + o[u]);
+        if (res_grad) gv[u] = *reinterpret_cast<const uint4*>(res_grad + o[u]);
+        if (res_act) av[u] = *reinterpret_cast<const uint4*>(res_act + o[u]);
+        if (RED) yv[u] = *reinterpret_cast<const uint4*>(red_y + o[u]);
+        if (RED == 2) zv[u] = *reinterpret_cast<const uint4*>(red_y2 + o[u]);
       }
-      if (premask) {
-        if (res_grad) {
-          const uint4 gv = *reinterpret_cast<const uint4*>(res_grad + o);
-          const uint32_t gg[4] = {gv.x, gv.y, gv.z, gv.w};
+    }
 #pragma unroll
-          for (int i = 0; i < 4; ++i) { f[2 * i] += bf16lo(gg[i]); f[2 * i + 1] += bf16hi(gg[i]); }
+    for (int u = 0; u < U; ++u) {
+      if (o[u] < 0) continue;
+      const int row = (tid + (b0 + u) * NTHREADS) / CH;
+      uint4 v = *reinterpret_cast<const uint4*>(sC + row * CLD + ch * 8);
+      if (any_in) {
+        uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+        float f[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { f[2 * i] = bf16lo(vv[i]); f[2 * i + 1] = bf16hi(vv[i]); }
+        if (add_prev) {
+          const uint32_t oo[4] = {pv[u].x, pv[u].y, pv[u].z, pv[u].w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { f[2 * i] += bf16lo(oo[i]); f[2 * i + 1] += bf16hi(oo[i]); }
         }
-        if (res_act) {
-          const uint4 av = *reinterpret_cast<const uint4*>(res_act + o);
-          const uint32_t aa[4] = {av.x, av.y, av.z, av.w};
+        if (premask) {
+          if (res_grad) {
+            const uint32_t gg[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { f[2 * i] += bf16lo(gg[i]); f[2 * i + 1] += bf16hi(gg[i]); }
+          }
+          if (res_act) {
+            const uint32_t aa[4] = {av[u].x, av[u].y, av[u].z, av[u].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              if (!(bf16lo(aa[i]) > 0.f)) f[2 * i] = 0.f;
+              if (!(bf16hi(aa[i]) > 0.f)) f[2 * i + 1] = 0.f;
+            }
+          }
+        } else if (res_grad) {
+          const uint32_t gg[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+          const uint32_t aa[4] = {av[u].x, av[u].y, av[u].z, av[u].w};
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            if (!(bf16lo(aa[i]) > 0.f)) f[2 * i] = 0.f;
-            if (!(bf16hi(aa[i]) > 0.f)) f[2 * i + 1] = 0.f;
+            if (bf16lo(aa[i]) > 0.f) f[2 * i] += bf16lo(gg[i]);
+            if (bf16hi(aa[i]) > 0.f) f[2 * i + 1] += bf16hi(gg[i]);
           }
         }
-      } else if (res_grad) {
-        const uint4 gv = *reinterpret_cast<const uint4*>(res_grad + o);
-        const uint4 av = *reinterpret_cast<const uint4*>(res_act + o);
-        const uint32_t gg[4] = {gv.x, gv.y, gv.z, gv.w}, aa[4] = {av.x, av.y, av.z, av.w};
+        v = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]),
+                       pack_bf16x2(f[6], f[7]));
+      }
+      *reinterpret_cast<uint4*>(out + o[u]) = v;
+      if (RED) {
+        const uint32_t gq4[4] = {v.x, v.y, v.z, v.w};
+        const uint32_t yy[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w};
+        float gq[8], yq[8];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          if (bf16lo(aa[i]) > 0.f) f[2 * i] += bf16lo(gg[i]);
-          if (bf16hi(aa[i]) > 0.f) f[2 * i + 1] += bf16hi(gg[i]);
+          gq[2 * i] = bf16lo(gq4[i]); gq[2 * i + 1] = bf16hi(gq4[i]);
+          yq[2 * i] = bf16lo(yy[i]); yq[2 * i + 1] = bf16hi(yy[i]);
+        }
+        if (red_coef) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            if (!(yq[i] * msc[RED ? i : 0] + msh[RED ? i : 0] > 0.f)) gq[i] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { red->s[i] += gq[i]; red->sy[i] += gq[i] * yq[i]; }
+        if (RED == 2) {
+          const uint32_t zz[4] = {zv[u].x, zv[u].y, zv[u].z, zv[u].w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            red->sy2[2 * i] += gq[2 * i] * bf16lo(zz[i]);
+            red->sy2[2 * i + 1] += gq[2 * i + 1] * bf16hi(zz[i]);
+          }
         }
       }
-      v = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]),
-                     pack_bf16x2(f[6], f[7]));
     }
-    *reinterpret_cast<uint4*>(out + o) = v;
+  }
+}
+
+// Fold the TileRed partials of a workgroup and add them to the exact statistic accumulators:
+// lanes of a wave that own the same channel chunk by shuffles, waves through `scratch`
+// (NTHREADS/64 x 3 x BN floats of LDS that nobody else is using any more), fixed order.
+// red_stats: sums (sum g, sum g*y); red_stats2 (RED == 2): (sum g, sum g*y2).
+template <int BN, int NTHREADS, int RED>
+__device__ __forceinline__ void igemm_red_finish(TileRed& r, float* scratch, float* red_stats,
+                                                 float* red_stats2, int Cout, int n0, int tid) {
+  constexpr int CH = BN / 8, NW = NTHREADS / 64;
+  static_assert(64 % CH == 0, "channel chunks must divide the wave");
+  const int lane = tid & 63, wave = tid >> 6, ch = tid % CH;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+#pragma unroll
+    for (int o = CH; o < 64; o <<= 1) {
+      r.s[i] += __shfl_xor(r.s[i], o, 64);
+      r.sy[i] += __shfl_xor(r.sy[i], o, 64);
+      if (RED == 2) r.sy2[i] += __shfl_xor(r.sy2[i], o, 64);
+    }
+  }
+  __syncthreads();                       // every wave is done with the LDS that becomes scratch
+  if (lane < CH) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      scratch[(wave * 3 + 0) * BN + ch * 8 + i] = r.s[i];
+      scratch[(wave * 3 + 1) * BN + ch * 8 + i] = r.sy[i];
+      if (RED == 2) scratch[(wave * 3 + 2) * BN + ch * 8 + i] = r.sy2[i];
+    }
+  }
+  __syncthreads();
+  if (tid < BN) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int w = 0; w < NW; ++w) {
+      a0 += scratch[(w * 3 + 0) * BN + tid];
+      a1 += scratch[(w * 3 + 1) * BN + tid];
+      if (RED == 2) a2 += scratch[(w * 3 + 2) * BN + tid];
+    }
+    const int stripe = blockIdx.x % IIC_STAT_STRIPES;
+    iic_stat_add(red_stats, stripe, Cout, n0 + tid, 0, a0);
+    iic_stat_add(red_stats, stripe, Cout, n0 + tid, 1, a1);
+    if (RED == 2) {
+      iic_stat_add(red_stats2, stripe, Cout, n0 + tid, 0, a0);
+      iic_stat_add(red_stats2, stripe, Cout, n0 + tid, 1, a2);
+    }
   }
 }

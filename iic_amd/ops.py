@@ -324,12 +324,33 @@ def frag_supported(g):
 ACC_ADD, ACC_PREMASK = 1, 2     # include/iic_hip.h IIC_ACC_*
 
 
+def red_supported(g, w_t):
+  """Can this backward-data launch carry a fused BatchNorm-backward reduction (`red=`)?"""
+  if not (isinstance(w_t, WOperand) and frag_supported(g)):
+    return False
+  ok = getattr(g, "_red_ok", None)
+  if ok is None:
+    ok = bool(lib().iic_conv_igemm_red_supported(ctypes.byref(g)))
+    g._red_ok = ok
+  return ok
+
+
 def conv_igemm(g, x_pt, w_t, out_pt, stats=None, res_grad=None, res_act=None, accumulate=False,
-               premask=False):
+               premask=False, red=None):
   """w_t: a row-major bf16 operand tensor (first-generation kernel) or a WOperand handle
   (second-generation weights-direct kernel wherever the geometry supports it).
-  premask: out = (value [+ previous] [+ res_grad]) where res_act > 0 else 0 (IIC_ACC_PREMASK)."""
+  premask: out = (value [+ previous] [+ res_grad]) where res_act > 0 else 0 (IIC_ACC_PREMASK).
+  red = (y, mask_coef | None, sums, y2 | None, sums2 | None): fused BatchNorm-backward reduction
+  over the stored tile (iic_conv_igemm_frag_red); only where red_supported(g, w_t)."""
   acc = (ACC_ADD if accumulate else 0) | (ACC_PREMASK if premask else 0)
+  if red is not None:
+    assert red_supported(g, w_t), "fused reduction needs the weights-direct kernel"
+    ry, rcoef, rsums, ry2, rsums2 = red
+    check(lib().iic_conv_igemm_frag_red(ctypes.byref(g), ptr(x_pt), ptr(w_t.pw.frag(w_t.bwd)),
+                                        ptr(out_pt), ptr(stats), ptr(res_grad), ptr(res_act), acc,
+                                        ptr(ry), ptr(rcoef), ptr(ry2), ptr(rsums), ptr(rsums2),
+                                        stream_ptr()), "iic_conv_igemm_frag_red")
+    return out_pt
   if isinstance(w_t, WOperand):
     if frag_supported(g):
       check(lib().iic_conv_igemm_frag(ctypes.byref(g), ptr(x_pt), ptr(w_t.pw.frag(w_t.bwd)),

@@ -164,6 +164,19 @@ int iic_conv_igemm_frag_supported(const iic_conv_geom* g);
 int iic_conv_igemm_frag(const iic_conv_geom* g, const void* in, const void* w_frag, void* out,
                         float* stats, const void* res_grad, const void* res_act, int accumulate,
                         void* stream);
+/* Same launch with a fused BatchNorm-backward reduction over the tile it stores (backward-data
+ * launches): the gradient g this conv produces is the upstream gradient of a BatchNorm whose
+ * input y (PT, shaped like `out`) is known, so the two sums that BatchNorm's backward needs,
+ *   red_stats += (sum g, sum g*y)     [red_y2 / red_stats2: (sum g, sum g*y2), downsample branch]
+ * (the quantities of iic_bn_bwd_reduce, residual.py:20-41 backward) are taken in the epilogue from
+ * the stored (bf16-rounded) values -- masked with (scale*y + shift > 0) when red_coef (that
+ * BatchNorm's forward coefficients) is given, i.e. a ReLU sits between it and this conv -- instead
+ * of in a separate HBM-bound pass over g and y.  Single-launch geometries only (stride 1).     */
+int iic_conv_igemm_red_supported(const iic_conv_geom* g);
+int iic_conv_igemm_frag_red(const iic_conv_geom* g, const void* in, const void* w_frag, void* out,
+                            float* stats, const void* res_grad, const void* res_act, int accumulate,
+                            const void* red_y, const float* red_coef, const void* red_y2,
+                            float* red_stats, float* red_stats2, void* stream);
 int iic_weight_prep_frag(const float* w_oihw, void* w_frag, int Cout, int Cin, int T, int bwd,
                          void* stream);
 

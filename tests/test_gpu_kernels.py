@@ -842,3 +842,58 @@ def test_eval_matching_against_reference_golden():
   assert em._original_match(pd, td, 24, 3) == eval_oracle.original_match(p, t, 24, 3)
   with pytest.raises(AssertionError):
     em._original_match(torch.from_numpy(p), td, 24, 3)        # the reference's is_cuda assert is kept
+
+
+@pytest.mark.parametrize("cin,cout,H,N,has2,masked", [
+  (64, 64, 19, 24, False, True),      # persistent 64->64 kernel, mask from y
+  (64, 64, 19, 24, True, False),      # ... with the downsample branch's second sum
+  (128, 128, 13, 40, False, True), (256, 128, 9, 33, True, False), (512, 512, 7, 16, False, False)])
+def test_fused_bn_backward_reduction_in_conv_epilogue(cin, cout, H, N, has2, masked, request):
+  """iic_conv_igemm_frag_red: the sums a BatchNorm backward needs (sum g, sum g*y [, sum g*y2]),
+  taken in the backward-data conv's epilogue, against (a) the separate iic_bn_bwd_reduce pass over
+  the tensor the same conv stored and (b) float64 sums of that tensor on the host; the stored
+  tensor itself must be bit-identical to the launch without the fused reduction."""
+  from iic_amd import geom, ops
+  g0 = torch.Generator(device="cpu").manual_seed(cin + cout + H)
+  def pt(c):
+    t = torch.randn(N, H + 2, H + 2, c, generator=g0).to(torch.bfloat16)
+    t[:, 0] = 0; t[:, -1] = 0; t[:, :, 0] = 0; t[:, :, -1] = 0
+    return t.to(dev())
+  # backward-data of a conv cin -> cout: the gradient dy has cout channels, the result dx cin
+  dy, y, y2, res, act = pt(cout), pt(cin), pt(cin), pt(cin), pt(cin)
+  w = (torch.randn(cout, cin, 3, 3, generator=g0) / math.sqrt(cout * 9)).to(dev())
+  coef = torch.stack([torch.rand(cin, generator=g0) + 0.5, torch.randn(cin, generator=g0) * 0.3,
+                      torch.zeros(cin), torch.ones(cin), torch.zeros(cin)]).to(dev())
+  spec = geom.ConvSpec(cin, cout, 3, 1, 1)
+  (gb,) = geom.bwd_data_geoms(spec, N, H, H, 1, 1)
+  pw = ops.PreppedWeights(w)
+  import ctypes
+  from iic_amd import _lib
+  L = ctypes.CDLL(_lib.LIB_PATH)
+  L.iic_debug_p64_red(1)          # (the persistent 64->64 kernel does not fuse by default: slower)
+  request.addfinalizer(lambda: L.iic_debug_p64_red(0))
+  gb._red_ok = None
+  assert ops.red_supported(gb, pw[1])
+  dx0 = torch.zeros(N, H + 2, H + 2, cin, dtype=torch.bfloat16, device=dev())
+  dx1 = torch.zeros_like(dx0)
+  ops.conv_igemm(gb, dy, pw[1], dx0, res_grad=res, res_act=act, premask=True)
+  s1, s2 = ops.new_stats(cin, dev()), ops.new_stats(cin, dev())
+  ops.conv_igemm(gb, dy, pw[1], dx1, res_grad=res, res_act=act, premask=True,
+                 red=(y, coef if masked else None, s1, y2 if has2 else None, s2 if has2 else None))
+  torch.cuda.synchronize()
+  assert torch.equal(dx0, dx1)
+  r1, r2 = ops.new_stats(cin, dev()), ops.new_stats(cin, dev())
+  ops.bn_bwd_reduce(dx0, None, y, r1, N, H, H, 1, cin, y2=y2 if has2 else None, sums2=r2 if has2 else None,
+                    mask_coef=coef if masked else None)
+  torch.cuda.synchronize()
+  gi = dx0[:, 1:-1, 1:-1, :].double()
+  yi = y[:, 1:-1, 1:-1, :].double()
+  if masked:
+    keep = (y[:, 1:-1, 1:-1, :].float() * coef[0] + coef[1]) > 0
+    gi = gi * keep
+  host = torch.stack([gi.sum((0, 1, 2)), (gi * yi).sum((0, 1, 2))])
+  for fused, sep, ref in ((s1, r1, host),) + (((s2, r2, torch.stack([gi.sum((0, 1, 2)), (gi * y2[:, 1:-1, 1:-1, :].double()).sum((0, 1, 2))])),) if has2 else ()):
+    f, s_ = ops.stats_decode(fused, cin), ops.stats_decode(sep, cin)
+    scale = float(ref.abs().max())
+    assert float((f - ref).abs().max()) <= 2e-5 * scale + 1e-6, float((f - ref).abs().max()) / scale
+    assert float((f - s_).abs().max()) <= 2e-5 * scale + 1e-6

@@ -482,8 +482,9 @@ def test_residual_layer_teacher_forced(layer, nblk, cin, planes, stride, H):
   try:
     xp = ops.pt_from_nchw(x.to(dev()), 1).requires_grad_(True)
     cur = xp
+    link = cl._Chain()        # as the trunk's forward: fused BatchNorm-backward reductions
     for b in blocks:
-      cur = b(cur)
+      cur = b(cur, link)
     got = ops.pt_to_nchw(cur.detach(), 1).cpu()
     gmask = (got > 0).float()
     cur.backward(ops.pt_from_nchw((dout * gmask).to(dev()), 1))
