@@ -73,7 +73,7 @@ _SIGNATURES = {
   "iic_stem_bwd_wgrad": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
   "iic_contingency": (c_int, [_P, _P, c_long, c_int, c_int, _P, _P]),
   "iic_count_equal": (c_int, [_P, _P, c_long, _P, _P]),
-  "iic_augment": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, c_int, _P, _P, c_int, _P, _P, c_int, _P]),
+  "iic_augment": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, c_int, _P, _P, c_int, _P, _P, c_int, _P, _P]),
   "iic_stem_bwd_fused": (c_int, [_P, _P, _P, _P, _P, _P, POINTER(c_int), c_int, c_int, c_int, c_int, _P]),
   "iic_stem_wgrad_combine": (c_int, [_P, c_int, _P, _P, c_int, _P]),
   "iic_firstconv_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),

@@ -89,7 +89,7 @@ def _center_xy(w, h, crop):
 class _AugmenterBase(object):
   """Dataset + resampling tables on the GPU, and the launch (`apply`)."""
 
-  def __init__(self, images_u8, crop_szs, input_sz, include_rgb, jitter, seed):
+  def __init__(self, images_u8, crop_szs, input_sz, include_rgb, jitter, seed, norm=None):
     assert images_u8.dtype == torch.uint8 and images_u8.is_contiguous()
     assert images_u8.dim() == 3 or (images_u8.dim() == 4 and images_u8.shape[3] == 3), \
         "[B, H, W] (mode L) or [B, H, W, 3] (RGB) uint8"
@@ -114,6 +114,13 @@ class _AugmenterBase(object):
     self.bounds = torch.from_numpy(np.concatenate(bl, 0)).to(dev)
     self.kk = torch.from_numpy(np.concatenate(kl, 0)).to(dev)
     self.lut = (torch.arange(256, dtype=torch.float32) / 255).to(dev)   # to_tensor's .div(255)
+    # --demean: torchvision Normalize(mean=config.data_mean, std=config.data_std) on the tensor
+    self.norm = None
+    if norm is not None:
+      mean, std = (np.asarray(v, dtype=np.float32).reshape(-1) for v in norm)
+      C = 1 if self.channels == 1 else (4 if self.include_rgb else 1)
+      assert mean.size == C and std.size == C, "data_mean / data_std need one entry per output channel"
+      self.norm = torch.from_numpy(np.concatenate([mean, std])).to(dev)
 
   @property
   def out_channels(self):
@@ -162,7 +169,8 @@ class _AugmenterBase(object):
     _lib.check(_lib.lib().iic_augment(
       self.images.data_ptr(), self.B, self.H, self.W, self.channels, ip.data_ptr(), fp.data_ptr(), n,
       self.tables_host.ctypes.data, len(self.crop_szs), self.bounds.data_ptr(), self.kk.data_ptr(),
-      self.S, self.lut.data_ptr(), out.data_ptr(), int(self.include_rgb), _lib.stream_ptr()),
+      self.S, self.lut.data_ptr(), out.data_ptr(), int(self.include_rgb),
+      None if self.norm is None else self.norm.data_ptr(), _lib.stream_ptr()),
       "iic_augment")
     return out
 
@@ -189,32 +197,89 @@ class _AugmenterBase(object):
 
 
 class PairedAugmenter(_AugmenterBase):
-  """`sobel_make_transforms` (default branch).  images_u8: uint8 [B, H, W, 3] on the GPU (HWC, the
-  layout torchvision datasets hold).
+  """`sobel_make_transforms` (code/utils/cluster/transforms.py:107-217).  images_u8: uint8
+  [B, H, W, 3] on the GPU (HWC, the layout torchvision datasets hold).
 
   plain(idx) / jittered(idx) / center(idx) return float32 [len(idx), C, input_sz, input_sz]
   (C = 4 with include_rgb, else 1) for tf1 / tf2 / tf3; `draw` exposes the parameter draws so
   that callers (and the tests) can replay them.
+
+  Branches of the reference's tf2 (all optional, the defaults are the default branch):
+    cutout (--cutout, transforms.py:170-186): with probability cutout_p a black box of side
+      2*floor(b/2), b uniform in [int(0.2 crop), int(cutout_max_box crop)], is pasted on the crop;
+    fluid_warp (--fluid_warp, :142-152): with probability 0.5 a RandomRotation(rot_val) of the
+      whole image (PIL NEAREST) first, then a RandomCrop whose size is chosen uniformly from
+      rand_crop_szs_tf;
+    demean (--demean, :196-204): Normalize(data_mean, data_std) at the end of tf1 / tf2 / tf3.
+  per_img_demean (:98-104, :206-212) asserts a 3-channel tensor and therefore cannot run behind
+  custom_greyscale_to_tensor (1 or 4 channels) in the reference either: not built.  random_affine
+  is never switched on by the reference's data layer (data.py calls sobel_make_transforms(config)).
   """
 
   def __init__(self, images_u8, rand_crop_sz, input_sz, include_rgb, jitter=(0.4, 0.4, 0.4, 0.125),
-               seed=0):
+               seed=0, cutout=False, cutout_p=0.5, cutout_max_box=0.5, fluid_warp=False, rot_val=0.0,
+               rand_crop_szs_tf=(), demean=False, data_mean=(), data_std=()):
     assert images_u8.dim() == 4, "RGB dataset [B, H, W, 3]"
-    super(PairedAugmenter, self).__init__(images_u8, [rand_crop_sz], input_sz, include_rgb, jitter, seed)
+    assert not (cutout and fluid_warp), "transforms.py:172"
+    szs = [int(rand_crop_sz)]
+    self.tf2_tables = [0]
+    if fluid_warp:
+      assert len(rand_crop_szs_tf) > 0
+      self.tf2_tables = []
+      for c in rand_crop_szs_tf:
+        if int(c) not in szs:
+          szs.append(int(c))
+        self.tf2_tables.append(szs.index(int(c)))
+    super(PairedAugmenter, self).__init__(images_u8, szs, input_sz, include_rgb, jitter, seed,
+                                          norm=(data_mean, data_std) if demean else None)
     self.crop = int(rand_crop_sz)
+    self.cutout, self.cutout_p = bool(cutout), float(cutout_p)
+    self.cut_min, self.cut_max = int(self.crop * 0.2), int(self.crop * float(cutout_max_box))
+    self.fluid_warp, self.rot_val = bool(fluid_warp), float(rot_val)
+
+  def _cutout_draws(self, ip):
+    """custom_cutout (transforms.py:28-44) under RandomApply(p): box side, centre."""
+    r, n = self.rng, ip.shape[0]
+    do = r.random_sample(n) < self.cutout_p
+    self.last_cutout = np.zeros((n, 4), np.int64)
+    for i in np.nonzero(do)[0]:
+      box_sz = r.randint(self.cut_min, self.cut_max + 1)
+      half = int(np.floor(box_sz / 2.))
+      crop = self.crop_szs[ip[i, 10]]
+      x_c = r.randint(half, crop - half)
+      y_c = r.randint(half, crop - half)
+      box = (x_c - half, y_c - half, x_c + half, y_c + half)
+      self.last_cutout[i] = box
+      if box[2] > box[0] and box[3] > box[1]:
+        ip[i, 18] = box[0] | (box[1] << 16)
+        ip[i, 19] = box[2] | (box[3] << 16)
 
   def draw(self, idx, mode):
     """mode 'plain' (tf1), 'jittered' (tf2) or 'center' (tf3).  Returns (iparams int32 [n, 20],
     fparams float32 [n, 4]) as iic_augment reads them."""
     ip, fp = self._new_params(idx)
+    n = ip.shape[0]
     if mode == "center":
       self._center_crops(ip)
       return ip, fp
-    self._random_crops(ip)
     if mode == "plain":
+      self._random_crops(ip)
       return ip, fp
     assert mode == "jittered"
-    ip[:, 3] = self.rng.random_sample(ip.shape[0]) < 0.5
+    self.last_angles = np.full(n, np.nan)
+    if self.fluid_warp:
+      do = self.rng.random_sample(n) < 0.5
+      ang = self.rng.uniform(-self.rot_val, self.rot_val, size=n)
+      for i in np.nonzero(do)[0]:
+        if ang[i] % 360.0 != 0:                     # PIL's angle-0 fast path is a plain copy
+          ip[i, 11] = 1
+          ip[i, 12:18] = rotation_fixed_point(float(ang[i]), self.W, self.H)
+          self.last_angles[i] = ang[i]
+      ip[:, 10] = np.asarray(self.tf2_tables)[self.rng.randint(0, len(self.tf2_tables), size=n)]
+    self._random_crops(ip)
+    if self.cutout:
+      self._cutout_draws(ip)
+    ip[:, 3] = self.rng.random_sample(n) < 0.5
     self._jitter_draws(ip, fp)
     return ip, fp
 
@@ -224,12 +289,15 @@ class GreyscaleAugmenter(_AugmenterBase):
   images_u8: uint8 [B, H, W] (mode L) on the GPU; `config` carries the reference's flags:
   crop_orig, tf1_crop ('random' | 'centre_half' | 'centre'), tf1_crop_sz, tf3_crop_diff,
   tf3_crop_sz, rot_val, always_rot, crop_other, tf2_crop, tf2_crop_szs, input_sz, no_flip,
-  no_jitter.  demean / per_img_demean are not built (NotImplementedError)."""
+  no_jitter, demean + data_mean / data_std (Normalize).  per_img_demean asserts a 3-channel tensor
+  (transforms.py:99) and cannot run on these 1-channel images in the reference either: refused."""
 
   def __init__(self, images_u8, config, jitter=(0.4, 0.4, 0.4, 0.125), seed=0):
     assert images_u8.dim() == 3, "mode-L dataset [B, H, W]"
-    if getattr(config, "demean", False) or getattr(config, "per_img_demean", False):
-      raise NotImplementedError("demean / per_img_demean are not built on the GPU path")
+    if getattr(config, "per_img_demean", False):
+      raise NotImplementedError("per_img_demean asserts a 3-channel tensor (transforms.py:99): it cannot "
+                                "run on the greyscale pipelines in the reference either")
+    norm = (config.data_mean, config.data_std) if getattr(config, "demean", False) else None
     H, W = int(images_u8.shape[1]), int(images_u8.shape[2])
     full = min(H, W)
     szs = []
@@ -253,7 +321,7 @@ class GreyscaleAugmenter(_AugmenterBase):
       assert H == W
       self.t2 = [table(full)]
     self.cfg = config
-    super(GreyscaleAugmenter, self).__init__(images_u8, szs, config.input_sz, False, jitter, seed)
+    super(GreyscaleAugmenter, self).__init__(images_u8, szs, config.input_sz, False, jitter, seed, norm=norm)
 
   def _crop_kind(self, ip, rows, kind):
     if kind == "random":

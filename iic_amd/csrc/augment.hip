@@ -37,7 +37,10 @@
 
 #define AUG_PREC 22
 #define AUG_IP 20      // ints per output image:  src, x0, y0, flip, nops, op[4], hue_delta, table,
-                       //                         rotate?, a0..a5 (16.16 fixed point), pad, pad
+                       //                         rotate?, a0..a5 (16.16 fixed point),
+                       //                         cutout box (left | upper << 16), (right | lower << 16)
+                       //                         in crop coordinates (custom_cutout, transforms.py:28-44:
+                       //                         img.paste(0, box) on the cropped image; right == left: none)
 #define AUG_FP 4       // floats per output image: factor of op 0 (brightness), 1 (contrast), 2 (saturation), -
 
 __device__ __forceinline__ int aug_luma(int r, int g, int b) {
@@ -103,7 +106,8 @@ template <int CH, bool INC_RGB>
 __global__ __launch_bounds__(256) void augment_kernel(
     const uint8_t* __restrict__ imgs, int H, int W, const int* __restrict__ iparams,
     const float* __restrict__ fparams, const AugTabs tabs, const int* __restrict__ bounds,
-    const int* __restrict__ kk, int S, const float* __restrict__ lut, float* __restrict__ out) {
+    const int* __restrict__ kk, int S, const float* __restrict__ lut, float* __restrict__ out,
+    const float* __restrict__ norm) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ int s_red[4];
   const int n = blockIdx.x, tid = threadIdx.x;
@@ -112,6 +116,8 @@ __global__ __launch_bounds__(256) void augment_kernel(
   const int src = ip[0], x0 = ip[1], y0 = ip[2], flip = ip[3], nops = ip[4], hdelta = ip[9];
   const int tab = ip[10], rot = ip[11];
   const int a0 = ip[12], a1 = ip[13], a2 = ip[14], a3 = ip[15], a4 = ip[16], a5 = ip[17];
+  const int bx0 = ip[18] & 0xffff, by0 = (ip[18] >> 16) & 0xffff;
+  const int bx1 = ip[19] & 0xffff, by1 = (ip[19] >> 16) & 0xffff;
   const int crop = tabs.crop[tab], KS = tabs.ksize[tab];
   const int* bnd = bounds + tabs.boff[tab] * 2;
   const int* kt = kk + tabs.koff[tab];
@@ -125,18 +131,24 @@ __global__ __launch_bounds__(256) void augment_kernel(
     const int xmin = bnd[xo * 2], cnt = bnd[xo * 2 + 1];
     int ss = 1 << (AUG_PREC - 1);
     const int Y = y0 + y, X = x0 + xmin;
+    const bool cut_row = y >= by0 && y < by1;       // cutout: crop pixels inside the box read as 0
     if (rot) {
       int xx = a2 + a1 * Y + a0 * X, yy = a5 + a4 * Y + a3 * X;
       for (int k = 0; k < cnt; ++k) {
         const int xin = xx >> 16, yin = yy >> 16;
-        const int v = (xin >= 0 && xin < W && yin >= 0 && yin < H) ? (int)im[((long)yin * W + xin) * CH + c] : 0;
+        int v = (xin >= 0 && xin < W && yin >= 0 && yin < H) ? (int)im[((long)yin * W + xin) * CH + c] : 0;
+        if (cut_row && xmin + k >= bx0 && xmin + k < bx1) v = 0;
         ss += v * kt[xo * KS + k];
         xx += a0;
         yy += a3;
       }
     } else {
       const uint8_t* row = im + ((long)Y * W + X) * CH + c;
-      for (int k = 0; k < cnt; ++k) ss += (int)row[k * CH] * kt[xo * KS + k];
+      for (int k = 0; k < cnt; ++k) {
+        int v = (int)row[k * CH];
+        if (cut_row && xmin + k >= bx0 && xmin + k < bx1) v = 0;
+        ss += v * kt[xo * KS + k];
+      }
     }
     sB[idx] = (uint8_t)aug_clip8(ss >> AUG_PREC);
   }
@@ -194,17 +206,29 @@ __global__ __launch_bounds__(256) void augment_kernel(
   for (int px = tid; px < S * S; px += 256) {
     const int y = px / S, x = px - y * S;
     const int sp = (y * S + (flip ? S - 1 - x : x)) * CH;
+    // norm (nullable): torchvision Normalize after the tensor conversion, (v - mean[c]) / std[c]
+    // as two float32 operations (t.sub_(m).div_(s)); norm = [C means][C stds]
     if (CH == 1) {
-      on[px] = lut[sC[sp]];
+      float v = lut[sC[sp]];
+      if (norm) v = (v - norm[0]) / norm[1];
+      on[px] = v;
       continue;
     }
     const int r = sC[sp], g = sC[sp + 1], b = sC[sp + 2];
     if (INC_RGB) {
-      on[px] = lut[r];
-      on[S * S + px] = lut[g];
-      on[2 * S * S + px] = lut[b];
+      float vr = lut[r], vg = lut[g], vb = lut[b];
+      if (norm) {
+        vr = (vr - norm[0]) / norm[C + 0];
+        vg = (vg - norm[1]) / norm[C + 1];
+        vb = (vb - norm[2]) / norm[C + 2];
+      }
+      on[px] = vr;
+      on[S * S + px] = vg;
+      on[2 * S * S + px] = vb;
     }
-    on[(C - 1) * S * S + px] = lut[aug_luma(r, g, b)];
+    float vl = lut[aug_luma(r, g, b)];
+    if (norm) vl = (vl - norm[C - 1]) / norm[2 * C - 1];
+    on[(C - 1) * S * S + px] = vl;
   }
 }
 
@@ -213,7 +237,7 @@ extern "C" {
 int iic_augment(const void* imgs_u8, int B, int H, int W, int channels, const int* iparams,
                 const float* fparams, int N, const int* tables_host, int n_tables,
                 const int* bounds, const int* kk, int S, const float* lut, float* out,
-                int include_rgb, void* stream) {
+                int include_rgb, const float* norm, void* stream) {
   if (!imgs_u8 || !iparams || !fparams || !tables_host || !bounds || !kk || !lut || !out) return IIC_ERR_ARG;
   if (B <= 0 || N <= 0 || S <= 0 || H <= 0 || W <= 0) return IIC_ERR_ARG;
   if (channels != 1 && channels != 3) return IIC_ERR_UNSUPPORTED;
@@ -243,7 +267,7 @@ int iic_augment(const void* imgs_u8, int B, int H, int W, int channels, const in
     }                                                                                            \
     hipLaunchKernelGGL((augment_kernel<CH_, RGB_>), dim3(N), dim3(256), lds, s,                   \
                        (const uint8_t*)imgs_u8, H, W, iparams, fparams, tabs, bounds, kk, S, lut, \
-                       out);                                                                     \
+                       out, norm);                                                               \
   } while (0)
   if (channels == 1) AUG_LAUNCH(1, false);
   else if (include_rgb) AUG_LAUNCH(3, true);

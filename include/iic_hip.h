@@ -348,7 +348,10 @@ int iic_count_equal(const long long* a, const long long* b, long n, long long* c
  * iparams  int32 [N][20]: source image, crop x0, crop y0, flip, n_ops, op[4] (0 brightness,
  *          1 contrast, 2 saturation, 3 hue -- in application order), hue shift (uint8 wrap),
  *          table index, rotate flag, a0..a5 = PIL's inverse rotation matrix in 16.16 fixed point
- *          (source x = (a2 + a1*y + a0*x) >> 16, source y = (a5 + a4*y + a3*x) >> 16), 0, 0.
+ *          (source x = (a2 + a1*y + a0*x) >> 16, source y = (a5 + a4*y + a3*x) >> 16), then the
+ *          cutout box of custom_cutout (transforms.py:28-44) in crop coordinates as
+ *          (left | upper << 16), (right | lower << 16); right == left = no cutout.
+ * norm     float [2][C] (means, then stds) of torchvision Normalize (--demean), or NULL.
  * fparams  float [N][4]: factor of brightness, contrast, saturation; [3] = hue factor (not read:
  *          the kernel uses the uint8 increment in iparams[9]).
  * tables_host  HOST int32 [n_tables][4] = (crop size, taps per output = row pitch of its kk table,
@@ -363,7 +366,7 @@ int iic_count_equal(const long long* a, const long long* b, long n, long long* c
 int iic_augment(const void* imgs_u8, int B, int H, int W, int channels, const int* iparams,
                 const float* fparams, int N, const int* tables_host, int n_tables,
                 const int* bounds, const int* kk, int S, const float* lut, float* out,
-                int include_rgb, void* stream);
+                int include_rgb, const float* norm, void* stream);
 
 #ifdef __cplusplus
 }

@@ -61,18 +61,30 @@ def hue_delta(hue_factor):
   return int(hue_factor * 255) % 256
 
 
+def _normalize(t, norm):
+  """torchvision 0.2.1 Normalize: t.sub_(m).div_(s) per channel, float32."""
+  if norm is None:
+    return t
+  mean, std = (np.asarray(v, dtype=np.float32).reshape(-1, 1, 1) for v in norm)
+  return ((t - mean) / std).astype(np.float32)
+
+
 def pil_pipeline(img_u8, crop_xy, crop_sz, out_sz, include_rgb, flip=False, order=(), factors=None,
-                 angle=None):
+                 angle=None, cutout_box=None, norm=None):
   """img_u8: HWC uint8 RGB (sobel pipelines) or HW uint8 (mode "L", greyscale pipelines).
   order: sequence of OP_* (the shuffled ColorJitter order); factors: dict op -> factor
   (brightness / contrast / saturation factors, hue_factor); angle: RandomRotation's draw in degrees
-  (F.rotate(img, angle, resample=False, expand=False, center=None)) or None.
+  (F.rotate(img, angle, resample=False, expand=False, center=None)) or None; cutout_box:
+  (left, upper, right, lower) of custom_cutout's img.paste(0, box) on the crop
+  (transforms.py:28-44) or None; norm: (data_mean, data_std) of the trailing Normalize or None.
   Returns float32 [C, out_sz, out_sz]: custom_greyscale_to_tensor for RGB input, ToTensor for L."""
   img = Image.fromarray(img_u8)
   if angle is not None:
     img = img.rotate(angle, Image.NEAREST, False, None)                     # F.rotate
   x0, y0 = crop_xy
   img = img.crop((x0, y0, x0 + crop_sz, y0 + crop_sz))                     # F.crop
+  if cutout_box is not None:
+    img.paste(0, box=tuple(int(v) for v in cutout_box))                    # custom_cutout
   img = img.resize((out_sz, out_sz), Image.BILINEAR)                       # F.resize
   if flip:
     img = img.transpose(Image.FLIP_LEFT_RIGHT)                             # F.hflip
@@ -87,12 +99,12 @@ def pil_pipeline(img_u8, crop_xy, crop_sz, out_sz, include_rgb, flip=False, orde
     elif img.mode != "L":                  # adjust_hue returns mode L / 1 / I / F images unchanged
       img = tv_adjust_hue(img, f)
   if img.mode == "L":                                                       # ToTensor
-    return (np.asarray(img).astype(np.float32) / np.float32(255))[None]
+    return _normalize((np.asarray(img).astype(np.float32) / np.float32(255))[None], norm)
   grey = np.asarray(img.convert("L")).astype(np.float32) / np.float32(255)  # to_tensor: .float().div(255)
   if not include_rgb:
-    return grey[None]
+    return _normalize(grey[None], norm)
   rgb = np.transpose(np.asarray(img).astype(np.float32) / np.float32(255), (2, 0, 1))
-  return np.concatenate([rgb, grey[None]], 0)
+  return _normalize(np.concatenate([rgb, grey[None]], 0), norm)
 
 
 def center_crop_xy(w, h, crop_sz):
@@ -231,13 +243,18 @@ def np_rotate(a, angle):
 
 
 def np_pipeline(img_u8, crop_xy, crop_sz, out_sz, include_rgb, flip=False, order=(), factors=None,
-                angle=None):
+                angle=None, cutout_box=None, norm=None):
   x0, y0 = crop_xy
   grey_in = img_u8.ndim == 2
   a = img_u8[..., None] if grey_in else img_u8
   if angle is not None:
     a = np_rotate(a, angle)
-  a = np_resize(a[y0:y0 + crop_sz, x0:x0 + crop_sz].astype(np.int64), out_sz)
+  a = a[y0:y0 + crop_sz, x0:x0 + crop_sz].astype(np.int64)
+  if cutout_box is not None:
+    l, u, r, lo = (int(v) for v in cutout_box)
+    a = a.copy()
+    a[max(u, 0):lo, max(l, 0):r] = 0
+  a = np_resize(a, out_sz)
   if flip:
     a = a[:, ::-1]
   for op in order:
@@ -259,11 +276,11 @@ def np_pipeline(img_u8, crop_xy, crop_sz, out_sz, include_rgb, flip=False, order
       a = np_hsv2rgb(hsv)
   lut = np.arange(256, dtype=np.float32) / np.float32(255)
   if grey_in:
-    return lut[a[..., 0]][None]
+    return _normalize(lut[a[..., 0]][None], norm)
   grey = lut[np_luma(a)]
   if not include_rgb:
-    return grey[None]
-  return np.concatenate([np.transpose(lut[a], (2, 0, 1)), grey[None]], 0)
+    return _normalize(grey[None], norm)
+  return _normalize(np.concatenate([np.transpose(lut[a], (2, 0, 1)), grey[None]], 0), norm)
 
 
 def random_params(rng, n, src_hw, crop_sz, jitter=(0.4, 0.4, 0.4, 0.125)):

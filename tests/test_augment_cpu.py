@@ -187,13 +187,47 @@ def test_sobel_draws_and_unsupported_flags():
     paired_dataloaders(aug, torch.zeros(6), 4, 2)                               # one target per image
   cfg = types.SimpleNamespace(crop_orig=True, tf1_crop="random", tf1_crop_sz=20, tf3_crop_diff=False,
                               tf3_crop_sz=0, rot_val=0, always_rot=False, crop_other=False, tf2_crop="random",
-                              tf2_crop_szs=[20], input_sz=24, no_flip=False, no_jitter=True, demean=True,
-                              per_img_demean=False)
+                              tf2_crop_szs=[20], input_sz=24, no_flip=False, no_jitter=True, demean=False,
+                              per_img_demean=True)
   with pytest.raises(NotImplementedError):
     GreyscaleAugmenter(torch.zeros(2, 28, 28, dtype=torch.uint8), cfg)
-  cfg.demean = False
+  cfg.per_img_demean = False
   g = GreyscaleAugmenter(torch.zeros(2, 28, 28, dtype=torch.uint8), cfg, seed=1)
   ipg, fpg = g.draw(np.arange(400) % 2, "jittered")
   assert g.crop_szs == [20, 28]                      # tf1/tf3 crop 20; tf2 without crop_other: whole image
   assert (ipg[:, 10] == 1).all() and (ipg[:, 1:3] == 0).all() and (ipg[:, 4] == 0).all() and (ipg[:, 11] == 0).all()
   assert 0.4 < ipg[:, 3].mean() < 0.6 and (fpg == 0).all()
+
+
+def test_cutout_and_normalize_spec_matches_pil():
+  """custom_cutout (transforms.py:28-44) and the trailing Normalize: the numpy specification of the
+  kernel against PIL, and the draws of PairedAugmenter(cutout=True)."""
+  import torch
+  from iic_amd.augment import PairedAugmenter
+  rng = np.random.default_rng(3)
+  img = rng.integers(0, 256, (40, 40, 3), dtype=np.uint8)
+  for box in ((0, 0, 8, 8), (5, 7, 21, 23), (20, 2, 32, 14), (30, 30, 32, 32)):
+    norm = ([0.4, 0.5, 0.45, 0.47], [0.2, 0.25, 0.3, 0.22])
+    a = ao.pil_pipeline(img, (4, 3), 32, 36, True, cutout_box=box, norm=norm)
+    b = ao.np_pipeline(img, (4, 3), 32, 36, True, cutout_box=box, norm=norm)
+    assert np.array_equal(a, b)
+    c = ao.pil_pipeline(img, (4, 3), 32, 36, True)
+    assert not np.array_equal(ao.pil_pipeline(img, (4, 3), 32, 36, True, cutout_box=box), c)
+  aug = PairedAugmenter(torch.zeros(5, 96, 96, 3, dtype=torch.uint8), 84, 96, False, seed=2, cutout=True,
+                        cutout_p=0.5, cutout_max_box=0.5)
+  ip, _ = aug.draw(np.arange(4000) % 5, "jittered")
+  has = ip[:, 19] != 0
+  assert 0.45 < has.mean() < 0.55
+  l, u = ip[has, 18] & 0xffff, ip[has, 18] >> 16
+  r, lo = ip[has, 19] & 0xffff, ip[has, 19] >> 16
+  side = r - l
+  assert (side == lo - u).all() and side.min() == 2 * (int(84 * 0.2) // 2) and side.max() == 2 * (42 // 2)
+  assert l.min() >= 0 and u.min() >= 0 and r.max() <= 84 and lo.max() <= 84
+  # fluid_warp: rotation half of the time, crop size chosen from the list
+  fw = PairedAugmenter(torch.zeros(5, 96, 96, 3, dtype=torch.uint8), 84, 96, False, seed=2, fluid_warp=True,
+                       rot_val=25.0, rand_crop_szs_tf=[64, 84])
+  ipf, _ = fw.draw(np.arange(2000) % 5, "jittered")
+  assert fw.crop_szs == [84, 64] and set(np.unique(ipf[:, 10])) == {0, 1}
+  assert 0.45 < (ipf[:, 11] == 1).mean() < 0.55 and np.nanmax(np.abs(fw.last_angles)) <= 25.0
+  ipp, _ = fw.draw(np.arange(100) % 5, "plain")
+  assert (ipp[:, 10] == 0).all() and (ipp[:, 11] == 0).all()

@@ -25,7 +25,7 @@ def _dataset(rng, B, H):
   return imgs
 
 
-def _oracle(imgs, ip, fp, crop, S, include_rgb, angles=None):
+def _oracle(imgs, ip, fp, crop, S, include_rgb, angles=None, norm=None):
   out = []
   for i in range(ip.shape[0]):
     ang = None if angles is None or np.isnan(angles[i]) else float(angles[i])
@@ -34,8 +34,11 @@ def _oracle(imgs, ip, fp, crop, S, include_rgb, angles=None):
     factors = {ao.OP_BRIGHTNESS: float(fp[i, 0]), ao.OP_CONTRAST: float(fp[i, 1]),
                ao.OP_SATURATION: float(fp[i, 2]), ao.OP_HUE: float(fp[i, 3])}
     assert ao.hue_delta(float(fp[i, 3])) == ip[i, 9]
+    box = None
+    if ip[i, 19] != 0:
+      box = (ip[i, 18] & 0xffff, ip[i, 18] >> 16, ip[i, 19] & 0xffff, ip[i, 19] >> 16)
     a = ao.pil_pipeline(imgs[ip[i, 0]], (int(ip[i, 1]), int(ip[i, 2])), c, S, include_rgb,
-                        bool(ip[i, 3]), order, factors, angle=ang)
+                        bool(ip[i, 3]), order, factors, angle=ang, cutout_box=box, norm=norm)
     out.append(a)
   return np.stack(out)
 
@@ -163,3 +166,36 @@ def test_greyscale_pipeline_bit_exact_vs_pil(variant):
     if mode == "jittered" and variant == "mnist685":
       assert 20 < int(ip[:, 11].sum()) < 76            # RandomApply(p=0.5)
       assert set(np.unique(ip[:, 10])) == {0, 1, 2}   # all three crop sizes drawn
+
+
+
+@pytest.mark.parametrize("variant", ["cutout", "fluid_warp", "demean"])
+def test_sobel_pipeline_variants_bit_exact_vs_pil(variant):
+  """The non-default branches of sobel_make_transforms (transforms.py:142-204): --cutout (the one a
+  published command uses, commands.txt), --fluid_warp (rotation + crop-size choice on RGB images)
+  and --demean (Normalize), bit for bit against PIL with the same draws."""
+  from iic_amd.augment import PairedAugmenter
+  rng = np.random.default_rng(17)
+  imgs = _dataset(rng, 8, 96)
+  kw, norm, include_rgb = {}, None, True
+  if variant == "cutout":
+    kw = dict(cutout=True, cutout_p=0.7, cutout_max_box=0.5)
+  elif variant == "fluid_warp":
+    kw = dict(fluid_warp=True, rot_val=25.0, rand_crop_szs_tf=[64, 84, 72])
+    include_rgb = False
+  else:
+    norm = ([0.43, 0.42, 0.39, 0.41], [0.27, 0.26, 0.28, 0.25])
+    kw = dict(demean=True, data_mean=norm[0], data_std=norm[1])
+  aug = PairedAugmenter(torch.from_numpy(imgs).cuda(), 84, 96, include_rgb, seed=4, **kw)
+  idx = rng.integers(0, 8, 64)
+  for mode in ("jittered", "plain", "center"):
+    ip, fp = aug.draw(idx, mode)
+    angles = aug.last_angles if (mode == "jittered" and variant == "fluid_warp") else None
+    got = aug.apply(ip, fp).cpu().numpy()
+    want = _oracle(imgs, ip, fp, aug.crop_szs, 96, include_rgb, angles=angles, norm=norm)
+    bad = [i for i in range(len(idx)) if not np.array_equal(got[i], want[i])]
+    assert not bad, (variant, mode, bad[:5], np.abs(got - want).max())
+    if mode == "jittered" and variant == "cutout":
+      assert (ip[:, 19] != 0).sum() > 20
+    if mode == "jittered" and variant == "fluid_warp":
+      assert (ip[:, 11] == 1).sum() > 10 and len(set(ip[:, 10])) == 3
