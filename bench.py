@@ -68,10 +68,15 @@ class ConvTimer(object):
       r = timer._orig(g, x_pt, w_t, out_pt, stats, res_grad, res_act, accumulate, premask, red)
       e1.record()
       flops = 2.0 * g.N * g.MY * g.MX * g.Cout * g.Cin * g.ntaps
-      # algorithmic HBM bytes: read the input rows once, write (or read-modify-write) the
-      # output rows, read the weight slice once -- bf16
+      # algorithmic HBM bytes: read the input rows once, write the output rows, read the weight
+      # slice once, plus every tensor a fused epilogue must read once (previous contents of an
+      # accumulating launch, residual gradient, mask activation, the y / y2 tiles of a fused
+      # BatchNorm-backward reduction) -- all bf16
       rows = float(g.N * g.MY * g.MX)
-      abytes = 2.0 * (rows * g.Cin + rows * g.Cout + g.ntaps * g.Cout * g.Cin)
+      extra = sum(1 for t in (res_grad, res_act) if t is not None) + (1 if accumulate else 0)
+      if red is not None:
+        extra += 1 + (1 if red[3] is not None else 0)
+      abytes = 2.0 * (rows * g.Cin + rows * g.Cout * (1 + extra) + g.ntaps * g.Cout * g.Cin)
       timer.records.append((e0, e1, flops, abytes))
       return r
     ops.conv_igemm = timed
@@ -93,7 +98,7 @@ class ConvTimer(object):
 def pmc_traffic():
   """HBM bytes per conv_igemm launch from the committed rocprofv3 PMC passes of this same
   command (tools/pmc_traffic.py; PMC cannot be collected from inside the process), or None."""
-  p = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+  p = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
   try:
     return float(json.load(open(p))["conv_igemm_hbm_bytes_per_launch"])
   except Exception:
@@ -521,7 +526,7 @@ def main():
           "bound": "mfma", "kernel": "conv_igemm_kernel + conv_igemm_bd_kernel (fwd + bwd-data implicit GEMM, bf16 MFMA)",
           "achieved": s["tflops"], "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
           "frac": s["tflops"] / BF16_PEAK_TFLOPS, "traffic": pmc_traffic(),
-          "traffic_unit": "HBM bytes per launch (PMC, profiles/r01_pmc_traffic.json)",
+          "traffic_unit": "HBM bytes per launch (PMC passes of this command, profiles/r02_pmc_traffic.json)",
           "algorithmic_bytes_per_launch": s["alg_bytes"],
           "launches_timed": s["launches"], "avg_launch_us": s["avg_us"],
           "timed_in": "%d instrumented steps run after the timed region (same batch, same state)" % min(args.steps, 3),
