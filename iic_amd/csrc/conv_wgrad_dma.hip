@@ -359,7 +359,8 @@ static int wd_config(const iic_conv_geom* g, int* bmk, int* nbuf) {
     return 1;
   }
   if (g->NP64 > 0) {
-    for (int nb = 4; nb >= 3; --nb)
+    // (2 buffers: the stride-2 layers, whose 64-row patch spans 330-440 input pixels)
+    for (int nb = 4; nb >= 2; --nb)
       if (wd_lds(g->NP64, cot, 64, nb) <= 160 * 1024) {
         *bmk = 64;
         *nbuf = nb;
@@ -408,8 +409,10 @@ int iic_wgrad_dma_launch(const iic_conv_geom* g, const void* x, const void* dy, 
   } while (0)
   if (bmk == 64 && nbuf == 4) {
     if (cot == 128) WD_LAUNCH(128, 64, 4); else WD_LAUNCH(64, 64, 4);
-  } else if (bmk == 64) {
+  } else if (bmk == 64 && nbuf == 3) {
     if (cot == 128) WD_LAUNCH(128, 64, 3); else WD_LAUNCH(64, 64, 3);
+  } else if (bmk == 64) {
+    if (cot == 128) WD_LAUNCH(128, 64, 2); else WD_LAUNCH(64, 64, 2);
   } else {
     if (cot == 128) WD_LAUNCH(128, 128, 2); else WD_LAUNCH(64, 128, 2);
   }

@@ -810,6 +810,32 @@ def test_full_size_kernels_vs_independent_reference(cin, cout, H):
   assert err <= 2e-4, err
 
 
+@pytest.mark.parametrize("cin,cout,H", [(64, 128, 49), (256, 512, 13)])
+def test_full_size_stride2_weight_gradient_vs_torch(cin, cout, H):
+  """Stride-2 3x3 weight gradient at the full batch (DMA kernel, 64-pixel K-tiles, 2 buffers: its
+  128-pixel patch does not fit LDS twice) against a torch einsum on the device."""
+  from iic_amd import geom, ops
+  N = 660
+  Ho = (H + 2 - 3) // 2 + 1
+  g0 = torch.Generator(device="cpu").manual_seed(cin + H)
+  x = torch.randn(N, H + 2, H + 2, cin, generator=g0).to(torch.bfloat16)
+  x[:, 0] = 0; x[:, -1] = 0; x[:, :, 0] = 0; x[:, :, -1] = 0
+  dy = torch.randn(N, Ho + 2, Ho + 2, cout, generator=g0).to(torch.bfloat16)
+  dy[:, 0] = 0; dy[:, -1] = 0; dy[:, :, 0] = 0; dy[:, :, -1] = 0
+  xd, dyd = x.to(dev()), dy.to(dev())
+  gf = geom.fwd_geom(geom.ConvSpec(cin, cout, 3, 2, 1), N, H, H, 1, 1)
+  dW = ops.conv_wgrad(gf, xd, dyd, 9, use_tr=True).view(cout, cin, 3, 3).clone()
+  torch.cuda.synchronize()
+  xi, dyi = xd.float(), dyd[:, 1:-1, 1:-1, :].float()
+  ref = torch.empty(cout, cin, 3, 3, device=dev())
+  for kh in range(3):
+    for kw in range(3):
+      patch = xi[:, kh:kh + 2 * Ho:2, kw:kw + 2 * Ho:2, :]
+      ref[:, :, kh, kw] = torch.einsum("nyxo,nyxi->oi", dyi, patch)
+  err = float((dW - ref).abs().max()) / float(ref.abs().max())
+  assert err <= 2e-4, err
+
+
 def test_eval_matching_against_reference_golden():
   """iic_amd.eval_metrics (one contingency kernel) vs the reference's own matching functions
   (tests/golden/eval.npz) -- integer work, exact; plus a large random case vs the oracle."""
