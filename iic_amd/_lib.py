@@ -97,6 +97,20 @@ _SIGNATURES = {
                             c_float, c_float, c_float, c_float, c_int, _P]),
   "iic_adam_step_dev": (c_int, [c_int, POINTER(_P), POINTER(_P), POINTER(_P), POINTER(_P), POINTER(_P), POINTER(c_long),
                                 c_float, c_float, c_float, c_float, _P, _P]),
+  "iic_f32_conv": (c_int, [POINTER(ConvGeom), _P, _P, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
+  "iic_f32_wgrad": (c_int, [POINTER(ConvGeom), _P, _P, _P, c_int, c_int, _P]),
+  "iic_f32_bn_apply": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+  "iic_f32_bn_bwd_reduce": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+  "iic_f32_bn_bwd_apply": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+  "iic_f32_avgpool_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+  "iic_f32_avgpool_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+  "iic_f32_maxpool_s2p1_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+  "iic_f32_maxpool_s2p1_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+  "iic_f32_maxpool2_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+  "iic_f32_maxpool2_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+  "iic_f32_window_gather": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+  "iic_f32_window_scatter": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+  "iic_f32_nchw_to_pt": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
   "iic_probe_tr16": (c_int, [_P, _P]),
 }
 

@@ -204,7 +204,7 @@ class _StemFn(torch.autograd.Function):
     ops.stem_apply_pool(x, wd, coef, out)
     ctx.mod = mod
     ctx.training = training
-    ctx.branch = ops.BRANCH[0]
+    ctx.branch, ctx.pt_dtype = ops.BRANCH[0], ops.PT_DTYPE[0]
     ctx.save_for_backward(x, w, gamma, coef, out)
     return out
 
@@ -227,6 +227,58 @@ class _StemFn(torch.autograd.Function):
       dW = ops.stem_bwd_wgrad(x, w.detach(), coef, bcoef, dpool)
     ops.POOL.release(dpool)
     ops.POOL.release(out)
+    return None, dW, dgamma, dbeta, None
+
+
+class _StemF32Fn(torch.autograd.Function):
+  """The stem inside ops.fp32_mode(): conv3x3 -> BN -> ReLU -> MaxPool2d(2, 2, padding=1) as the
+  plain fp32 kernels of csrc/f32_path.hip on materialised tensors (net5g.py:14-26, 42-45)."""
+
+  @staticmethod
+  def forward(ctx, x, w, gamma, beta, mod):
+    assert x.is_cuda
+    x = x.contiguous().float()
+    N, C, H, W = x.shape
+    bn, h = mod.bn1, mod._h_conv1
+    rm, rv, nbt = _bn_buffers(bn)
+    training = _bn_training(bn)
+    dev = x.device
+    xp = ops.f32_nchw_to_pt(x, ops.pt_alloc(N, H, W, C, 1, dev), 1)
+    gf, _ = h.geoms(N, H, W)
+    st = h.stats(dev) if training else None
+    y = ops.pt_alloc(N, H, W, 64, 1, dev)
+    ops.conv_igemm(gf, xp, h.weights()[0], y, stats=st)
+    if training:
+      coef = ops.bn_finalize(st, gamma.detach(), beta.detach(), rm if bn.training else None,
+                             rv if bn.training else None, nbt if bn.training else None, 64, N * H * W, True)
+    else:
+      coef = ops.bn_finalize(None, gamma.detach(), beta.detach(), rm, rv, None, 64, N * H * W, False)
+    a = ops.bn_apply(y, coef, ops.pt_alloc(N, H, W, 64, 1, dev), N, H, W, 1, 64, relu=True)
+    Ho, Wo = H // 2 + 1, W // 2 + 1
+    out = ops.f32_maxpool_s2p1_fwd(a, ops.pt_alloc(N, Ho, Wo, 64, 1, dev), N, H, W, 64)
+    ctx.mod, ctx.training, ctx.branch, ctx.pt_dtype = mod, training, ops.BRANCH[0], ops.PT_DTYPE[0]
+    ctx.dims = (N, C, H, W)
+    ctx.save_for_backward(xp, y, a, coef, gamma)
+    return out
+
+  @ops.branch_backward
+  def backward(ctx, dpool):
+    xp, y, a, coef, gamma = ctx.saved_tensors
+    if not ctx.training:
+      raise RuntimeError("HIP BatchNorm backward is implemented for batch statistics only")
+    N, C, H, W = ctx.dims
+    dev, h = xp.device, ctx.mod._h_conv1
+    with ops.fp32_mode():
+      da = ops.f32_maxpool_s2p1_bwd(a, dpool.contiguous(), ops.pt_alloc(N, H, W, 64, 1, dev), N, H, W, 64)
+      sums = h.stats(dev, "bwd")
+      ops.bn_bwd_reduce(da, None, y, sums, N, H, W, 1, 64, mask_coef=coef)
+      bcoef, dgamma, dbeta = ops.bn_bwd_finalize(sums, gamma.detach(), coef, 64, N * H * W)
+      dy = ops.pt_alloc(N, H, W, 64, 1, dev)
+      ops.bn_bwd_apply(da, None, y, bcoef, dy, N, H, W, 1, 64, mask_coef=coef)
+      gf, _ = h.geoms(N, H, W)
+      dW = ops.conv_wgrad(gf, xp, dy, 9).view(64, C, 3, 3)
+    for t in (dpool, da, dy, xp, y, a):
+      ops.POOL.release(t)
     return None, dW, dgamma, dbeta, None
 
 
@@ -280,7 +332,7 @@ class _BlockFn(torch.autograd.Function):
 
     if need_grad:
       ctx.blk = blk
-      ctx.branch = ops.BRANCH[0]
+      ctx.branch, ctx.pt_dtype = ops.BRANCH[0], ops.PT_DTYPE[0]
       ctx.dims = (N, H, W, Ho, Wo, Cin, planes)
       ctx.bn_batch = (_bn_training(blk.bn1) and _bn_training(blk.bn2))
       # (set by the trunk for the duration of its sequential forward, see PREMASK)
@@ -445,7 +497,7 @@ class _AvgPoolFn(torch.autograd.Function):
   def forward(ctx, x, premask):
     N, Hp, Wp, C = x.shape
     ctx.dims = (N, Hp - 2, Wp - 2, C)
-    ctx.branch = ops.BRANCH[0]
+    ctx.branch, ctx.pt_dtype = ops.BRANCH[0], ops.PT_DTYPE[0]
     ctx.premask = bool(premask)
     if premask:
       ctx.save_for_backward(x)      # its ReLU mask is applied to the gradient here (PREMASK)
@@ -575,7 +627,8 @@ class ClusterNet5gTrunk(nn.Module):
       b._mask_dx = chain and i > 0        # block 0's input gradient goes to the stem (own masking)
       b._chain = link
     try:
-      x = _StemFn.apply(x, ops.pv(self.conv1.weight), ops.pv(self.bn1.weight), ops.pv(self.bn1.bias), self)
+      stem = _StemF32Fn if ops.PT_DTYPE[0] is torch.float32 else _StemFn
+      x = stem.apply(x, ops.pv(self.conv1.weight), ops.pv(self.bn1.weight), ops.pv(self.bn1.bias), self)
       x = self.layer1(x)
       x = self.layer2(x)
       x = self.layer3(x)

@@ -30,7 +30,10 @@ class _SegHeadFn(torch.autograd.Function):
     M = N * Hw * Ww
     L, s = lib(), stream_ptr()
     Fm = torch.empty((M, C), dtype=F32, device=x.device)
-    check(L.iic_seg_window_gather(ptr(x), ptr(Fm), N, Hw, Ww, Hp, Wp, off, C, s), "iic_seg_window_gather")
+    if x.dtype == F32:      # exact-fp32 parity path
+      check(L.iic_f32_window_gather(ptr(x), ptr(Fm), N, Hw, Ww, Hp, Wp, off, C, s), "iic_f32_window_gather")
+    else:
+      check(L.iic_seg_window_gather(ptr(x), ptr(Fm), N, Hw, Ww, Hp, Wp, off, C, s), "iic_seg_window_gather")
     W2 = w.detach().reshape(k, C).contiguous()
     logits = torch.empty((M, k), dtype=F32, device=x.device)
     ops.gemm_f32(Fm, C, 1, W2, 1, C, logits, k, M, k, C)
@@ -39,7 +42,7 @@ class _SegHeadFn(torch.autograd.Function):
     check(L.iic_bilinear_fwd(ptr(probs), ptr(out), N, Hw, Ww, k, S, s), "iic_bilinear_fwd")
     ctx.save_for_backward(Fm, W2, probs)
     ctx.meta = (tuple(x.shape), P, S, Hw, Ww, off, k)
-    ctx.branch = ops.BRANCH[0]
+    ctx.branch, ctx.pt_dtype = ops.BRANCH[0], x.dtype
     return out
 
   @ops.branch_backward
@@ -59,7 +62,10 @@ class _SegHeadFn(torch.autograd.Function):
     dF = torch.empty((M, C), dtype=F32, device=dout.device)
     ops.gemm_f32(dlog, k, 1, W2, C, 1, dF, C, M, C, k)
     dx = ops.POOL.alloc(shape, dout.device, P)
-    check(L.iic_seg_window_scatter(ptr(dF), ptr(dx), N, Hw, Ww, Hp, Wp, off, C, s), "iic_seg_window_scatter")
+    if dx.dtype == F32:
+      check(L.iic_f32_window_scatter(ptr(dF), ptr(dx), N, Hw, Ww, Hp, Wp, off, C, s), "iic_f32_window_scatter")
+    else:
+      check(L.iic_seg_window_scatter(ptr(dF), ptr(dx), N, Hw, Ww, Hp, Wp, off, C, s), "iic_seg_window_scatter")
     return dx, dW.view(k, C, 1, 1), None, None
 
 

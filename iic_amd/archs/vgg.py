@@ -39,7 +39,12 @@ class _StageFn(torch.autograd.Function):
       Ho, Wo = H, W
       y = ops.pt_alloc(N, Ho, Wo, C, P, dev)
       stt = st.holder.stats(dev) if training else None
-      ops.firstconv_fwd(x, w.detach(), y, stt, st.K, st.pad, P)
+      if ops.PT_DTYPE[0] is torch.float32:      # exact-fp32 parity path: generic conv on the PT image
+        x = ops.f32_nchw_to_pt(x, ops.pt_alloc(N, H, W, x.shape[1], P, dev), P)
+        gf, _ = st.holder.geoms(N, H, W)
+        ops.conv_igemm(gf, x, st.holder.weights()[0], y, stats=stt)
+      else:
+        ops.firstconv_fwd(x, w.detach(), y, stt, st.K, st.pad, P)
     else:
       N, Hp, Wp, _ = x.shape
       H, W = Hp - 2 * P, Wp - 2 * P
@@ -64,7 +69,7 @@ class _StageFn(torch.autograd.Function):
     need_grad = any(ctx.needs_input_grad)
     if need_grad:
       ctx.st = st
-      ctx.branch = ops.BRANCH[0]
+      ctx.branch, ctx.pt_dtype = ops.BRANCH[0], ops.PT_DTYPE[0]
       ctx.dims = (N, H, W, Ho, Wo)
       ctx.training = training
       ctx.save_for_backward(x, w, gamma, y, a, coef, out if st.pool else None)
@@ -98,7 +103,11 @@ class _StageFn(torch.autograd.Function):
     dy = ops.pt_alloc(N, Ho, Wo, C, P, dev)
     ops.bn_bwd_apply(da, None, y, bcoef, dy, N, Ho, Wo, P, C, mask_coef=coef)
     dx = None
-    if st.first:
+    if st.first and x.dim() == 4 and x.dtype == torch.float32 and dy.dtype == torch.float32:
+      gf, _ = st.holder.geoms(N, H, W)         # fp32 parity path: x is the PT copy of the image
+      dW = ops.conv_wgrad(gf, x, dy, st.K * st.K).view(C, st.cin, st.K, st.K)
+      ops.POOL.release(x)
+    elif st.first:
       dW = ops.firstconv_wgrad(x, dy, tuple(w.shape), st.K, st.pad, P)
     else:
       gf, gb = st.holder.geoms(N, H, W)
@@ -126,7 +135,7 @@ class _FlattenFn(torch.autograd.Function):
   def forward(ctx, x, P):
     N, Hp, Wp, C = x.shape
     ctx.meta = (tuple(x.shape), P)
-    ctx.branch = ops.BRANCH[0]
+    ctx.branch, ctx.pt_dtype = ops.BRANCH[0], x.dtype
     return x[:, P:Hp - P, P:Wp - P, :].float().reshape(N, -1)
 
   @ops.branch_backward
@@ -134,7 +143,7 @@ class _FlattenFn(torch.autograd.Function):
     shape, P = ctx.meta
     N, Hp, Wp, C = shape
     dx = ops.POOL.alloc(shape, dfeat.device, P)
-    dx[:, P:Hp - P, P:Wp - P, :] = dfeat.contiguous().view(N, Hp - 2 * P, Wp - 2 * P, C).to(torch.bfloat16)
+    dx[:, P:Hp - P, P:Wp - P, :] = dfeat.contiguous().view(N, Hp - 2 * P, Wp - 2 * P, C).to(dx.dtype)
     return dx, None
 
 

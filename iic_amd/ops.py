@@ -152,12 +152,13 @@ def flush_deferred_running():
 def branch_backward(fn):
   """Decorator for autograd Function.backward: run under the branch the forward recorded."""
   def wrapped(ctx, *grads):
-    prev = BRANCH[0]
+    prev, prev_dt = BRANCH[0], PT_DTYPE[0]
     BRANCH[0] = getattr(ctx, "branch", 0)
+    PT_DTYPE[0] = getattr(ctx, "pt_dtype", prev_dt)     # (fp32_mode() forwards allocate fp32 in backward too)
     try:
       return fn(ctx, *grads)
     finally:
-      BRANCH[0] = prev
+      BRANCH[0], PT_DTYPE[0] = prev, prev_dt
   wrapped.__name__ = getattr(fn, "__name__", "backward")
   return staticmethod(wrapped)
 
@@ -168,6 +169,24 @@ def branch_backward(fn):
 # (no per-step memset traffic).  A buffer is handed out by `alloc`, and returned with
 # `release` once every kernel that reads it has been enqueued (stream-ordered reuse).
 # ------------------------------------------------------------------------------------
+# Storage type of PT tensors: bf16 (the product path) or, inside `with fp32_mode():`, fp32 -- the
+# exact-fp32 parity path of csrc/f32_path.hip (SURVEY.md §8c tier T2): same orchestration, plain
+# fp32 kernels, for whole-network comparisons with the reference's fp32 results.  Every wrapper
+# below dispatches on the dtype of the tensors it is handed.
+PT_DTYPE = [BF16]
+
+
+class fp32_mode(object):
+  def __enter__(self):
+    self.prev = PT_DTYPE[0]
+    PT_DTYPE[0] = F32
+    return self
+
+  def __exit__(self, *exc):
+    PT_DTYPE[0] = self.prev
+    return False
+
+
 class PTPool(object):
   """Buffers are keyed by (shape, border P, device, branch): a recycled buffer is only valid for
   a tensor with the SAME interior/border split (its border must still be zero), and only on the
@@ -179,13 +198,14 @@ class PTPool(object):
     self.allocated_bytes = 0
 
   def alloc(self, shape, device, P=1):
-    key = (tuple(shape), int(P), str(device), BRANCH[0])
+    dt = PT_DTYPE[0]
+    key = (tuple(shape), int(P), str(device), BRANCH[0], dt)
     lst = self.free.get(key)
     if lst:
       return lst.pop()
-    t = torch.zeros(shape, dtype=BF16, device=device)
+    t = torch.zeros(shape, dtype=dt, device=device)
     self.border[t.data_ptr()] = (int(P), BRANCH[0])
-    self.allocated_bytes += t.numel() * 2
+    self.allocated_bytes += t.numel() * t.element_size()
     return t
 
   def release(self, t):
@@ -194,7 +214,7 @@ class PTPool(object):
     ent = self.border.get(t.data_ptr())
     if ent is None:
       return                  # not one of ours (e.g. a user tensor): never recycle it
-    key = (tuple(t.shape), ent[0], str(t.device), ent[1])
+    key = (tuple(t.shape), ent[0], str(t.device), ent[1], t.dtype)
     self.free.setdefault(key, []).append(t)
 
   def clear(self):
@@ -210,10 +230,10 @@ def pt_alloc(N, H, W, C, P, device):
 
 
 def pt_from_nchw(x, P):
-  """(test / boundary helper) NCHW float tensor -> PT bf16."""
+  """(test / boundary helper) NCHW float tensor -> PT (bf16, or fp32 inside fp32_mode())."""
   n, c, h, w = x.shape
-  out = torch.zeros((n, h + 2 * P, w + 2 * P, c), dtype=BF16, device=x.device)
-  out[:, P:P + h, P:P + w, :] = x.permute(0, 2, 3, 1).to(BF16)
+  out = torch.zeros((n, h + 2 * P, w + 2 * P, c), dtype=PT_DTYPE[0], device=x.device)
+  out[:, P:P + h, P:P + w, :] = x.permute(0, 2, 3, 1).to(PT_DTYPE[0])
   return out
 
 
@@ -326,7 +346,7 @@ ACC_ADD, ACC_PREMASK = 1, 2     # include/iic_hip.h IIC_ACC_*
 
 def red_supported(g, w_t):
   """Can this backward-data launch carry a fused BatchNorm-backward reduction (`red=`)?"""
-  if not (isinstance(w_t, WOperand) and frag_supported(g)):
+  if PT_DTYPE[0] is not BF16 or not (isinstance(w_t, WOperand) and frag_supported(g)):
     return False
   ok = getattr(g, "_red_ok", None)
   if ok is None:
@@ -343,6 +363,13 @@ def conv_igemm(g, x_pt, w_t, out_pt, stats=None, res_grad=None, res_act=None, ac
   red = (y, mask_coef | None, sums, y2 | None, sums2 | None): fused BatchNorm-backward reduction
   over the stored tile (iic_conv_igemm_frag_red); only where red_supported(g, w_t)."""
   acc = (ACC_ADD if accumulate else 0) | (ACC_PREMASK if premask else 0)
+  if x_pt.dtype == F32:       # exact-fp32 parity path: the fp32 OIHW parameter itself is the operand
+    assert isinstance(w_t, WOperand) and red is None and out_pt.dtype == F32
+    w = w_t.pw.w
+    check(lib().iic_f32_conv(ctypes.byref(g), ptr(x_pt), ptr(w), w.shape[2] * w.shape[3], 1 if w_t.bwd else 0,
+                             ptr(out_pt), ptr(stats), ptr(res_grad), ptr(res_act), acc, stream_ptr()),
+          "iic_f32_conv")
+    return out_pt
   if red is not None:
     assert red_supported(g, w_t), "fused reduction needs the weights-direct kernel"
     ry, rcoef, rsums, ry2, rsums2 = red
@@ -370,6 +397,12 @@ _WG_PART = {}
 def conv_wgrad(g, x_pt, dy_pt, wtaps, use_tr=True, out=None, accumulate=False, nsplit=None):
   """Returns dW fp32 [Co][Ci][kh][kw] flattened as [Co, Ci, wtaps].  nsplit: override of the
   split-K factor (tests: few splits = many K-tiles per workgroup)."""
+  if x_pt.dtype == F32:
+    if out is None:
+      out = torch.empty((g.Cout, g.Cin, wtaps), dtype=F32, device=x_pt.device)
+    check(lib().iic_f32_wgrad(ctypes.byref(g), ptr(x_pt), ptr(dy_pt), ptr(out), wtaps, 1 if accumulate else 0,
+                              stream_ptr()), "iic_f32_wgrad")
+    return out
   ns = int(nsplit) if nsplit else lib().iic_conv_wgrad_nsplit(ctypes.byref(g))
   need = ns * g.ntaps * g.Cout * g.Cin
   key = (str(x_pt.device), BRANCH[0])
@@ -415,6 +448,10 @@ def bn_finalize(stats, gamma, beta, running_mean, running_var, nbt, C, count, tr
 
 
 def bn_apply(y, coef, out, N, H, W, P, C, res=None, y2=None, coef2=None, relu=True):
+  if y.dtype == F32:
+    check(lib().iic_f32_bn_apply(ptr(y), ptr(coef), ptr(res), ptr(y2), ptr(coef2), ptr(out), N, H, W, P, C,
+                                 1 if relu else 0, stream_ptr()), "iic_f32_bn_apply")
+    return out
   check(lib().iic_bn_apply(ptr(y), ptr(coef), ptr(res), ptr(y2), ptr(coef2), ptr(out), N, H, W, P,
                            C, 1 if relu else 0, stream_ptr()), "iic_bn_apply")
   return out
@@ -423,6 +460,10 @@ def bn_apply(y, coef, out, N, H, W, P, C, res=None, y2=None, coef2=None, relu=Tr
 def bn_bwd_reduce(dout, act, y, sums, N, H, W, P, C, y2=None, sums2=None, mask_coef=None):
   """mask_coef: forward coef of this BN when act = relu(bn(y)) exactly (pass act=None): the ReLU
   mask is recomputed from y instead of reading the activation tensor."""
+  if y.dtype == F32:
+    check(lib().iic_f32_bn_bwd_reduce(ptr(dout), ptr(act), ptr(y), ptr(y2), ptr(sums), ptr(sums2),
+                                      ptr(mask_coef), N, H, W, P, C, stream_ptr()), "iic_f32_bn_bwd_reduce")
+    return
   check(lib().iic_bn_bwd_reduce(ptr(dout), ptr(act), ptr(y), ptr(y2), ptr(sums), ptr(sums2),
                                 ptr(mask_coef), N, H, W, P, C, stream_ptr()), "iic_bn_bwd_reduce")
 
@@ -438,6 +479,11 @@ def bn_bwd_finalize(sums, gamma, coef, C, count):
 
 def bn_bwd_apply(dout, act, y, bcoef, dy, N, H, W, P, C, y2=None, bcoef2=None, dy2=None,
                  mask_coef=None):
+  if y.dtype == F32:
+    check(lib().iic_f32_bn_bwd_apply(ptr(dout), ptr(act), ptr(y), ptr(bcoef), ptr(dy), ptr(y2), ptr(bcoef2),
+                                     ptr(dy2), ptr(mask_coef), N, H, W, P, C, stream_ptr()),
+          "iic_f32_bn_bwd_apply")
+    return
   check(lib().iic_bn_bwd_apply(ptr(dout), ptr(act), ptr(y), ptr(bcoef), ptr(dy), ptr(y2),
                                ptr(bcoef2), ptr(dy2), ptr(mask_coef), N, H, W, P, C, stream_ptr()),
         "iic_bn_bwd_apply")
@@ -519,16 +565,40 @@ def stem_wgrad_combine(handle, bcoef, w):
   return dW
 
 
+def f32_nchw_to_pt(x, out_pt, P):
+  n, c, h, w = x.shape
+  check(lib().iic_f32_nchw_to_pt(ptr(x), ptr(out_pt), n, c, h, w, P, stream_ptr()), "iic_f32_nchw_to_pt")
+  return out_pt
+
+
+def f32_maxpool_s2p1_fwd(x_pt, out_pt, N, H, W, C):
+  check(lib().iic_f32_maxpool_s2p1_fwd(ptr(x_pt), ptr(out_pt), N, H, W, C, stream_ptr()), "iic_f32_maxpool_s2p1_fwd")
+  return out_pt
+
+
+def f32_maxpool_s2p1_bwd(x_pt, dout_pt, din_pt, N, H, W, C):
+  check(lib().iic_f32_maxpool_s2p1_bwd(ptr(x_pt), ptr(dout_pt), ptr(din_pt), N, H, W, C, stream_ptr()),
+        "iic_f32_maxpool_s2p1_bwd")
+  return din_pt
+
+
 # ------------------------------------------------------------------------------------
 # heads
 # ------------------------------------------------------------------------------------
 def avgpool_fwd(x_pt, N, H, W, P, C):
   feats = torch.empty((N, C), dtype=F32, device=x_pt.device)
+  if x_pt.dtype == F32:
+    check(lib().iic_f32_avgpool_fwd(ptr(x_pt), ptr(feats), N, H, W, P, C, stream_ptr()), "iic_f32_avgpool_fwd")
+    return feats
   check(lib().iic_avgpool_fwd(ptr(x_pt), ptr(feats), N, H, W, P, C, stream_ptr()), "iic_avgpool_fwd")
   return feats
 
 
 def avgpool_bwd(dfeats, out_pt, N, H, W, P, C, mask_act=None):
+  if out_pt.dtype == F32:
+    check(lib().iic_f32_avgpool_bwd(ptr(dfeats), ptr(out_pt), N, H, W, P, C, ptr(mask_act), stream_ptr()),
+          "iic_f32_avgpool_bwd")
+    return out_pt
   check(lib().iic_avgpool_bwd(ptr(dfeats), ptr(out_pt), N, H, W, P, C, ptr(mask_act), stream_ptr()),
         "iic_avgpool_bwd")
   return out_pt
@@ -586,12 +656,19 @@ def firstconv_wgrad(x, dy_pt, w_shape, K, pad, P):
 
 
 def maxpool2_fwd(x_pt, out_pt, N, H, W, Pi, Po, C):
+  if x_pt.dtype == F32:
+    check(lib().iic_f32_maxpool2_fwd(ptr(x_pt), ptr(out_pt), N, H, W, Pi, Po, C, stream_ptr()), "iic_f32_maxpool2_fwd")
+    return out_pt
   check(lib().iic_maxpool2_fwd(ptr(x_pt), ptr(out_pt), N, H, W, Pi, Po, C, stream_ptr()),
         "iic_maxpool2_fwd")
   return out_pt
 
 
 def maxpool2_bwd(x_pt, dout_pt, din_pt, N, H, W, Pi, Po, C):
+  if x_pt.dtype == F32:
+    check(lib().iic_f32_maxpool2_bwd(ptr(x_pt), ptr(dout_pt), ptr(din_pt), N, H, W, Pi, Po, C, stream_ptr()),
+          "iic_f32_maxpool2_bwd")
+    return din_pt
   check(lib().iic_maxpool2_bwd(ptr(x_pt), ptr(dout_pt), ptr(din_pt), N, H, W, Pi, Po, C,
                                stream_ptr()), "iic_maxpool2_bwd")
   return din_pt

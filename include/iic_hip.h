@@ -320,6 +320,45 @@ int iic_adam_step_dev(int n, float* const* params, const float* const* grads,
                       const long* numel, float lr, float beta1, float beta2, float eps,
                       int* steps_done, void* stream);
 
+/* ---------------------------------------------------------------------------------
+ * Exact-fp32 path (SURVEY.md 8c parity tier T2; csrc/f32_path.hip).  The same operators as above
+ * on fp32 PT tensors -- same geometry descriptors, epilogue flags and statistic accumulators --
+ * as plain one-thread-per-output kernels.  Selected only by iic_amd.ops.fp32_mode(): it lets a whole
+ * network be compared with the reference's fp32 results to ~1e-4; never used by the product path.
+ * Weights are the fp32 OIHW parameters themselves (wtaps = kh*kw); transposed = 1 for the
+ * backward-data geometries (the geometry's output channels are the parameter's input channels).
+ * ------------------------------------------------------------------------------- */
+int iic_f32_conv(const iic_conv_geom* g, const float* in, const float* w_oihw, int wtaps, int transposed,
+                 float* out, float* stats, const float* res_grad, const float* res_act, int accumulate,
+                 void* stream);
+int iic_f32_wgrad(const iic_conv_geom* g, const float* x, const float* dy, float* dW_oihw, int wtaps,
+                  int accumulate, void* stream);
+int iic_f32_bn_apply(const float* y, const float* coef, const float* res, const float* y2, const float* coef2,
+                     float* out, int N, int H, int W, int P, int C, int relu, void* stream);
+int iic_f32_bn_bwd_reduce(const float* dout, const float* act, const float* y, const float* y2, float* sums,
+                          float* sums2, const float* mask_coef, int N, int H, int W, int P, int C,
+                          void* stream);
+int iic_f32_bn_bwd_apply(const float* dout, const float* act, const float* y, const float* bcoef, float* dy,
+                         const float* y2, const float* bcoef2, float* dy2, const float* mask_coef, int N, int H,
+                         int W, int P, int C, void* stream);
+int iic_f32_avgpool_fwd(const float* in_pt, float* feats, int N, int H, int W, int P, int C, void* stream);
+int iic_f32_avgpool_bwd(const float* dfeats, float* din_pt, int N, int H, int W, int P, int C,
+                        const float* mask_act_pt, void* stream);
+/* nn.MaxPool2d(2, 2, padding=1) of the ClusterNet5g stem (net5g.py:26), PT (P = 1) in and out */
+int iic_f32_maxpool_s2p1_fwd(const float* in_pt, float* out_pt, int N, int H, int W, int C, void* stream);
+int iic_f32_maxpool_s2p1_bwd(const float* in_pt, const float* dout_pt, float* din_pt, int N, int H, int W, int C,
+                             void* stream);
+int iic_f32_nchw_to_pt(const float* x_nchw, float* out_pt, int N, int C, int H, int W, int P, void* stream);
+/* nn.MaxPool2d(2, 2) of the VGG-style trunks and the SegmentationNet10a head's window copies */
+int iic_f32_maxpool2_fwd(const float* in_pt, float* out_pt, int N, int H, int W, int Pi, int Po, int C,
+                         void* stream);
+int iic_f32_maxpool2_bwd(const float* in_pt, const float* dout_pt, float* din_pt, int N, int H, int W, int Pi,
+                         int Po, int C, void* stream);
+int iic_f32_window_gather(const float* pt, float* out, int N, int Hw, int Ww, int Hp, int Wp, int off, int C,
+                          void* stream);
+int iic_f32_window_scatter(const float* in, float* pt, int N, int Hw, int Ww, int Hp, int Wp, int off, int C,
+                           void* stream);
+
 /* one-time device probes used by the test-suite (documented in DESIGN.md) */
 int iic_probe_tr16(void* out_u16_64x4, void* stream);
 

@@ -562,3 +562,58 @@ def test_premasked_gradient_chain_matches_self_masking_blocks():
   for n in g0:
     assert _cos(g0[n], g1[n]) > 0.9999, n
     assert abs(float(g1[n].norm() / g0[n].norm()) - 1) < 2e-3, n
+
+
+def test_net5g_fp32_mode_vs_reference_golden():
+  """SURVEY.md §8c parity tier T2: the WHOLE ClusterNet5g train step (sobel -> two train-mode
+  forwards -> IID_loss x sub-heads -> backward) with the library's host orchestration running on
+  the exact-fp32 kernels (`ops.fp32_mode()`, csrc/f32_path.hip) against the fp32 golden produced by
+  the reference itself (tests/golden/nets.npz): nothing but fp32 summation order separates the two,
+  so outputs, loss, running statistics and every parameter gradient are held tightly -- which the
+  bf16 production path (rounding amplified by 33 batch-statistics BatchNorm layers) cannot be."""
+  from iic_amd import archs, ops
+  from iic_amd.losses import IID_loss
+  from iic_amd.transforms import sobel_process
+  from oracle import net_oracle
+  g = np.load(os.path.join(G, "nets.npz"))
+  params = net_oracle.make_net5g_params(2, 10, 2, True, seed=3, randomize_bn=True, head_std=0.3)
+  net = archs.ClusterNet5g(_cfg(input_sz=32, num_sub_heads=2, output_k=10))
+  net.load_state_dict(params, strict=True)
+  net.to(dev()).train()
+  imgs, imgs_tf = net_oracle.make_paired_batch(24, 32, 3, seed=5)
+  with ops.fp32_mode():
+    xo = net(sobel_process(imgs.to(dev()), False))
+    xt = net(sobel_process(imgs_tf.to(dev()), False))
+  tot = None
+  for i in range(2):
+    l, _ = IID_loss(xo[i], xt[i], lamb=1.0)
+    tot = l if tot is None else tot + l
+  tot = tot / 2
+  tot.backward()                       # (outside the context: the Functions remember their mode)
+  torch.cuda.synchronize()
+  out = np.stack([o.detach().cpu().numpy() for o in xo])
+  out_tf = np.stack([o.detach().cpu().numpy() for o in xt])
+  assert np.abs(out - g["net5g_out"]).max() <= 2e-4, np.abs(out - g["net5g_out"]).max()
+  assert np.abs(out_tf - g["net5g_out_tf"]).max() <= 2e-4, np.abs(out_tf - g["net5g_out_tf"]).max()
+  lref = float(g["net5g_loss"][0])
+  assert abs(float(tot.detach()) - lref) <= 2e-4 * abs(lref), (float(tot.detach()), lref)
+  worst = 0.0
+  for n, p in net.named_parameters():
+    gn, gs, g0 = g["net5g_grad/" + n]
+    gd = p.grad.detach().double()
+    assert abs(float(gd.norm()) - gn) <= 5e-3 * max(gn, 1e-6) + 1e-9, (n, float(gd.norm()), gn)
+    # single elements: the loss here is ~-0.015 (MI ~ 0), its gradient is a difference of nearly
+    # equal terms and the fp32 reference itself carries ~1e-2 of element noise against float64
+    rms = gn / max(gd.numel() ** 0.5, 1)
+    assert abs(float(gd.flatten()[0]) - g0) <= 3e-2 * max(rms, abs(g0)) + 1e-9, (n, float(gd.flatten()[0]), g0)
+    assert abs(float(gd.sum()) - gs) <= 3e-2 * (abs(gs) + gn), (n, float(gd.sum()), gs)
+    worst = max(worst, abs(float(gd.norm()) - gn) / max(gn, 1e-12))
+  sd = net.state_dict()
+  assert np.abs(sd["trunk.bn1.running_mean"].cpu().numpy() - g["net5g_rm_bn1"]).max() <= 1e-5
+  assert np.allclose(sd["trunk.bn1.running_var"].cpu().numpy(), g["net5g_rv_bn1"], rtol=1e-4, atol=1e-7)
+  assert np.allclose(sd["trunk.layer4.2.bn2.running_var"].cpu().numpy(), g["net5g_rv_l4"], rtol=1e-3, atol=1e-7)
+  os.makedirs("gpurun_out", exist_ok=True)
+  with open("gpurun_out/net5g_fp32_mode.txt", "w") as f:
+    f.write("max|dprob| %.3e / %.3e, loss %.9f vs %.9f, worst grad-norm rel err %.3e\n"
+            % (np.abs(out - g["net5g_out"]).max(), np.abs(out_tf - g["net5g_out_tf"]).max(),
+               float(tot.detach()), lref, worst))

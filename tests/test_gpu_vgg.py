@@ -166,3 +166,30 @@ def test_net6c_vs_reference_golden_and_twohead():
     tf = net2(x6.to(dev()), trunk_features=True)
   assert oa[0].shape == (24, 50) and ob[2].shape == (24, 10) and tf.shape == (24, 4608)
   assert torch.allclose(oa[1].sum(1), torch.ones(24, device=dev()), atol=1e-5)
+
+
+def test_net6c_fp32_mode_vs_reference_golden():
+  """Parity tier T2 for the VGG-style trunk: the whole ClusterNet6c train step on the exact-fp32
+  kernels (ops.fp32_mode()) against the reference's own fp32 golden -- outputs, loss, gradients."""
+  from iic_amd import archs, ops
+  from iic_amd.losses import IID_loss
+  from oracle import net_oracle
+  g = np.load(os.path.join(G, "nets.npz"))
+  cfg = types.SimpleNamespace(in_channels=1, input_sz=24, batchnorm_track=True, num_sub_heads=2, output_k=10)
+  params = net_oracle.make_net6c_params(1, 24, 10, 2, True, seed=4, randomize_bn=True, head_std=0.05)
+  net = archs.ClusterNet6c(cfg)
+  net.load_state_dict(params, strict=True)
+  net.to(dev()).train()
+  x6, x6t = net_oracle.make_paired_batch(24, 24, 3, seed=6)
+  with ops.fp32_mode():
+    xo, xt = net(x6.to(dev())), net(x6t.to(dev()))
+  tot = sum(IID_loss(xo[i], xt[i], lamb=1.0)[0] for i in range(2)) / 2
+  tot.backward()
+  torch.cuda.synchronize()
+  out = np.stack([o.detach().cpu().numpy() for o in xo])
+  assert np.abs(out - g["net6c_out"]).max() <= 2e-4, np.abs(out - g["net6c_out"]).max()
+  lref = float(g["net6c_loss"][0])
+  assert abs(float(tot.detach()) - lref) <= 5e-4 * abs(lref) + 1e-7, (float(tot.detach()), lref)
+  for n, p in net.named_parameters():
+    gn = g["net6c_grad/" + n][0]
+    assert abs(float(p.grad.double().norm()) - gn) <= 1e-2 * max(gn, 1e-6) + 1e-9, (n, float(p.grad.double().norm()), gn)
