@@ -351,6 +351,9 @@ def main():
   ap.add_argument("--no-branch", action="store_true",
                   help="run the two views one after the other on one stream instead of as two "
                        "concurrent branches of the step graph (iic_amd.ops.branch)")
+  ap.add_argument("--eager-branch", action="store_true",
+                  help="(with --no-graph) eager launches, but the second view on a side stream "
+                       "(iic_amd.ops.branch): what the two-stream overlap gives without graphs")
   ap.add_argument("--no-reference-api", action="store_true",
                   help="skip the second measurement through the reference's own call sequence "
                        "(net(x) -> list, IID_loss per sub-head, torch.optim.Adam; reported in config)")
@@ -408,8 +411,13 @@ def main():
   imgs, imgs_tf = make_batch(args.pairs, INPUT_SZ, dev, seed=rank)
   params = list(net.parameters())
   # N > 1: gradient all-reduce overlapped with backward (IIC_DIST_OVERLAP=0: after backward)
+  # N > 1 (eager launches): by default the two views run on two streams (measured at N = 1:
+  # 42.0 -> 38.0 ms without graphs); the side view's gradients are folded into .grad after backward
+  # and ONE bucketed SUM all-reduce follows.  IIC_DIST_OVERLAP=1 selects the round-1 mode instead:
+  # one stream, gradient all-reduce overlapped with backward through post-accumulate hooks.
   reducer = None
-  if world > 1 and os.environ.get("IIC_DIST_OVERLAP", "1") != "0":
+  two_stream = args.eager_branch or (world > 1 and os.environ.get("IIC_DIST_OVERLAP", "0") != "1")
+  if world > 1 and not two_stream:
     reducer = idist.GradReducer(params)
 
   aug = None
@@ -439,13 +447,20 @@ def main():
     net.zero_grad(set_to_none=True)
     ops.clear_branch_grads()
     bi, bt = next_batch() if aug is not None else (imgs, imgs_tf)
-    xo = net.forward_packed(sobel_process(bi, False))
-    xt = net.forward_packed(sobel_process(bt, False))
+    if two_stream:
+      with ops.branch():
+        xt = net.forward_packed(sobel_process(bt, False))
+      xo = net.forward_packed(sobel_process(bi, False))
+      ops.join()
+    else:
+      xo = net.forward_packed(sobel_process(bi, False))
+      xt = net.forward_packed(sobel_process(bt, False))
     loss = loss_fn(xo, xt)
     loss.backward()
     if reducer is not None:
       reducer.finish()
-    else:
+    elif world > 1:
+      ops.fold_branch_grads(params)          # .grad += the side view's gradients (one foreach add)
       idist.all_reduce_grads(params)
     opt.step()
     return loss
@@ -514,6 +529,7 @@ def main():
                              "stem+heads+loss, fused HIP Adam" % args.pairs,
                  "global_batch_pairs": args.pairs * world, "input": "96x96x1 grey -> sobel 2ch",
                  "parallelism": "dp%d" % world, "final_loss": loss_val,
+                 "streams": 2 if (use_branch or two_stream) else 1,
                  "launch": ("hip-graph replay: 6 linear graphs, the two views on two streams" if use_branch
                             else "hip-graph replay") if use_graph else "eager (python/ctypes)",
                  "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps,

@@ -65,6 +65,22 @@ def branch_grads(p):
   return [q.grad for q in ent[1].values() if q.grad is not None]
 
 
+def fold_branch_grads(params):
+  """p.grad += the gradients the side branches accumulated for p (and drop those): for callers that
+  need ONE gradient per parameter before the optimiser -- e.g. a gradient all-reduce."""
+  tgt, src = [], []
+  for p in params:
+    for g in branch_grads(p):
+      if p.grad is None:
+        p.grad = g.clone()
+      else:
+        tgt.append(p.grad)
+        src.append(g)
+  if tgt:
+    torch._foreach_add_(tgt, src)
+  clear_branch_grads()
+
+
 def clear_branch_grads():
   for _, d in _PROXIES.values():
     for q in d.values():

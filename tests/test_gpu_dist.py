@@ -1,0 +1,42 @@
+"""The N > 1 bench path end to end on ONE GPU: two ranks (gloo) share cuda:0.  Functional, not a
+performance number: the sharded raw-joint all-reduce, the gradient all-reduce and the optimiser on
+real device tensors, in both launch modes -- two streams with the side view's gradients folded before
+ONE all-reduce (default) and one stream with the all-reduce overlapped with backward
+(IIC_DIST_OVERLAP=1).  Training is deterministic, so both must print the same final loss."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+  s = socket.socket()
+  s.bind(("127.0.0.1", 0))
+  p = s.getsockname()[1]
+  s.close()
+  return p
+
+
+def _run(overlap):
+  env = dict(os.environ, IIC_DIST_BACKEND="gloo", IIC_DIST_OVERLAP="1" if overlap else "0", PYTHONPATH=ROOT)
+  r = subprocess.run([sys.executable, "-W", "ignore", "-m", "torch.distributed.run", "--nnodes=1",
+                      "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                      os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--pairs", "66",
+                      "--no-roofline"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+  lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+  assert r.returncode == 0 and lines, r.stdout[-2000:] + r.stderr[-2000:]
+  return json.loads(lines[-1])
+
+
+def test_two_rank_bench_modes_agree():
+  a, b = _run(False), _run(True)
+  assert a["n_gpus"] == 2 and a["config"]["streams"] == 2 and b["config"]["streams"] == 1
+  assert a["config"]["global_batch_pairs"] == 132
+  la, lb = a["config"]["final_loss"], b["config"]["final_loss"]
+  assert la == la and la == lb, (la, lb)
