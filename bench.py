@@ -183,18 +183,20 @@ def cpu_baseline_mnist(batch=700, budget_s=40.0):
                     % (imgs.size(0), len(times) - 1)}
 
 
-def reference_api_rate(cfg, dev, imgs, imgs_tf, pairs, steps):
+def reference_api_rate(cfg, dev, imgs, imgs_tf, pairs, steps, auto_branch=False):
   """The same step through the reference's OWN call sequence (cluster_sobel.py:235-272 as the
   unchanged script issues it): net(x) -> python list of sub-head tensors, IID_loss once per
   sub-head, `+=` / `/=` averaging, stock torch.optim.Adam, `.item()` reads of the loss
   (cluster_sobel.py:255-266), eager launches.  Reported next to the headline number so that the
   cost of the drop-in boundary is visible (VERDICT r1 weak #8)."""
-  from iic_amd import archs
+  from iic_amd import archs, ops
   from iic_amd.losses import IID_loss
   from iic_amd.transforms import sobel_process
   torch.manual_seed(0)
   net = archs.ClusterNet5g(cfg).to(dev).train()
   opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+  prev_auto = ops.AUTO_BRANCH[0]
+  ops.AUTO_BRANCH[0] = bool(auto_branch)
 
   def step():
     net.zero_grad()
@@ -219,12 +221,15 @@ def reference_api_rate(cfg, dev, imgs, imgs_tf, pairs, steps):
   torch.cuda.synchronize()
   t0 = time.perf_counter()
   for _ in range(steps):
-    step()
+    v = step()
   torch.cuda.synchronize()
   dt = (time.perf_counter() - t0) / steps
-  return {"paired_images_per_sec": pairs / dt, "ms_per_step": 1e3 * dt,
+  ops.AUTO_BRANCH[0] = prev_auto
+  return {"paired_images_per_sec": pairs / dt, "ms_per_step": 1e3 * dt, "final_loss": v,
           "what": "list-returning net(x), IID_loss per sub-head, torch.optim.Adam, loss .item() "
-                  "every step, eager launches -- the unchanged script's call sequence"}
+                  "every step, eager launches -- the unchanged script's call sequence"
+                  + (", its two forwards on two streams (what `python -m iic_amd.run` does: "
+                     "iic_amd.ops.auto_branch)" if auto_branch else ", one stream")}
 
 
 SEG_CONFIGS = {
@@ -448,9 +453,9 @@ def main():
     ops.clear_branch_grads()
     bi, bt = next_batch() if aug is not None else (imgs, imgs_tf)
     if two_stream:
-      with ops.branch():
-        xt = net.forward_packed(sobel_process(bt, False))
-      xo = net.forward_packed(sobel_process(bi, False))
+      with ops.branch():          # the view that comes first goes to the side stream
+        xo = net.forward_packed(sobel_process(bi, False))
+      xt = net.forward_packed(sobel_process(bt, False))
       ops.join()
     else:
       xo = net.forward_packed(sobel_process(bi, False))
@@ -509,6 +514,7 @@ def main():
   ref_api = None
   if world == 1 and not args.no_reference_api:
     ref_api = reference_api_rate(cfg, dev, imgs, imgs_tf, args.pairs, args.steps)
+    ref_api["two_streams"] = reference_api_rate(cfg, dev, imgs, imgs_tf, args.pairs, args.steps, auto_branch=True)
   loss_val = float(last.detach())
   if world > 1:
     t = torch.tensor([dt], device=dev, dtype=torch.float64)

@@ -673,6 +673,7 @@ class ClusterNet5g(nn.Module):
     """All sub-head outputs as one [N, H, k] tensor (feeds IID_loss_heads; 3 loss launches)."""
     return self.head.forward_packed(self.trunk(x))
 
+  @ops.auto_branch
   def forward(self, x, kmeans_use_features=False, trunk_features=False, penultimate_features=False):
     x = self.trunk(x, penultimate_features=penultimate_features)
     if trunk_features:
@@ -698,6 +699,7 @@ class ClusterNet5gTwoHead(nn.Module):
   def forward_packed(self, x, head="B"):
     return (self.head_A if head == "A" else self.head_B).forward_packed(self.trunk(x))
 
+  @ops.auto_branch
   def forward(self, x, head="B", kmeans_use_features=False, trunk_features=False,
               penultimate_features=False):
     x = self.trunk(x, penultimate_features=penultimate_features)

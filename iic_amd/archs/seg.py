@@ -113,6 +113,7 @@ class SegmentationNet10a(nn.Module):
     self.head = SegmentationNet10aHead(config, output_k=config.output_k, cfg=SegmentationNet10a.cfg)
     _initialize_weights_vgg(self)
 
+  @ops.auto_branch
   def forward(self, x):
     return self.head(self.trunk(x))
 
@@ -129,6 +130,7 @@ class SegmentationNet10aTwoHead(nn.Module):
     self.head_B = SegmentationNet10aHead(config, output_k=config.output_k_B, cfg=SegmentationNet10a.cfg)
     _initialize_weights_vgg(self)
 
+  @ops.auto_branch
   def forward(self, x, head="B"):
     x = self.trunk(x)
     if head == "A":

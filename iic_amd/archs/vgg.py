@@ -262,6 +262,7 @@ class ClusterNet6c(nn.Module):
   def forward_packed(self, x):
     return self.head.forward_packed(self.trunk(x))
 
+  @ops.auto_branch
   def forward(self, x, kmeans_use_features=False, trunk_features=False, penultimate_features=False):
     if penultimate_features:
       raise NotImplementedError("Not needed/implemented for this arch (net6c.py:78-80)")
@@ -294,6 +295,7 @@ class ClusterNet6cTwoHead(nn.Module):
   def forward_packed(self, x, head="B"):
     return (self.head_A if head == "A" else self.head_B).forward_packed(self.trunk(x))
 
+  @ops.auto_branch
   def forward(self, x, head="B", kmeans_use_features=False, trunk_features=False,
               penultimate_features=False):
     if penultimate_features:

@@ -25,14 +25,15 @@ F32 = torch.float32
 # autograd Functions remember their branch (ctx.branch) and restore it in backward, where the
 # engine already runs them on the stream they were recorded on.
 #   with ops.branch():            # fork: side stream waits for the current one
-#     xt = net(all_imgs_tf)       # enqueued on the side stream
-#   xo = net(all_imgs)            # main stream, concurrently
+#     xo = net(all_imgs)          # the view that comes FIRST is enqueued on the side stream
+#   xt = net(all_imgs_tf)         # main stream, concurrently
 #   ops.join()                    # the current stream waits for the side stream (the losses and
 #                                 # the optimiser call it themselves if it is still pending)
 # Inside a branch: parameters are seen through per-branch leaf aliases (`pv`), so that gradient
 # accumulation of shared parameters never synchronises the branches (the optimiser adds the two
-# gradient sets, iic_amd.optim.Adam); BatchNorm running statistics are updated at the join in
-# the order a sequential run would have used (bn_finalize -> _DEFERRED_RUNNING).
+# gradient sets, iic_amd.optim.Adam); while a branch is pending, BatchNorm running-statistic
+# updates of BOTH views are postponed to the join and applied there in call order -- the order a
+# sequential run would have used (bn_finalize -> _DEFERRED_RUNNING).
 # ------------------------------------------------------------------------------------
 BRANCH = [0]
 _BRANCH_STREAM = {}
@@ -41,10 +42,19 @@ _DEFERRED_RUNNING = []    # (coef, running_mean, running_var, num_batches_tracke
 _PENDING_JOIN = []        # (main stream, side stream) of branches not joined yet
 
 
+# IIC_BRANCH_PROXIES=0: side branches use the parameters themselves.  Autograd then accumulates
+# both views' gradients into p.grad (correct with ANY optimiser, e.g. stock torch.optim.Adam) at
+# the price of cross-stream synchronisation in the backward pass.
+USE_PROXIES = [os.environ.get("IIC_BRANCH_PROXIES", "1") != "0"]
+
+
+_NO_PROXY_BRANCHES = set()
+
+
 def pv(p):
   """Parameter as seen by the current branch (the parameter itself on the main branch)."""
   b = BRANCH[0]
-  if b == 0 or p is None or not p.requires_grad:
+  if b == 0 or p is None or not p.requires_grad or not USE_PROXIES[0] or b in _NO_PROXY_BRANCHES:
     return p
   ent = _PROXIES.get(id(p))
   if ent is None or ent[0] is not p:
@@ -90,12 +100,14 @@ def clear_branch_grads():
 class branch(object):
   """Fork the enclosed forward onto a side stream / graph branch (see above).  Not re-entrant."""
 
-  def __init__(self, index=1):
+  def __init__(self, index=1, proxies=True):
     assert index >= 1
     self.index = index
+    self.proxies = proxies
 
   def __enter__(self):
     assert BRANCH[0] == 0, "branches do not nest"
+    (_NO_PROXY_BRANCHES.discard if self.proxies else _NO_PROXY_BRANCHES.add)(self.index)
     dev = torch.cuda.current_device()
     key = (dev, self.index)
     st = _BRANCH_STREAM.get(key)
@@ -139,6 +151,31 @@ class on_branch(object):
     BRANCH[0] = 0
     self.ctx.__exit__(*exc)
     return False
+
+
+# Automatic two-stream execution for UNCHANGED training scripts (IIC_AUTO_BRANCH=1; `python -m
+# iic_amd.run` switches it on).  The reference's step calls net(all_imgs) and net(all_imgs_tf) one
+# after the other (cluster_sobel.py:238-239, segmentation_twohead.py:300-306) and hands both
+# results to the loss: the first training forward since the last join is put on the side stream,
+# the second runs on the caller's stream meanwhile, and the loss (ours) joins.  No parameter
+# aliases here -- autograd accumulates both views into p.grad, so any optimiser works.  Contract:
+# the outputs of the first forward must not be consumed by anything but this library's losses
+# before the join (true of every reference script); evaluation / no_grad forwards never branch.
+AUTO_BRANCH = [os.environ.get("IIC_AUTO_BRANCH", "0") == "1"]
+
+
+def auto_branch(fwd):
+  """Decorator for the architectures' forward()."""
+  def wrapped(self, x, *a, **k):
+    if (AUTO_BRANCH[0] and self.training and torch.is_grad_enabled() and BRANCH[0] == 0
+        and not _PENDING_JOIN and torch.is_tensor(x) and x.is_cuda):
+      with branch(proxies=False) as br:
+        x.record_stream(br.side)         # allocated on the caller's stream, consumed on the side stream
+        return fwd(self, x, *a, **k)
+    return fwd(self, x, *a, **k)
+  wrapped.__name__ = getattr(fwd, "__name__", "forward")
+  wrapped.__doc__ = fwd.__doc__
+  return wrapped
 
 
 def join():
@@ -451,9 +488,10 @@ BN_REPLICAS = [1]
 def bn_finalize(stats, gamma, beta, running_mean, running_var, nbt, C, count, training):
   """coef [5][C]: scale, shift, mean, invstd, unbiased batch variance."""
   coef = torch.empty((5, C), dtype=F32, device=gamma.device)
-  if training and BRANCH[0] != 0 and running_mean is not None:
-    # side branch: the main branch updates the same running statistics concurrently -- postpone
-    # this view's update to the join (same order as a sequential run: main view first)
+  if training and running_mean is not None and (BRANCH[0] != 0 or _PENDING_JOIN):
+    # a side branch is (or may still be) running: both views update the same running statistics,
+    # so every update is postponed to the join and applied there in CALL order -- the order a
+    # sequential run would have used (fork the view that comes first in the script)
     _DEFERRED_RUNNING.append((coef, running_mean, running_var, nbt, C))
     running_mean = running_var = nbt = None
   check(lib().iic_bn_finalize(ptr(stats), ptr(gamma), ptr(beta), ptr(running_mean),

@@ -8,6 +8,10 @@ reference training script (Python-2 source, read where it lies) on the HIP hot p
   3. N > 1 (launched under torchrun, one process per GPU): `setup_distributed()`;
   4. execute the script module as __main__.
 
+The scripts' two training forwards per step run on two HIP streams (iic_amd.ops.auto_branch:
+net(all_imgs) on a side stream while net(all_imgs_tf) is enqueued; the loss joins) unless
+IIC_AUTO_BRANCH=0.
+
 Multi-GPU semantics for the unchanged scripts: every rank's loaders produce
 the full batch; each architecture's TRAINING forward keeps this rank's contiguous rows (pairs
 stay together: both views are sliced identically), evaluation forwards run the whole batch on
@@ -85,9 +89,12 @@ def main(argv=None):
   argv = list(sys.argv[1:] if argv is None else argv)
   if not argv:
     sys.exit("usage: python -m iic_amd.run <reference.script.module> [script args...]")
-  from . import py2compat
+  from . import ops, py2compat
   from .install import install
   install(strict=True)
+  # the two forwards of the scripts' train step on two streams (iic_amd.ops.auto_branch);
+  # IIC_AUTO_BRANCH=0 keeps everything on one stream
+  ops.AUTO_BRANCH[0] = os.environ.get("IIC_AUTO_BRANCH", "1") != "0"
   if int(os.environ.get("WORLD_SIZE", "1")) > 1:
     import torch
     import torch.distributed as dist

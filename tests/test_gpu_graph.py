@@ -33,9 +33,9 @@ def _make_step(net, opt, imgs, imgs_tf, branch):
   def step():
     net.zero_grad(set_to_none=True)
     if branch:
-      with ops.branch():
-        xt = net.forward_packed(sobel_process(imgs_tf, False))
-      xo = net.forward_packed(sobel_process(imgs, False))
+      with ops.branch():          # the first view on the side stream
+        xo = net.forward_packed(sobel_process(imgs, False))
+      xt = net.forward_packed(sobel_process(imgs_tf, False))
       ops.join()
     else:
       xo = net.forward_packed(sobel_process(imgs, False))
@@ -176,3 +176,46 @@ def test_training_is_bit_reproducible_run_to_run():
     else:
       assert losses == ref[0], (losses, ref[0])
       assert torch.equal(flat, ref[1])
+
+
+def test_auto_branch_reference_call_sequence_is_bit_identical():
+  """iic_amd.ops.auto_branch (what `python -m iic_amd.run` switches on): the unchanged scripts' call
+  sequence -- net(x), net(x_tf), IID_loss per sub-head, stock torch.optim.Adam -- with the first
+  forward on a side stream, against the same sequence on one stream: identical bits."""
+  from iic_amd import ops
+  from iic_amd.losses import IID_loss
+  from iic_amd.transforms import sobel_process
+  imgs, imgs_tf = _batch()
+  res = []
+  for auto in (False, True):
+    net = _net()
+    opt = torch.optim.Adam(net.parameters(), lr=2e-4)
+    ops.AUTO_BRANCH[0] = auto
+    try:
+      losses = []
+      for _ in range(4):
+        net.zero_grad()
+        xo = net(sobel_process(imgs, False))
+        assert (len(ops._PENDING_JOIN) == 1) == auto
+        xt = net(sobel_process(imgs_tf, False))
+        tot = None
+        for i in range(2):
+          l, _ = IID_loss(xo[i], xt[i], lamb=1.0)
+          tot = l if tot is None else tot + l
+        assert not ops._PENDING_JOIN          # the loss joined
+        tot /= 2
+        losses.append(tot.item())
+        tot.backward()
+        opt.step()
+      net.eval()
+      with torch.no_grad():
+        ev = net(sobel_process(imgs, False))[0].clone()     # evaluation never branches
+      assert not ops._PENDING_JOIN
+    finally:
+      ops.AUTO_BRANCH[0] = False
+    torch.cuda.synchronize()
+    res.append((losses, ev, [p.detach().clone() for p in net.parameters()],
+                net.trunk.bn1.running_mean.clone(), int(net.trunk.bn1.num_batches_tracked)))
+  assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+  assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][3], res[1][3]) and res[0][4] == res[1][4] == 8
+  assert all(torch.equal(a, b) for a, b in zip(res[0][2], res[1][2]))
