@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     var = running_var[c];
   }
   const float invstd = rsqrtf(var + eps);
-  // one Newton step: rsqrtf is ~1 ulp on gfx950, keep it exact enough for fp32 parity
+  // (rsqrtf is ~1 ulp on gfx950: no refinement step; the parity tests hold it against 1/sqrt in fp64)
   const float sc = gamma[c] * invstd;
   coef[c] = sc;
   coef[C + c] = beta[c] - mean * sc;

@@ -172,6 +172,12 @@ def auto_branch(fwd):
       with branch(proxies=False) as br:
         x.record_stream(br.side)         # allocated on the caller's stream, consumed on the side stream
         return fwd(self, x, *a, **k)
+    if not torch.is_grad_enabled():
+      mark = POOL.mark()                 # evaluation: nothing will release the activations later
+      try:
+        return fwd(self, x, *a, **k)
+      finally:
+        POOL.sweep(mark)
     return fwd(self, x, *a, **k)
   wrapped.__name__ = getattr(fwd, "__name__", "forward")
   wrapped.__doc__ = fwd.__doc__
@@ -205,6 +211,11 @@ def flush_deferred_running():
 def branch_backward(fn):
   """Decorator for autograd Function.backward: run under the branch the forward recorded."""
   def wrapped(ctx, *grads):
+    if getattr(ctx, "_iic_ran", False):
+      raise RuntimeError("iic_amd: backward through this graph a second time -- the saved activation "
+                         "buffers went back to the pool after the first pass (retain_graph is not "
+                         "supported on the HIP path)")
+    ctx._iic_ran = True
     prev, prev_dt = BRANCH[0], PT_DTYPE[0]
     BRANCH[0] = getattr(ctx, "branch", 0)
     PT_DTYPE[0] = getattr(ctx, "pt_dtype", prev_dt)     # (fp32_mode() forwards allocate fp32 in backward too)
@@ -241,13 +252,20 @@ class fp32_mode(object):
 
 
 class PTPool(object):
-  """Buffers are keyed by (shape, border P, device, branch): a recycled buffer is only valid for
-  a tensor with the SAME interior/border split (its border must still be zero), and only on the
-  stream (branch) whose kernels used it last."""
+  """Buffers are keyed by (shape, border P, device, branch, dtype): a recycled buffer is only valid
+  for a tensor with the SAME interior/border split (its border must still be zero), and only on
+  the stream (branch) whose kernels used it last.
+
+  The pool keeps a reference to every buffer it created (`owned`), so an address can never come
+  back from the caching allocator as some other tensor and be mistaken for a zero-border buffer;
+  `release` only accepts buffers that are currently handed out (a second release -- e.g. a
+  backward run twice -- is ignored instead of putting one buffer on the free list twice)."""
 
   def __init__(self):
     self.free = {}
-    self.border = {}          # data_ptr -> (P, branch) of every buffer this pool created
+    self.owned = {}           # data_ptr -> (tensor, P, branch) of every buffer this pool created
+    self.live = {}            # data_ptr -> serial of the alloc() that handed it out
+    self.serial = 0
     self.allocated_bytes = 0
 
   def alloc(self, shape, device, P=1):
@@ -255,24 +273,39 @@ class PTPool(object):
     key = (tuple(shape), int(P), str(device), BRANCH[0], dt)
     lst = self.free.get(key)
     if lst:
-      return lst.pop()
-    t = torch.zeros(shape, dtype=dt, device=device)
-    self.border[t.data_ptr()] = (int(P), BRANCH[0])
-    self.allocated_bytes += t.numel() * t.element_size()
+      t = lst.pop()
+    else:
+      t = torch.zeros(shape, dtype=dt, device=device)
+      self.owned[t.data_ptr()] = (t, int(P), BRANCH[0])
+      self.allocated_bytes += t.numel() * t.element_size()
+    self.serial += 1
+    self.live[t.data_ptr()] = self.serial
     return t
 
   def release(self, t):
     if t is None:
       return
-    ent = self.border.get(t.data_ptr())
-    if ent is None:
-      return                  # not one of ours (e.g. a user tensor): never recycle it
-    key = (tuple(t.shape), ent[0], str(t.device), ent[1], t.dtype)
-    self.free.setdefault(key, []).append(t)
+    ent = self.owned.get(t.data_ptr())
+    if ent is None or ent[0].shape != t.shape:
+      return                  # not one of ours (a user tensor, a view): never recycle it
+    if self.live.pop(t.data_ptr(), None) is None:
+      return                  # already back in the pool
+    key = (tuple(t.shape), ent[1], str(t.device), ent[2], t.dtype)
+    self.free.setdefault(key, []).append(ent[0])
+
+  def mark(self):
+    return self.serial
+
+  def sweep(self, mark):
+    """Return every buffer handed out since `mark` that is still out: the end of a forward that
+    no backward will follow (torch.no_grad evaluation), whose consumers are all enqueued."""
+    for dp in [dp for dp, ser in self.live.items() if ser > mark]:
+      self.release(self.owned[dp][0])
 
   def clear(self):
     self.free.clear()
-    self.border.clear()
+    self.owned.clear()
+    self.live.clear()
 
 
 POOL = PTPool()
