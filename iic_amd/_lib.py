@@ -140,6 +140,13 @@ def lib():
         raise IICLibraryError("libiic_hip.so lacks symbol %s" % name) from e
       fn.restype = res
       fn.argtypes = args
+    # A/B switches for measurements, e.g. IIC_DEBUG="iic_debug_bd_ms=2,iic_debug_p64_red=1": calls the
+    # named iic_debug_* setters (int argument) of the library once at load.  Unset = defaults.
+    for item in filter(None, os.environ.get("IIC_DEBUG", "").split(",")):
+      name, _, val = item.partition("=")
+      if not name.startswith("iic_debug_"):
+        raise IICLibraryError("IIC_DEBUG: %r is not an iic_debug_* switch" % name)
+      getattr(h, name)(int(val or 1))
     _lib = h
   return _lib
 

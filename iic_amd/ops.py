@@ -280,7 +280,9 @@ class PTPool(object):
       self.allocated_bytes += t.numel() * t.element_size()
     self.serial += 1
     self.live[t.data_ptr()] = self.serial
-    return t
+    # a fresh tensor object per hand-out: the caller's autograd state (grad_fn of the Function that
+    # returns it, user hooks registered on it) must not survive into the buffer's next life
+    return t.detach()
 
   def release(self, t):
     if t is None:

@@ -86,3 +86,19 @@ def test_second_backward_raises():
   y.backward(retain_graph=True)
   with pytest.raises(RuntimeError, match="second time"):
     y.backward()
+
+
+def test_recycled_buffer_is_a_fresh_tensor_object():
+  """Autograd state of a buffer's previous life (grad_fn, user hooks) must not leak into the next:
+  Tensor.register_hook binds its hook dict to the grad_fn only the first time it is called on an
+  object, so a recycled OBJECT would silently lose hooks registered in a later step."""
+  pool = ops.PTPool()
+  a = pool.alloc((1, 4, 4, 8), "cpu", 1)
+  fired = []
+  (a.float().requires_grad_(True) * 1.0).register_hook(lambda g: fired.append(1))
+  a.requires_grad_(True)
+  a.register_hook(lambda g: fired.append(2))
+  pool.release(a)
+  b = pool.alloc((1, 4, 4, 8), "cpu", 1)
+  assert b.data_ptr() == a.data_ptr() and b is not a
+  assert not b.requires_grad and b._backward_hooks is None and b.grad_fn is None
