@@ -44,7 +44,8 @@ _SIGNATURES = {
   "iic_seg_joint_nsplit": (c_int, [c_int, c_int, c_int, c_int]),
   "iic_seg_joint_raw": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
   "iic_seg_loss_from_joint": (c_int, [_P, c_int, c_int, c_int, c_double, c_double, _P, _P, _P, _P, _P, c_int, _P]),
-  "iic_seg_grad": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+  "iic_seg_grad_workspace_bytes": (c_long, [c_int, c_int]),
+  "iic_seg_grad": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
   "iic_affine_warp_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
   "iic_affine_warp_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
   "iic_conv_lds_bytes": (c_long, [POINTER(ConvGeom), c_int]),

@@ -231,9 +231,353 @@ __global__ __launch_bounds__(256) void seg_grad_kernel(
   }
 }
 
+
+// ====================================================================================
+// Streaming versions of the two kernels above (the default path whenever w % 4 == 0, k <= 32 and
+// the tensors are 16-byte aligned).  Same tiles, same MFMA order -- identical results -- but the
+// row staging no longer serialises on memory latency: the generic kernels fetch one 4-byte element
+// per loop trip (a runtime division, a mask load and a source load each), i.e. ~50 dependent
+// round trips to L2/HBM per staged row while the matrix core waits (measured: 20 % of the fp32
+// MFMA rate at k = 24, T = 10).  Here a thread owns a fixed set of float4 units of the row
+// (lane -> 4 pixels, thread row -> channels cr, cr + CR, ...), issues ALL loads of the NEXT row /
+// G slice right after publishing the current one to LDS, and only waits for them after the MFMA
+// loop: one round trip per row, hidden under the arithmetic.
+// ====================================================================================
+__device__ __forceinline__ float4 seg_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 seg_rev4(float4 v) { return make_float4(v.w, v.z, v.y, v.x); }
+
+template <int TK, int QG, int LW>
+__global__ __launch_bounds__(256) void seg_joint_stream_kernel(
+    const float* __restrict__ x1, const float* __restrict__ x2, const float* __restrict__ mask,
+    const int* __restrict__ flips, float* __restrict__ part, int bn, int k, int h, int w, int T) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int CR = 256 / LW, NJ = (16 * TK + CR - 1) / CR;
+  const int nq = 2 * T + 1;
+  const int w4 = w;                                        // w % 4 == 0 here
+  const int P1 = (w4 + 2 * T) | 1, P2 = w4 | 1;
+  float* sX1 = reinterpret_cast<float*>(smem_raw);          // [16*TK][P1]
+  float* sX2 = sX1 + 16 * TK * P1;                          // [16*TK][P2]
+  const int p = blockIdx.x, q0 = blockIdx.y * QG, split = blockIdx.z, S = gridDim.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, kk = lane >> 4;
+  const int xl = tid % LW, cr = tid / LW, wq = w >> 2;
+  const bool xact = xl < wq;
+  const long rows = (long)bn * h;
+  const long per = (rows + S - 1) / S;
+  const long r0 = split * per, r1 = min(rows, r0 + per);
+
+  f32x4 acc[QG][TK][TK];
+#pragma unroll
+  for (int a = 0; a < QG; ++a)
+#pragma unroll
+    for (int ti = 0; ti < TK; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < TK; ++tj) acc[a][ti][tj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // halo columns and padding channels stay zero for the whole kernel: only interiors are rewritten
+  for (int idx = tid; idx < 16 * TK * (P1 + P2); idx += 256) sX1[idx] = 0.f;
+
+  float4 pre1[NJ], pre2[NJ], m1, m2;
+  auto next_valid = [&](long r) {
+    while (r < r1) {
+      const int y1 = (int)(r % h) + p - T;
+      if (y1 >= 0 && y1 < h) break;                  // else the shifted row is all padding
+      ++r;
+    }
+    return r;
+  };
+  auto issue = [&](long r) {
+    const int n = (int)(r / h), y = (int)(r - (long)n * h), y1 = y + p - T;
+    const int fx = flips[2 * n], fy = flips[2 * n + 1];
+    const int sy = fy ? h - 1 - y : y, sx = fx ? wq - 1 - xl : xl;
+    if (xact) {
+      m2 = seg_ld4(mask + ((long)n * h + y) * w + 4 * xl);
+      m1 = seg_ld4(mask + ((long)n * h + y1) * w + 4 * xl);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int ch = cr + CR * j;
+        if (ch < k) {
+          const float4 v = seg_ld4(x2 + (((long)n * k + ch) * h + sy) * w + 4 * sx);
+          pre2[j] = fx ? seg_rev4(v) : v;
+          pre1[j] = seg_ld4(x1 + (((long)n * k + ch) * h + y1) * w + 4 * xl);
+        }
+      }
+    }
+  };
+
+  long r = next_valid(r0);
+  if (r < r1) issue(r);
+  while (r < r1) {
+    __syncthreads();                                 // everyone is done reading the previous row
+    if (xact) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int ch = cr + CR * j;
+        if (ch < k) {
+          float* d2 = sX2 + ch * P2 + 4 * xl;
+          d2[0] = pre2[j].x * m2.x; d2[1] = pre2[j].y * m2.y; d2[2] = pre2[j].z * m2.z; d2[3] = pre2[j].w * m2.w;
+          float* d1 = sX1 + ch * P1 + T + 4 * xl;
+          d1[0] = pre1[j].x * m1.x; d1[1] = pre1[j].y * m1.y; d1[2] = pre1[j].z * m1.z; d1[3] = pre1[j].w * m1.w;
+        }
+      }
+    }
+    __syncthreads();
+    const long rn = next_valid(r + 1);
+    if (rn < r1) issue(rn);                          // in flight during the MFMA loop below
+    for (int st = wave; st < w4 / 4; st += 4) {
+      const int x0 = 4 * st + kk;
+      float b[TK];
+#pragma unroll
+      for (int tj = 0; tj < TK; ++tj) b[tj] = sX2[(tj * 16 + c) * P2 + x0];
+#pragma unroll
+      for (int a = 0; a < QG; ++a) {
+        const int q = q0 + a;
+        if (q < nq) {
+#pragma unroll
+          for (int ti = 0; ti < TK; ++ti) {
+            const float av = sX1[(ti * 16 + c) * P1 + x0 + q];
+#pragma unroll
+            for (int tj = 0; tj < TK; ++tj) acc[a][ti][tj] = mfma16(av, b[tj], acc[a][ti][tj]);
+          }
+        }
+      }
+    }
+    r = rn;
+  }
+  float* red = reinterpret_cast<float*>(smem_raw);          // [4][TK*TK][256]
+  constexpr int TT = TK * TK;
+#pragma unroll
+  for (int a = 0; a < QG; ++a) {
+    const int q = q0 + a;
+    if (q >= nq) continue;
+    __syncthreads();
+#pragma unroll
+    for (int ti = 0; ti < TK; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < TK; ++tj)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+          red[(wave * TT + ti * TK + tj) * 256 + lane * 4 + rr] = acc[a][ti][tj][rr];
+    __syncthreads();
+    float* out = part + (((long)split * nq + p) * nq + q) * k * k;
+    for (int idx = tid; idx < TT * 256; idx += 256) {
+      const int t = idx >> 8, e = idx & 255, ln = e >> 2, rr = e & 3;
+      const int i = (t / TK) * 16 + (ln >> 4) * 4 + rr, j = (t % TK) * 16 + (ln & 15);
+      if (i < k && j < k)
+        out[(long)i * k + j] = red[(0 * TT + t) * 256 + e] + red[(1 * TT + t) * 256 + e] +
+                               red[(2 * TT + t) * 256 + e] + red[(3 * TT + t) * 256 + e];
+    }
+  }
+}
+
+// G of one launch, laid out as the gradient kernel's LDS image wants it:
+//   Gp[p][r = q*k4 + b][a (pitch 16*TK)] = gl*dR1[p,q][e] + gnl*dR2[p,q][e],  e = a*k+b (which 0) | b*k+a
+// k4 = roundup4(k); rows with b >= k and columns a >= k are zero.  grid = (nq, ceil(rowsP*PG/256)).
+__global__ __launch_bounds__(256) void seg_gprep_kernel(
+    const float* __restrict__ dR1, const float* __restrict__ dR2, const float* __restrict__ gl,
+    const float* __restrict__ gnl, float* __restrict__ Gp, int k, int nq, int PG, int rowsP,
+    int which, int shift_stride) {
+  const int p = blockIdx.x;
+  const int idx = blockIdx.y * 256 + threadIdx.x;
+  if (idx >= rowsP * PG) return;
+  const int k4 = (k + 3) & ~3;
+  const int r = idx / PG, a = idx - r * PG;
+  const int q = r / k4, b = r - q * k4;
+  float v = 0.f;
+  if (q < nq && b < k && a < k) {
+    const long hh = (long)(p * nq + q) * shift_stride;
+    const long e = which == 0 ? ((long)a * k + b) : ((long)b * k + a);
+    const float w1 = gl[hh], w2 = gnl ? gnl[hh] : 0.f;
+    v = w1 * dR1[hh * k * k + e] + w2 * dR2[hh * k * k + e];
+  }
+  Gp[((long)p * rowsP + r) * PG + a] = v;
+}
+
+#define SEG_NG 9     // float4 of G per thread per slice: a slice is at most 256*9*4 floats = 36 KB
+
+// The MFMA loop of one G slice for a wave that owns N units: one G fragment and N source
+// fragments per step, all reads issued before the N MFMAs (no per-unit branches in the loop).
+template <int TK, int N>
+__device__ __forceinline__ void seg_grad_ksteps(f32x4 (&acc)[4 * TK], const float* sS, const float* sG,
+                                                int gc, int PS, int k4, int qn, int xoff0, int sgn,
+                                                int kk, const int (&ubase)[4 * TK]) {
+  constexpr int PG = 16 * TK;
+  for (int ql = 0; ql < qn; ++ql) {
+    const int xoff = xoff0 + sgn * ql;                        // wave-uniform column offset
+    const float* sGq = sG + ql * k4 * PG;
+    for (int b0 = 0; b0 < k4; b0 += 4) {
+      const int b = b0 + kk;                                  // class row of this lane's k index
+      const int sw = TK == 2 ? ((b & 1) << 4) : 0;            // (k4 % 4 == 0: slice row parity = b parity)
+      const float* srow = sS + b * PS + xoff;
+      const float bv = sGq[b * PG + (gc ^ sw)];               // gc = the wave's class tile * 16 + c
+      float av[N];
+#pragma unroll
+      for (int u = 0; u < N; ++u) av[u] = srow[ubase[u]];
+#pragma unroll
+      for (int u = 0; u < N; ++u) acc[u] = mfma16(av[u], bv, acc[u]);
+    }
+  }
+}
+
+// K order of the streaming gradient kernel: (column shift q, class b padded to k4 = roundup4(k)),
+// so the four k-lanes of one MFMA step share q (the column offset is wave-uniform) and no lane
+// does index arithmetic inside the loop; the padded classes multiply zero rows of G and of the
+// source tile.  MFMA work is spread over the waves as (pixel tile, class tile) units, unit =
+// wave + 4u: 13 pixel tiles x 2 class tiles (w = 200, k = 24) split 7/7/6/6 instead of 8/6/6/6.
+template <int TK, int LW>
+__global__ __launch_bounds__(256) void seg_grad_stream_kernel(
+    const float* __restrict__ src, const float* __restrict__ mask, const int* __restrict__ flips,
+    const float* __restrict__ Gp, float* __restrict__ out, int bn, int k, int h, int w, int T,
+    int which, int src_is_x2, int QC, int rowsP) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int CR = 256 / LW, NJ = (16 * TK + CR - 1) / CR;
+  constexpr int PG = 16 * TK;
+  constexpr int NU = 4 * TK;                               // MFMA units per wave (w <= 256)
+  const int nq = 2 * T + 1;
+  const int k4 = (k + 3) & ~3;
+  const int w16 = (w + 15) & ~15;
+  const int PS = (w16 + 2 * T) | 1;
+  float* sS = reinterpret_cast<float*>(smem_raw);          // [k4][PS]     masked source row
+  float* sG = sS + (((long)k4 * PS + 3) & ~3L);            // [slice rows][PG], 16-byte aligned
+  const int n = blockIdx.x / h, y = blockIdx.x - n * h;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, kk = lane >> 4;
+  const int xl = tid % LW, cr = tid / LW, wq = w >> 2;
+  const bool xact = xl < wq;
+  const int sgn = which == 0 ? -1 : 1;
+  const int fx = src_is_x2 ? flips[2 * n] : 0, fy = src_is_x2 ? flips[2 * n + 1] : 0;
+  const int nunit = (w16 / 16) * TK;
+  const int nch = (nq + QC - 1) / QC;                      // G slices per row shift
+  const int nu = nunit > wave ? (nunit - wave + 3) / 4 : 0;   // units of this wave (uniform)
+  f32x4 acc[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int idx = tid; idx < k4 * PS; idx += 256) sS[idx] = 0.f;   // halo + padded classes stay zero
+
+  float4 pres[NJ], pm, preg[SEG_NG];
+  auto next_valid = [&](int p) {
+    while (p < nq) {
+      const int ys = y + sgn * (p - T);
+      if (ys >= 0 && ys < h) break;
+      ++p;
+    }
+    return p;
+  };
+  // item = (row shift p, slice ch_): loads the G slice, plus the source row when ch_ == 0
+  auto issue = [&](int p, int ch_) {
+    const float* g = Gp + ((long)p * rowsP + (long)ch_ * QC * k4) * PG;
+    const int nf4 = min(QC, nq - ch_ * QC) * k4 * (PG / 4);
+#pragma unroll
+    for (int j = 0; j < SEG_NG; ++j) {
+      const int f = tid + 256 * j;
+      if (f < nf4) preg[j] = seg_ld4(g + 4 * f);
+    }
+    if (ch_ == 0 && xact) {
+      const int ys = y + sgn * (p - T);
+      const int sy = fy ? h - 1 - ys : ys, sx = fx ? wq - 1 - xl : xl;
+      pm = seg_ld4(mask + ((long)n * h + ys) * w + 4 * xl);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int ch = cr + CR * j;
+        if (ch < k) {
+          const float4 v = seg_ld4(src + (((long)n * k + ch) * h + sy) * w + 4 * sx);
+          pres[j] = fx ? seg_rev4(v) : v;
+        }
+      }
+    }
+  };
+  // per-unit constants: pixel tile -> column base in the source row, class tile -> column in G
+  int ubase[NU], gcol[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int unit = wave + 4 * u;
+    const int tile = unit / TK, t = unit - tile * TK;
+    ubase[u] = tile * 16 + c;
+    gcol[u] = t * 16 + c;
+  }
+
+  int p = next_valid(0), ch_ = 0;
+  if (p < nq) issue(p, 0);
+  while (p < nq) {
+    __syncthreads();
+    {
+      const int nf4 = min(QC, nq - ch_ * QC) * k4 * (PG / 4);
+#pragma unroll
+      for (int j = 0; j < SEG_NG; ++j) {
+        const int f = tid + 256 * j;
+        if (f < nf4) {
+          const int rr = (4 * f) / PG, a = 4 * f - rr * PG;
+          // PG = 32: rows of one k-step group would hit the same banks -> odd rows swap halves
+          const int as = TK == 2 ? (a ^ ((rr & 1) << 4)) : a;
+          *reinterpret_cast<float4*>(sG + rr * PG + as) = preg[j];
+        }
+      }
+    }
+    if (ch_ == 0 && xact) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int ch = cr + CR * j;
+        if (ch < k) {
+          float* d = sS + ch * PS + T + 4 * xl;
+          d[0] = pres[j].x * pm.x; d[1] = pres[j].y * pm.y; d[2] = pres[j].z * pm.z; d[3] = pres[j].w * pm.w;
+        }
+      }
+    }
+    __syncthreads();
+    int pn = p, cn = ch_ + 1;
+    if (cn == nch) { cn = 0; pn = next_valid(p + 1); }
+    if (pn < nq) issue(pn, cn);
+    {
+      const int qc0 = ch_ * QC;
+      const int qn = min(QC, nq - qc0);
+      const int xoff0 = sgn * (qc0 - T) + T;
+      // (a wave's units all use the same class tile: unit = wave + 4u and TK divides 4)
+#define SEG_KS(N_) seg_grad_ksteps<TK, N_>(acc, sS, sG, gcol[0], PS, k4, qn, xoff0, sgn, kk, ubase)
+      switch (nu) {
+        case 1: SEG_KS(1); break;
+        case 2: SEG_KS(2); break;
+        case 3: SEG_KS(3); break;
+        case 4: SEG_KS(4); break;
+        case 5: if (TK == 2) SEG_KS(5); break;
+        case 6: if (TK == 2) SEG_KS(6); break;
+        case 7: if (TK == 2) SEG_KS(7); break;
+        case 8: if (TK == 2) SEG_KS(8); break;
+        default: break;
+      }
+#undef SEG_KS
+    }
+    p = pn; ch_ = cn;
+  }
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int unit = wave + 4 * u;
+    if (unit >= nunit) continue;
+    const int tile = unit / TK, t = unit - tile * TK;
+    const int a = t * 16 + c;
+    if (a >= k) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int x = tile * 16 + kk * 4 + r;
+      if (x < w) {
+        const float v = acc[u][r] * mask[((long)n * h + y) * w + x];
+        const int oy = (src_is_x2 == 0 && which == 1 && flips[2 * n + 1]) ? h - 1 - y : y;
+        const int ox = (src_is_x2 == 0 && which == 1 && flips[2 * n]) ? w - 1 - x : x;
+        out[(((long)n * k + a) * h + oy) * w + ox] = v;
+      }
+    }
+  }
+}
+
 extern "C" {
 
 static int seg_tk(int k) { return (k + 15) / 16; }
+// streaming kernels: float4 rows (w % 4 == 0, 16-byte aligned tensors), k <= 32.  A/B: iic_debug_seg_stream(0).
+static int g_seg_stream = 1;
+extern "C" void iic_debug_seg_stream(int v) { g_seg_stream = v; }
+static bool seg_stream_ok(int k, int w, const void* a, const void* b, const void* c) {
+  return g_seg_stream && (w & 3) == 0 && k <= 32 &&
+         ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c)) & 15) == 0;
+}
 static int seg_qg(int tk) { return tk == 1 ? 21 : (tk == 2 ? 7 : 3); }
 
 int iic_seg_joint_nsplit(int bn, int h, int k, int T) {
@@ -266,27 +610,74 @@ int iic_seg_joint_raw(const float* x1, const float* x2, const float* mask, const
     hipLaunchKernelGGL((seg_joint_kernel<TK_, QG_>), grid, dim3(256), lds, s, x1, x2, mask,     \
                        flips, partials, bn, k, h, w, T);                                        \
   } while (0)
-  if (tk == 1) SEGJ(1, 21);
+#define SEGJS(TK_, QG_, LW_)                                                                    \
+  do {                                                                                          \
+    if (lds > 48 * 1024)                                                                        \
+      (void)hipFuncSetAttribute(                                                                \
+          reinterpret_cast<const void*>(&seg_joint_stream_kernel<TK_, QG_, LW_>),               \
+          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
+    hipLaunchKernelGGL((seg_joint_stream_kernel<TK_, QG_, LW_>), grid, dim3(256), lds, s, x1,   \
+                       x2, mask, flips, partials, bn, k, h, w, T);                              \
+  } while (0)
+#define SEGJS_LW(TK_, QG_)                                                                      \
+  do {                                                                                          \
+    if (w > 128) SEGJS(TK_, QG_, 64); else if (w > 64) SEGJS(TK_, QG_, 32); else SEGJS(TK_, QG_, 16); \
+  } while (0)
+  if (seg_stream_ok(k, w, x1, x2, mask)) {
+    if (tk == 1) SEGJS_LW(1, 21); else SEGJS_LW(2, 7);
+  } else if (tk == 1) SEGJ(1, 21);
   else if (tk == 2) SEGJ(2, 7);
   else SEGJ(3, 3);
   return iic_launch_status();
 }
 
+long iic_seg_grad_workspace_bytes(int k, int T) {
+  if (k < 1 || k > 48 || T < 0 || T > 10) return 0;
+  const int nq = 2 * T + 1, tk = seg_tk(k);
+  return (long)nq * nq * ((k + 3) & ~3) * 16 * tk * (long)sizeof(float);
+}
+
 int iic_seg_grad(const float* src, const float* mask, const int* flips, const float* dR_loss,
                  const float* dR_loss_no_lamb, const float* g_loss, const float* g_loss_no_lamb,
                  float* out, int bn, int k, int h, int w, int T, int which, int collapsed,
-                 void* stream) {
+                 float* workspace, void* stream) {
   if (!src || !mask || !flips || !dR_loss || !dR_loss_no_lamb || !g_loss || !out) return IIC_ERR_ARG;
   if (k < 1 || k > 48 || T < 0 || T > 10 || w > SEG_MAXW || bn <= 0 || h < 1) return IIC_ERR_UNSUPPORTED;
   const int nq = 2 * T + 1, tk = seg_tk(k);
   const int w16 = (w + 15) & ~15;
+  const int src_is_x2 = which == 0 ? 1 : 0;   // d/dx1 reads x2m ; d/dx2 reads x1m
+  hipStream_t s = (hipStream_t)stream;
+  if (g_seg_stream && workspace && seg_stream_ok(k, w, src, mask, out) && ((uintptr_t)workspace & 15) == 0) {
+    // streaming path: G laid out once per launch (workspace), then one workgroup per output row
+    const int PG = 16 * tk, k4 = (k + 3) & ~3, rowsP = nq * k4;
+    int QC = (256 * SEG_NG * 4 / PG) / k4;    // column shifts per G slice: SEG_NG float4 per thread
+    if (QC < 1) return IIC_ERR_UNSUPPORTED;
+    if (QC > nq) QC = nq;
+    hipLaunchKernelGGL(seg_gprep_kernel, dim3(nq, (rowsP * PG + 255) / 256), dim3(256), 0, s,
+                       dR_loss, dR_loss_no_lamb, g_loss, g_loss_no_lamb, workspace, k, nq, PG, rowsP,
+                       which, collapsed ? 0 : 1);
+    const int PS = (w16 + 2 * T) | 1;
+    const size_t lds = ((((size_t)k4 * PS + 3) & ~(size_t)3) + (size_t)QC * k4 * PG) * sizeof(float);
+#define SEGGS(TK_, LW_)                                                                         \
+  do {                                                                                          \
+    if (lds > 48 * 1024)                                                                        \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seg_grad_stream_kernel<TK_, LW_>), \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
+    hipLaunchKernelGGL((seg_grad_stream_kernel<TK_, LW_>), dim3(bn * h), dim3(256), lds, s, src, \
+                       mask, flips, workspace, out, bn, k, h, w, T, which, src_is_x2, QC, rowsP); \
+  } while (0)
+#define SEGGS_LW(TK_)                                                                           \
+  do {                                                                                          \
+    if (w > 128) SEGGS(TK_, 64); else if (w > 64) SEGGS(TK_, 32); else SEGGS(TK_, 16);          \
+  } while (0)
+    if (tk == 1) SEGGS_LW(1); else SEGGS_LW(2);
+    return iic_launch_status();
+  }
   const int PS = (w16 + 2 * T) | 1, PG = 16 * tk + 1;
   int QC = (40 * 1024) / (k * PG * 4);        // G slice kept in LDS per chunk of column shifts
   if (QC < 1) QC = 1;
   if (QC > nq) QC = nq;
   const size_t lds = ((size_t)k * PS + (size_t)((QC * k + 3) & ~3) * PG) * sizeof(float);
-  const int src_is_x2 = which == 0 ? 1 : 0;   // d/dx1 reads x2m ; d/dx2 reads x1m
-  hipStream_t s = (hipStream_t)stream;
 #define SEGG(TK_)                                                                               \
   do {                                                                                          \
     if (lds > 48 * 1024)                                                                        \
@@ -299,7 +690,6 @@ int iic_seg_grad(const float* src, const float* mask, const int* flips, const fl
   if (tk == 1) SEGG(1);
   else if (tk == 2) SEGG(2);
   else SEGG(3);
-  (void)nq;
   return iic_launch_status();
 }
 

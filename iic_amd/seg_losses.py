@@ -144,10 +144,12 @@ class _SegLossFn(torch.autograd.Function):
     g_loss, g_nl = g_loss.contiguous().to(F32), g_nl.contiguous().to(F32)
     dx1, dx2 = torch.empty_like(x1), torch.empty_like(x2)
     L, s = lib(), stream_ptr()
+    # scratch of the two launches (stream-ordered, so they share it): per-shift gradient matrices
+    ws = torch.empty(L.iic_seg_grad_workspace_bytes(k, T) // 4, dtype=F32, device=x1.device)
     check(L.iic_seg_grad(ptr(x2), ptr(mask), ptr(flips), ptr(dR1), ptr(dR2), ptr(g_loss), ptr(g_nl),
-                         ptr(dx1), bn, k, h, w, T, 0, 1 if collapsed else 0, s), "iic_seg_grad")
+                         ptr(dx1), bn, k, h, w, T, 0, 1 if collapsed else 0, ptr(ws), s), "iic_seg_grad")
     check(L.iic_seg_grad(ptr(x1), ptr(mask), ptr(flips), ptr(dR1), ptr(dR2), ptr(g_loss), ptr(g_nl),
-                         ptr(dx2), bn, k, h, w, T, 1, 1 if collapsed else 0, s), "iic_seg_grad")
+                         ptr(dx2), bn, k, h, w, T, 1, 1 if collapsed else 0, ptr(ws), s), "iic_seg_grad")
     return dx1, dx2, None, None, None, None, None
 
 

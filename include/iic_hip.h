@@ -73,11 +73,15 @@ int iic_seg_loss_from_joint(const float* partials, int nparts, int H, int k, dou
                             double eps, void* workspace, float* loss, float* loss_no_lamb,
                             float* dR_loss, float* dR_loss_no_lamb, int detach_norm, void* stream);
 /* which = 0: out = dLoss/dx1 (src = x2);  which = 1: out = dLoss/dx2 (src = x1).
- * g_loss / g_loss_no_lamb: DEVICE arrays [H] of upstream gradients per shift ([1] if collapsed). */
+ * g_loss / g_loss_no_lamb: DEVICE arrays [H] of upstream gradients per shift ([1] if collapsed).
+ * workspace: iic_seg_grad_workspace_bytes(k, T) bytes, 16-byte aligned, caller-owned scratch of
+ * this launch (the per-shift gradient matrices laid out for the streaming kernel); NULL selects
+ * the generic kernel (any w, k <= 48), which needs none.                                     */
+long iic_seg_grad_workspace_bytes(int k, int T);
 int iic_seg_grad(const float* src, const float* mask, const int* flips, const float* dR_loss,
                  const float* dR_loss_no_lamb, const float* g_loss, const float* g_loss_no_lamb,
                  float* out, int bn, int k, int h, int w, int T, int which, int collapsed,
-                 void* stream);
+                 float* workspace, void* stream);
 /* General case of the second view's warp -- perform_affine_tf (code/utils/segmentation/
  * transforms.py:131-143: affine_grid + grid_sample, bilinear, zero padding) followed by the
  * whole-batch integer shift of random_translation_multiple (transforms.py:145-165; IID_losses.py:
