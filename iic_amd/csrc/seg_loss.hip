@@ -245,16 +245,72 @@ __global__ __launch_bounds__(256) void seg_grad_kernel(
 // ====================================================================================
 __device__ __forceinline__ float4 seg_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 seg_rev4(float4 v) { return make_float4(v.w, v.z, v.y, v.x); }
+__device__ __forceinline__ void seg_store4(float* d, float4 v, float4 m) {
+  d[0] = v.x * m.x; d[1] = v.y * m.y; d[2] = v.z * m.z; d[3] = v.w * m.w;
+}
+// LDS pitches of the streaming kernels.  Joint: lanes (class c, k index kk) read row c, column
+// x + kk: a pitch of 2 * odd spreads the 16 rows over the even banks and kk = 0,1 over even / odd.
+// Gradient: lanes read row b0 + kk, column x0 + c: a pitch = 16 (mod 32) puts rows kk = 0,1 on the
+// two halves of the banks.
+__host__ __device__ __forceinline__ int seg_pitch2(int n) { return (n & 3) == 2 ? n : ((n + 1) & ~3) + 2; }   // >= n, = 2 (mod 4)
+__host__ __device__ __forceinline__ int seg_pitch16(int n) { return ((n + 15) & ~31) + 16; }               // >= n, = 16 (mod 32)
 
-template <int TK, int QG, int LW>
-__global__ __launch_bounds__(256) void seg_joint_stream_kernel(
+// MFMA loop of one staged row: the (column shift, class) pairs of this workgroup's QG shifts are
+// packed densely into 16-row MFMA tiles (k = 24: 6 shifts = 144 rows = 9 full tiles, not 6 x 2
+// padded ones), lane c of tile ti reads its row at sX1[aoff[ti] + x].  Tiles are issued in groups
+// of GT (reads of a group before its MFMAs); groups past the mt tiles in use are skipped by one
+// wave-uniform branch each.
+template <int TK, int MTMAX, int GT>
+__device__ __forceinline__ void seg_joint_ksteps(f32x4 (*acc)[TK], const float* sX1, const float* sX2,
+                                                 const int* aoff, int P2, int nst, int mt, int wave,
+                                                 int kk, int c) {
+  // Fragments of step st + 4 are read while the MFMAs of step st run (left to itself the compiler
+  // emits read -> wait -> 2 MFMAs per tile: the LDS latency is then paid 9 times per step).
+  float b0[TK], a0[MTMAX], b1[TK], a1[MTMAX];                // two fragment sets, used alternately
+  int st = wave;
+  if (st >= nst) return;
+  auto load = [&](float (&bb)[TK], float (&aa)[MTMAX], int stl) {
+    const int x0 = 4 * stl + kk;
+#pragma unroll
+    for (int tj = 0; tj < TK; ++tj) bb[tj] = sX2[(tj * 16 + c) * P2 + x0];
+#pragma unroll
+    for (int ti = 0; ti < MTMAX; ++ti) aa[ti] = sX1[aoff[ti] + x0];
+  };
+  auto step = [&](float (&bc)[TK], float (&ac)[MTMAX], float (&bn)[TK], float (&an)[MTMAX]) {
+    load(bn, an, st + 4 < nst ? st + 4 : st);                 // (last step: re-reads itself)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g0 = 0; g0 < MTMAX; g0 += GT) {
+      if (g0 < mt) {
+#pragma unroll
+        for (int ti = 0; ti < GT; ++ti)
+          if (g0 + ti < MTMAX) {
+#pragma unroll
+            for (int tj = 0; tj < TK; ++tj) acc[g0 + ti][tj] = mfma16(ac[g0 + ti], bc[tj], acc[g0 + ti][tj]);
+          }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    st += 4;
+  };
+  load(b0, a0, st);
+  while (true) {
+    step(b0, a0, b1, a1);
+    if (st >= nst) break;
+    step(b1, a1, b0, a0);
+    if (st >= nst) break;
+  }
+}
+
+template <int TK, int MTMAX, int LW>
+__global__ __launch_bounds__(256, 2) void seg_joint_stream_kernel(
     const float* __restrict__ x1, const float* __restrict__ x2, const float* __restrict__ mask,
-    const int* __restrict__ flips, float* __restrict__ part, int bn, int k, int h, int w, int T) {
+    const int* __restrict__ flips, float* __restrict__ part, int bn, int k, int h, int w, int T, int QG) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int CR = 256 / LW, NJ = (16 * TK + CR - 1) / CR;
   const int nq = 2 * T + 1;
   const int w4 = w;                                        // w % 4 == 0 here
-  const int P1 = (w4 + 2 * T) | 1, P2 = w4 | 1;
+  const int P1 = seg_pitch2(w4 + 2 * T), P2 = seg_pitch2(w4);
   float* sX1 = reinterpret_cast<float*>(smem_raw);          // [16*TK][P1]
   float* sX2 = sX1 + 16 * TK * P1;                          // [16*TK][P2]
   const int p = blockIdx.x, q0 = blockIdx.y * QG, split = blockIdx.z, S = gridDim.z;
@@ -265,19 +321,25 @@ __global__ __launch_bounds__(256) void seg_joint_stream_kernel(
   const long rows = (long)bn * h;
   const long per = (rows + S - 1) / S;
   const long r0 = split * per, r1 = min(rows, r0 + per);
+  const int qn = min(QG, nq - q0);                         // column shifts of this workgroup
+  const int mrows = qn * k, mt = (mrows + 15) >> 4;        // packed (shift, class) rows -> row tiles
 
-  f32x4 acc[QG][TK][TK];
+  f32x4 acc[MTMAX][TK];
+  int aoff[MTMAX];
 #pragma unroll
-  for (int a = 0; a < QG; ++a)
+  for (int ti = 0; ti < MTMAX; ++ti) {
 #pragma unroll
-    for (int ti = 0; ti < TK; ++ti)
-#pragma unroll
-      for (int tj = 0; tj < TK; ++tj) acc[a][ti][tj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int tj = 0; tj < TK; ++tj) acc[ti][tj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int m = ti * 16 + c, a = m / k, i = m - a * k;
+    // rows past the packed range read the all-zero padding channel (exists whenever a tile is ragged)
+    aoff[ti] = m < mrows ? i * P1 + q0 + a : (16 * TK - 1) * P1;
+  }
 
   // halo columns and padding channels stay zero for the whole kernel: only interiors are rewritten
   for (int idx = tid; idx < 16 * TK * (P1 + P2); idx += 256) sX1[idx] = 0.f;
 
   float4 pre1[NJ], pre2[NJ], m1, m2;
+  int pfx = 0;                                             // x flip of the row in flight
   auto next_valid = [&](long r) {
     while (r < r1) {
       const int y1 = (int)(r % h) + p - T;
@@ -290,6 +352,7 @@ __global__ __launch_bounds__(256) void seg_joint_stream_kernel(
     const int n = (int)(r / h), y = (int)(r - (long)n * h), y1 = y + p - T;
     const int fx = flips[2 * n], fy = flips[2 * n + 1];
     const int sy = fy ? h - 1 - y : y, sx = fx ? wq - 1 - xl : xl;
+    pfx = fx;
     if (xact) {
       m2 = seg_ld4(mask + ((long)n * h + y) * w + 4 * xl);
       m1 = seg_ld4(mask + ((long)n * h + y1) * w + 4 * xl);
@@ -297,8 +360,8 @@ __global__ __launch_bounds__(256) void seg_joint_stream_kernel(
       for (int j = 0; j < NJ; ++j) {
         const int ch = cr + CR * j;
         if (ch < k) {
-          const float4 v = seg_ld4(x2 + (((long)n * k + ch) * h + sy) * w + 4 * sx);
-          pre2[j] = fx ? seg_rev4(v) : v;
+          // (raw values only: any arithmetic on them here would wait for the loads before the MFMA loop)
+          pre2[j] = seg_ld4(x2 + (((long)n * k + ch) * h + sy) * w + 4 * sx);
           pre1[j] = seg_ld4(x1 + (((long)n * k + ch) * h + y1) * w + 4 * xl);
         }
       }
@@ -314,58 +377,37 @@ __global__ __launch_bounds__(256) void seg_joint_stream_kernel(
       for (int j = 0; j < NJ; ++j) {
         const int ch = cr + CR * j;
         if (ch < k) {
-          float* d2 = sX2 + ch * P2 + 4 * xl;
-          d2[0] = pre2[j].x * m2.x; d2[1] = pre2[j].y * m2.y; d2[2] = pre2[j].z * m2.z; d2[3] = pre2[j].w * m2.w;
-          float* d1 = sX1 + ch * P1 + T + 4 * xl;
-          d1[0] = pre1[j].x * m1.x; d1[1] = pre1[j].y * m1.y; d1[2] = pre1[j].z * m1.z; d1[3] = pre1[j].w * m1.w;
+          seg_store4(sX2 + ch * P2 + 4 * xl, pfx ? seg_rev4(pre2[j]) : pre2[j], m2);
+          seg_store4(sX1 + ch * P1 + T + 4 * xl, pre1[j], m1);
         }
       }
     }
     __syncthreads();
     const long rn = next_valid(r + 1);
     if (rn < r1) issue(rn);                          // in flight during the MFMA loop below
-    for (int st = wave; st < w4 / 4; st += 4) {
-      const int x0 = 4 * st + kk;
-      float b[TK];
-#pragma unroll
-      for (int tj = 0; tj < TK; ++tj) b[tj] = sX2[(tj * 16 + c) * P2 + x0];
-#pragma unroll
-      for (int a = 0; a < QG; ++a) {
-        const int q = q0 + a;
-        if (q < nq) {
-#pragma unroll
-          for (int ti = 0; ti < TK; ++ti) {
-            const float av = sX1[(ti * 16 + c) * P1 + x0 + q];
-#pragma unroll
-            for (int tj = 0; tj < TK; ++tj) acc[a][ti][tj] = mfma16(av, b[tj], acc[a][ti][tj]);
-          }
-        }
-      }
-    }
+    seg_joint_ksteps<TK, MTMAX, (TK == 2 ? 3 : 4)>(acc, sX1, sX2, aoff, P2, w4 / 4, mt, wave, kk, c);
     r = rn;
   }
-  float* red = reinterpret_cast<float*>(smem_raw);          // [4][TK*TK][256]
-  constexpr int TT = TK * TK;
+  // cross-wave reduction, one row tile at a time, through LDS (reuses the row buffers)
+  float* red = reinterpret_cast<float*>(smem_raw);          // [4 waves][TK][256]
 #pragma unroll
-  for (int a = 0; a < QG; ++a) {
-    const int q = q0 + a;
-    if (q >= nq) continue;
+  for (int ti = 0; ti < MTMAX; ++ti) {
+    if (ti >= mt) continue;
     __syncthreads();
 #pragma unroll
-    for (int ti = 0; ti < TK; ++ti)
+    for (int tj = 0; tj < TK; ++tj)
 #pragma unroll
-      for (int tj = 0; tj < TK; ++tj)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr)
-          red[(wave * TT + ti * TK + tj) * 256 + lane * 4 + rr] = acc[a][ti][tj][rr];
+      for (int rr = 0; rr < 4; ++rr) red[(wave * TK + tj) * 256 + lane * 4 + rr] = acc[ti][tj][rr];
     __syncthreads();
-    float* out = part + (((long)split * nq + p) * nq + q) * k * k;
-    for (int idx = tid; idx < TT * 256; idx += 256) {
-      const int t = idx >> 8, e = idx & 255, ln = e >> 2, rr = e & 3;
-      const int i = (t / TK) * 16 + (ln >> 4) * 4 + rr, j = (t % TK) * 16 + (ln & 15);
-      if (i < k && j < k)
-        out[(long)i * k + j] = red[(0 * TT + t) * 256 + e] + red[(1 * TT + t) * 256 + e] +
-                               red[(2 * TT + t) * 256 + e] + red[(3 * TT + t) * 256 + e];
+    for (int idx = tid; idx < TK * 256; idx += 256) {
+      const int tj = idx >> 8, e = idx & 255, ln = e >> 2, rr = e & 3;
+      const int m = ti * 16 + (ln >> 4) * 4 + rr, j = tj * 16 + (ln & 15);
+      if (m < mrows && j < k) {
+        const int a = m / k, i = m - a * k;
+        float* out = part + (((long)split * nq + p) * nq + q0 + a) * k * k;
+        out[(long)i * k + j] = red[(0 * TK + tj) * 256 + e] + red[(1 * TK + tj) * 256 + e] +
+                               red[(2 * TK + tj) * 256 + e] + red[(3 * TK + tj) * 256 + e];
+      }
     }
   }
 }
@@ -402,6 +444,9 @@ __device__ __forceinline__ void seg_grad_ksteps(f32x4 (&acc)[4 * TK], const floa
                                                 int gc, int PS, int k4, int qn, int xoff0, int sgn,
                                                 int kk, const int (&ubase)[4 * TK]) {
   constexpr int PG = 16 * TK;
+  // (an explicit next-step fragment prefetch, as in the joint kernel, was measured SLOWER here: with
+  // only N <= 7 MFMAs per step the extra stepping arithmetic costs more than the LDS latency that
+  // the second wave of the SIMD already hides -- 20.9 vs 23.0 ms at k = 24, 4.05 vs 5.3 ms at k = 15)
   for (int ql = 0; ql < qn; ++ql) {
     const int xoff = xoff0 + sgn * ql;                        // wave-uniform column offset
     const float* sGq = sG + ql * k4 * PG;
@@ -436,11 +481,19 @@ __global__ __launch_bounds__(256) void seg_grad_stream_kernel(
   const int nq = 2 * T + 1;
   const int k4 = (k + 3) & ~3;
   const int w16 = (w + 15) & ~15;
-  const int PS = (w16 + 2 * T) | 1;
+  const int PS = seg_pitch16(w16 + 2 * T);
   float* sS = reinterpret_cast<float*>(smem_raw);          // [k4][PS]     masked source row
   float* sG = sS + (((long)k4 * PS + 3) & ~3L);            // [slice rows][PG], 16-byte aligned
-  const int n = blockIdx.x / h, y = blockIdx.x - n * h;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // workgroups are dealt round-robin to the 8 XCDs: give each XCD a contiguous band of output rows
+  // so that the 2T+1 source rows a workgroup reads are the ones its L2 neighbours just fetched
+  const int per8 = gridDim.x >> 3;                         // grid = 8 * ceil(bn*h / 8)
+  const int row = (blockIdx.x & 7) * per8 + (blockIdx.x >> 3);
+  if (row >= bn * h) return;
+  const int n = row / h, y = row - n * h;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // the waves owning one MFMA unit more (units = wave + 4u) sit on different SIMDs in the two
+  // workgroups a CU holds at a time (dispatch fills a CU's second slot 32 workgroups later)
+  const int wave = ((tid >> 6) + 2 * ((blockIdx.x >> 8) & 1)) & 3;
   const int c = lane & 15, kk = lane >> 4;
   const int xl = tid % LW, cr = tid / LW, wq = w >> 2;
   const bool xact = xl < wq;
@@ -480,8 +533,7 @@ __global__ __launch_bounds__(256) void seg_grad_stream_kernel(
       for (int j = 0; j < NJ; ++j) {
         const int ch = cr + CR * j;
         if (ch < k) {
-          const float4 v = seg_ld4(src + (((long)n * k + ch) * h + sy) * w + 4 * sx);
-          pres[j] = fx ? seg_rev4(v) : v;
+          pres[j] = seg_ld4(src + (((long)n * k + ch) * h + sy) * w + 4 * sx);   // (raw: see the joint kernel)
         }
       }
     }
@@ -518,8 +570,7 @@ __global__ __launch_bounds__(256) void seg_grad_stream_kernel(
       for (int j = 0; j < NJ; ++j) {
         const int ch = cr + CR * j;
         if (ch < k) {
-          float* d = sS + ch * PS + T + 4 * xl;
-          d[0] = pres[j].x * pm.x; d[1] = pres[j].y * pm.y; d[2] = pres[j].z * pm.z; d[3] = pres[j].w * pm.w;
+          seg_store4(sS + ch * PS + T + 4 * xl, fx ? seg_rev4(pres[j]) : pres[j], pm);
         }
       }
     }
@@ -579,10 +630,23 @@ static bool seg_stream_ok(int k, int w, const void* a, const void* b, const void
          ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c)) & 15) == 0;
 }
 static int seg_qg(int tk) { return tk == 1 ? 21 : (tk == 2 ? 7 : 3); }
+// streaming joint kernel: row tiles per workgroup (accumulators) and the column shifts per group that
+// fill them -- groups balanced over the 2T+1 shifts
+#define SEG_MT1 21
+#define SEG_MT2 11
+static int seg_stream_groups(int k, int nq, int* qg_out) {
+  const int mt = seg_tk(k) == 1 ? SEG_MT1 : SEG_MT2;
+  int qgmax = mt * 16 / k;
+  if (qgmax < 1) qgmax = 1;
+  const int groups = (nq + qgmax - 1) / qgmax;
+  if (qg_out) *qg_out = (nq + groups - 1) / groups;
+  return groups;
+}
 
 int iic_seg_joint_nsplit(int bn, int h, int k, int T) {
   const int nq = 2 * T + 1, tk = seg_tk(k), qg = seg_qg(tk);
-  const int groups = nq * ((nq + qg - 1) / qg);
+  int groups = nq * ((nq + qg - 1) / qg);
+  if (tk <= 2) groups = nq * seg_stream_groups(k, nq, nullptr);   // (any split count suits either kernel)
   int s = 1536 / groups;
   if (s < 1) s = 1;
   const long rows = (long)bn * h;
@@ -610,21 +674,27 @@ int iic_seg_joint_raw(const float* x1, const float* x2, const float* mask, const
     hipLaunchKernelGGL((seg_joint_kernel<TK_, QG_>), grid, dim3(256), lds, s, x1, x2, mask,     \
                        flips, partials, bn, k, h, w, T);                                        \
   } while (0)
-#define SEGJS(TK_, QG_, LW_)                                                                    \
+#define SEGJS(TK_, MT_, LW_)                                                                    \
   do {                                                                                          \
     if (lds > 48 * 1024)                                                                        \
       (void)hipFuncSetAttribute(                                                                \
-          reinterpret_cast<const void*>(&seg_joint_stream_kernel<TK_, QG_, LW_>),               \
+          reinterpret_cast<const void*>(&seg_joint_stream_kernel<TK_, MT_, LW_>),               \
           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
-    hipLaunchKernelGGL((seg_joint_stream_kernel<TK_, QG_, LW_>), grid, dim3(256), lds, s, x1,   \
-                       x2, mask, flips, partials, bn, k, h, w, T);                              \
+    hipLaunchKernelGGL((seg_joint_stream_kernel<TK_, MT_, LW_>), sgrid, dim3(256), lds, s, x1,  \
+                       x2, mask, flips, partials, bn, k, h, w, T, sqg);                         \
   } while (0)
-#define SEGJS_LW(TK_, QG_)                                                                      \
+#define SEGJS_LW(TK_, MT_)                                                                      \
   do {                                                                                          \
-    if (w > 128) SEGJS(TK_, QG_, 64); else if (w > 64) SEGJS(TK_, QG_, 32); else SEGJS(TK_, QG_, 16); \
+    if (w > 128) SEGJS(TK_, MT_, 64); else SEGJS(TK_, MT_, 32);                                 \
   } while (0)
   if (seg_stream_ok(k, w, x1, x2, mask)) {
-    if (tk == 1) SEGJS_LW(1, 21); else SEGJS_LW(2, 7);
+    const size_t srows = (size_t)16 * tk * (seg_pitch2(w + 2 * T) + seg_pitch2(w)) * sizeof(float);
+    const size_t sred = (size_t)4 * tk * 256 * sizeof(float);
+    const size_t lds = srows > sred ? srows : sred;
+    int sqg = 1;
+    const int sgroups = seg_stream_groups(k, nq, &sqg);
+    dim3 sgrid(nq, sgroups, nsplit);
+    if (tk == 1) SEGJS_LW(1, SEG_MT1); else SEGJS_LW(2, SEG_MT2);
   } else if (tk == 1) SEGJ(1, 21);
   else if (tk == 2) SEGJ(2, 7);
   else SEGJ(3, 3);
@@ -656,14 +726,14 @@ int iic_seg_grad(const float* src, const float* mask, const int* flips, const fl
     hipLaunchKernelGGL(seg_gprep_kernel, dim3(nq, (rowsP * PG + 255) / 256), dim3(256), 0, s,
                        dR_loss, dR_loss_no_lamb, g_loss, g_loss_no_lamb, workspace, k, nq, PG, rowsP,
                        which, collapsed ? 0 : 1);
-    const int PS = (w16 + 2 * T) | 1;
+    const int PS = seg_pitch16(w16 + 2 * T);
     const size_t lds = ((((size_t)k4 * PS + 3) & ~(size_t)3) + (size_t)QC * k4 * PG) * sizeof(float);
 #define SEGGS(TK_, LW_)                                                                         \
   do {                                                                                          \
     if (lds > 48 * 1024)                                                                        \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seg_grad_stream_kernel<TK_, LW_>), \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
-    hipLaunchKernelGGL((seg_grad_stream_kernel<TK_, LW_>), dim3(bn * h), dim3(256), lds, s, src, \
+    hipLaunchKernelGGL((seg_grad_stream_kernel<TK_, LW_>), dim3(8 * ((bn * h + 7) / 8)), dim3(256), lds, s, src, \
                        mask, flips, workspace, out, bn, k, h, w, T, which, src_is_x2, QC, rowsP); \
   } while (0)
 #define SEGGS_LW(TK_)                                                                           \
