@@ -60,7 +60,9 @@ int iic_iid_grad(const float* z, const float* zt, const float* dR_loss,
  * identity / axis-flip transforms (transforms.py:131-143; `flips` = int32 [bn][2]: flip x, y).
  * x1, x2: fp32 NCHW [bn][k][h][w] (post-softmax), mask fp32 [bn][h][w], T = half_T_side_dense.
  *   partials[s][p][q][i][j] = sum over row-slice s of x1m[i](y+p-T, x+q-T) * x2m[j](y, x)
- * Exact fp32 MFMA (16x16x4).  k <= 48, T <= 10, w <= 256.
+ * Exact fp32 MFMA (16x16x4).  k <= 48, T <= 10, w <= 256.  Rows with w % 4 == 0, k <= 32 and
+ * 16-byte aligned tensors take the streaming kernels (float4 rows prefetched under the MFMA loop);
+ * anything else the element-wise generic ones -- same results (bit-identical joint).
  * ------------------------------------------------------------------------------- */
 int iic_seg_joint_nsplit(int bn, int h, int k, int T);
 int iic_seg_joint_raw(const float* x1, const float* x2, const float* mask, const int* flips,
