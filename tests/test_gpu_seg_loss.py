@@ -185,3 +185,87 @@ def test_stream_kernels_match_generic_kernels_bitwise(bn, k, h, w, T, collapsed)
       # gradient kernel, k % 4 != 0: the streaming kernel pads the classes of every column shift to
       # a multiple of 4, so its MFMA steps group the same products differently (rounding only)
       assert float((a - b).norm() / a.norm()) <= 2e-6
+
+
+@pytest.mark.parametrize("name,bn,k,h,w,T,dens", [("potsdam3", 75, 24, 200, 200, 10, 1.0),
+                                                  ("coco3", 120, 15, 128, 128, 10, 0.6)])
+def test_full_size_joint_and_gradient_vs_independent_float64(name, bn, k, h, w, T, dens):
+  """BASELINE.json shapes at FULL size (the oracle only finishes reduced sizes in seconds):
+  (1) checksum of checksums -- softmax rows sum to 1, so sum_ij R_t[i][j] must equal the mask's
+      autocorrelation at t (integers, computed independently);
+  (2) sampled shifts of the joint against a float64 torch contraction of the shifted slices;
+  (3) the gradient kernel on sampled output pixels against the closed form
+      dX1_i(n,v) = mask(v) * sum_t sum_j G_t[i][j] x2m_j(n, v - t) in float64, plus linearity in G."""
+  from iic_amd._lib import check, lib, ptr, stream_ptr
+  L = lib()
+  g = torch.Generator().manual_seed(11)
+  x1 = torch.softmax(torch.randn(bn, k, h, w, generator=g) * 2, 1).to(dev())
+  x2 = torch.softmax(torch.randn(bn, k, h, w, generator=g) * 2, 1).to(dev())
+  mask = (torch.rand(bn, h, w, generator=g) < dens).float().to(dev())
+  fl = torch.tensor([[i & 1, (i >> 1) & 1] for i in range(bn)], dtype=torch.int32)
+  flips = fl.to(dev())
+  nq = 2 * T + 1
+  ns = L.iic_seg_joint_nsplit(bn, h, k, T)
+  part = torch.empty((ns, nq * nq, k, k), device=dev())
+  check(L.iic_seg_joint_raw(ptr(x1), ptr(x2), ptr(mask), ptr(flips), ptr(part), bn, k, h, w, T, ns, stream_ptr()), "joint")
+  R = part.double().sum(0).view(nq, nq, k, k)                     # [p][q][i][j]
+  # masked / inverse-warped maps in float64, independent of the kernels
+  x2i = x2.double().clone()
+  for n in range(bn):
+    dims = [d for d, f in ((2, int(fl[n, 0])), (1, int(fl[n, 1]))) if f]
+    if dims:
+      x2i[n] = torch.flip(x2i[n], dims)
+  m64 = mask.double()
+  x1m, x2m = x1.double() * m64[:, None], x2i * m64[:, None]
+
+  def shifted(a, ty, tx):     # a(n, ., y + ty, x + tx), zero outside
+    out = torch.zeros_like(a)
+    ys, ye = max(0, -ty), min(h, h - ty)
+    xs, xe = max(0, -tx), min(w, w - tx)
+    out[..., ys:ye, xs:xe] = a[..., ys + ty:ye + ty, xs + tx:xe + tx]
+    return out
+
+  # (1) every shift: sum_ij R_t = sum_u mask(u + t) mask(u)
+  tot = R.sum((2, 3))
+  for p in range(nq):
+    for q in (0, T, nq - 1, (3 * p) % nq):
+      want = float((shifted(m64, p - T, q - T) * m64).sum())
+      assert abs(float(tot[p, q]) - want) <= 2e-5 * max(want, 1.0), (p, q, float(tot[p, q]), want)
+  # (2) sampled shifts, all k x k entries
+  for p, q in ((0, 0), (T, T), (nq - 1, 3), (4, nq - 1), (T + 1, T - 2)):
+    want = torch.einsum("nihw,njhw->ij", shifted(x1m, p - T, q - T), x2m)
+    err = float((R[p, q] - want).abs().max() / want.abs().max())
+    assert err <= 2e-5, (p, q, err)
+  # (3) gradient w.r.t. x1 on sampled pixels; G random per shift
+  H = nq * nq
+  dR1 = torch.randn(H, k, k, generator=g).to(dev())
+  dR2 = torch.randn(H, k, k, generator=g).to(dev())
+  g1 = torch.randn(H, generator=g).to(dev())
+  g2 = torch.randn(H, generator=g).to(dev())
+  ws = torch.empty(L.iic_seg_grad_workspace_bytes(k, T) // 4, device=dev())
+
+  def grad(which, src, a, b):
+    o = torch.empty_like(x1)
+    check(L.iic_seg_grad(ptr(src), ptr(mask), ptr(flips), ptr(a), ptr(b), ptr(g1), ptr(g2), ptr(o), bn, k, h, w, T,
+                         which, 0, ptr(ws), stream_ptr()), "grad")
+    return o
+
+  dx1 = grad(0, x2, dR1, dR2)
+  G = (g1.double()[:, None, None] * dR1.double() + g2.double()[:, None, None] * dR2.double()).view(nq, nq, k, k)
+  x2p = torch.nn.functional.pad(x2m, (T, T, T, T))                # zero padded, index + T
+  rs = torch.Generator().manual_seed(5)
+  for _ in range(40):
+    n = int(torch.randint(bn, (1,), generator=rs)); y = int(torch.randint(h, (1,), generator=rs))
+    x = int(torch.randint(w, (1,), generator=rs))
+    if _ % 4 == 0:
+      y, x = (0, w - 1) if _ % 8 == 0 else (h - 1, 0)              # corners: the halo paths
+    win = x2p[n, :, y:y + nq, x:x + nq].flip(1, 2)                 # win[j][p][q] = x2m_j(v - t), t = (p - T, q - T)
+    want = torch.einsum("pqij,jpq->i", G, win) * m64[n, y, x]
+    got = dx1[n, :, y, x].double()
+    assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max() + 1e-3), (n, y, x)
+  # linearity in G: grad(dR1 + dR1', .) = grad(dR1, .) + grad(dR1', .)  (dR2 weight set to zero)
+  zero = torch.zeros_like(dR2)
+  a = grad(1, x1, dR1, zero)
+  b = grad(1, x1, dR2, zero)
+  c = grad(1, x1, dR1 + dR2, zero)
+  assert float((a + b - c).norm() / c.norm()) <= 1e-5
