@@ -89,6 +89,11 @@ _SIGNATURES = {
   "iic_gemm_f32_splitk": (c_int, [_P, c_long, c_long, _P, c_long, c_long, _P, c_long, c_int, c_int, c_int, c_int, _P]),
   "iic_seg_window_gather": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
   "iic_seg_window_scatter": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+  "iic_seg_head_supported": (c_int, [c_int, c_int]),
+  "iic_seg_head_wgrad_chunks": (c_int, [c_long]),
+  "iic_seg_head_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+  "iic_seg_head_bwd_dx": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+  "iic_seg_head_wgrad": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
   "iic_bilinear_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
   "iic_bilinear_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
   "iic_softmax_fwd": (c_int, [_P, _P, c_int, c_int, _P]),

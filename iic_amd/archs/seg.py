@@ -8,6 +8,8 @@ Head = 1x1 conv with padding 1 as an fp32-MFMA GEMM over the (Hf+2)x(Wf+2) windo
 feature map, Softmax2d, bilinear up-sampling to input_sz -- all fp32 (feeds the loss).
 state_dict keys / init follow the reference (vgg.py:8-54, net10a.py:34-80).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -17,6 +19,11 @@ from .vgg import VGGTrunkHIP, _initialize_weights_vgg
 
 __all__ = ["SegmentationNet10a", "SegmentationNet10aTwoHead"]
 F32 = torch.float32
+
+
+# 1: the head's three GEMMs run directly on the bf16 PT window (iic_seg_head_*); 0: window gather ->
+# generic fp32 GEMM -> scatter (the exact-fp32 parity path always takes the latter).  A/B + tests.
+FUSED_HEAD = [os.environ.get("IIC_SEG_FUSED_HEAD", "1") != "0"]
 
 
 class _SegHeadFn(torch.autograd.Function):
@@ -29,18 +36,25 @@ class _SegHeadFn(torch.autograd.Function):
     k = w.shape[0]
     M = N * Hw * Ww
     L, s = lib(), stream_ptr()
-    Fm = torch.empty((M, C), dtype=F32, device=x.device)
-    if x.dtype == F32:      # exact-fp32 parity path
-      check(L.iic_f32_window_gather(ptr(x), ptr(Fm), N, Hw, Ww, Hp, Wp, off, C, s), "iic_f32_window_gather")
-    else:
-      check(L.iic_seg_window_gather(ptr(x), ptr(Fm), N, Hw, Ww, Hp, Wp, off, C, s), "iic_seg_window_gather")
     W2 = w.detach().reshape(k, C).contiguous()
     logits = torch.empty((M, k), dtype=F32, device=x.device)
-    ops.gemm_f32(Fm, C, 1, W2, 1, C, logits, k, M, k, C)
+    # fused path: the GEMMs read / write the bf16 window in place (csrc/seg_head.hip)
+    fused = FUSED_HEAD[0] and x.dtype != F32 and bool(L.iic_seg_head_supported(C, k))
+    Fm = None
+    if fused:
+      check(L.iic_seg_head_fwd(ptr(x), ptr(W2), ptr(logits), N, Hw, Ww, Hp, Wp, off, C, k, s), "iic_seg_head_fwd")
+    else:
+      Fm = torch.empty((M, C), dtype=F32, device=x.device)
+      if x.dtype == F32:      # exact-fp32 parity path
+        check(L.iic_f32_window_gather(ptr(x), ptr(Fm), N, Hw, Ww, Hp, Wp, off, C, s), "iic_f32_window_gather")
+      else:
+        check(L.iic_seg_window_gather(ptr(x), ptr(Fm), N, Hw, Ww, Hp, Wp, off, C, s), "iic_seg_window_gather")
+      ops.gemm_f32(Fm, C, 1, W2, 1, C, logits, k, M, k, C)
     probs = ops.softmax_fwd(logits, M, k)
     out = torch.empty((N, k, S, S), dtype=F32, device=x.device)
     check(L.iic_bilinear_fwd(ptr(probs), ptr(out), N, Hw, Ww, k, S, s), "iic_bilinear_fwd")
-    ctx.save_for_backward(Fm, W2, probs)
+    ctx.save_for_backward(x if fused else Fm, W2, probs)
+    ctx.fused = fused
     ctx.meta = (tuple(x.shape), P, S, Hw, Ww, off, k)
     ctx.branch, ctx.pt_dtype = ops.BRANCH[0], x.dtype
     return out
@@ -55,13 +69,22 @@ class _SegHeadFn(torch.autograd.Function):
     dprobs = torch.empty((M, k), dtype=F32, device=dout.device)
     check(L.iic_bilinear_bwd(ptr(dout.contiguous()), ptr(dprobs), N, Hw, Ww, k, S, s), "iic_bilinear_bwd")
     dlog = ops.softmax_bwd(probs, dprobs, M, k)
+    dx = ops.POOL.alloc(shape, dout.device, P)
+    if ctx.fused:
+      x = Fm                                      # (the PT feature tensor itself was saved)
+      nch = L.iic_seg_head_wgrad_chunks(M)
+      part = torch.empty((nch, k * C), dtype=F32, device=dout.device)
+      check(L.iic_seg_head_wgrad(ptr(dlog), ptr(x), ptr(part), N, Hw, Ww, Hp, Wp, off, C, k, s), "iic_seg_head_wgrad")
+      dW = torch.empty((k, C), dtype=F32, device=dout.device)
+      check(L.iic_colsum_f32(ptr(part), ptr(dW), nch, k * C, 0, s), "iic_colsum_f32")
+      check(L.iic_seg_head_bwd_dx(ptr(dlog), ptr(W2), ptr(dx), N, Hw, Ww, Hp, Wp, off, C, k, s), "iic_seg_head_bwd_dx")
+      return dx, dW.view(k, C, 1, 1), None, None
     dW = torch.zeros((k, C), dtype=F32, device=dout.device)
     splitk = max(1, min(512, M // 2048))
     check(L.iic_gemm_f32_splitk(ptr(dlog), 1, k, ptr(Fm), C, 1, ptr(dW), C, k, C, M, splitk, s),
           "iic_gemm_f32_splitk")
     dF = torch.empty((M, C), dtype=F32, device=dout.device)
     ops.gemm_f32(dlog, k, 1, W2, C, 1, dF, C, M, C, k)
-    dx = ops.POOL.alloc(shape, dout.device, P)
     if dx.dtype == F32:
       check(L.iic_f32_window_scatter(ptr(dF), ptr(dx), N, Hw, Ww, Hp, Wp, off, C, s), "iic_f32_window_scatter")
     else:

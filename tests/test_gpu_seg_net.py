@@ -42,10 +42,15 @@ def test_bilinear_forward_backward(Hl, S, k):
   assert float((din.cpu().permute(0, 3, 1, 2) - x.grad).abs().max()) <= 1e-4 * float(x.grad.abs().max())
 
 
-def test_seg_head_forward_backward():
+@pytest.mark.parametrize("k,Hf,fused", [(6, 8, True), (6, 8, False), (24, 9, True), (3, 7, True), (15, 10, True)])
+def test_seg_head_forward_backward(k, Hf, fused, monkeypatch):
+  """fused: the three head GEMMs on the bf16 PT window (iic_seg_head_*); not fused: gather -> generic
+  fp32 GEMM -> scatter.  Both against torch's conv2d(1x1, padding 1) + softmax + bilinear in fp32."""
   from iic_amd import ops
+  from iic_amd.archs import seg as seg_mod
   from iic_amd.archs.seg import _SegHeadFn
-  N, C, Hf, k, S, P = 3, 512, 8, 6, 24, 3
+  monkeypatch.setattr(seg_mod, "FUSED_HEAD", [fused])
+  N, C, S, P = 3, 512, 24, 3
   rng = np.random.default_rng(3)
   f = torch.from_numpy(rng.standard_normal((N, C, Hf, Hf)).astype(np.float32)).relu().to(torch.bfloat16).float()
   w = torch.from_numpy((rng.standard_normal((k, C, 1, 1)) * 0.05).astype(np.float32))
@@ -64,6 +69,12 @@ def test_seg_head_forward_backward():
   gx = ops.pt_to_nchw(xp.grad, P).cpu()
   assert _cos(gx, ft.grad) >= 0.9999
   assert xp.grad[:, :P].abs().max() == 0   # gradient of the conv's zero padding is dropped
+  assert xp.grad[:, :, -P:].abs().max() == 0 and xp.grad[:, -P:].abs().max() == 0
+  if fused:                                 # the chunked weight gradient is order-fixed: bit-reproducible
+    xp2 = ops.pt_from_nchw(f.to(d), P).requires_grad_(True)
+    wd2 = w.to(d).requires_grad_(True)
+    _SegHeadFn.apply(xp2, wd2, P, S).backward(dy.to(d))
+    assert torch.equal(wd2.grad, wd.grad) and torch.equal(xp2.grad, xp.grad)
 
 
 def test_net10a_vs_reference_golden_and_emulation():
