@@ -161,18 +161,33 @@ __global__ __launch_bounds__(256) void firstconv_wgrad_kernel(const float* __res
     const int y = (int)(row % H), n = (int)(row / H);
     const float* xin = x + (long)n * Cin * H * W + (long)y * W;
     const bf16_t* drow = dy + (((long)n * Hp + y + P) * Wp + P) * FC_CO;
-    for (int st = 0; st < 16; ++st) {
-      const int px = seg * 32 + 2 * st + kk;   // this lane's k-slot pixel
-      const bool pv = px < W;
-      const float a0 = pv ? bf16_to_f32(drow[(long)px * FC_CO + i]) : 0.f;
-      const float a1 = pv ? bf16_to_f32(drow[(long)px * FC_CO + 32 + i]) : 0.f;
+    // operands of 8 pixel pairs are fetched before their MFMAs (one load round trip per 8 steps
+    // instead of one per step: the loop was latency-bound at 1/7 of the fp32 MFMA rate)
 #pragma unroll
-      for (int t = 0; t < NKT; ++t) {
-        const int yy = y + kdy[t], xx = px + kdx[t];
-        float b = 0.f;
-        if (pv && yy >= 0 && yy < H && xx >= 0 && xx < W) b = xin[px + koff[t]];
-        acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0][t], 0, 0, 0);
-        acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1][t], 0, 0, 0);
+    for (int sb = 0; sb < 16; sb += 8) {
+      unsigned short ra0[8], ra1[8];
+      float rb[8][NKT];
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) {
+        const int px = seg * 32 + 2 * (sb + s8) + kk;   // this lane's k-slot pixel
+        const bool pv = px < W;
+        ra0[s8] = pv ? drow[(long)px * FC_CO + i] : (unsigned short)0;
+        ra1[s8] = pv ? drow[(long)px * FC_CO + 32 + i] : (unsigned short)0;
+#pragma unroll
+        for (int t = 0; t < NKT; ++t) {
+          const int yy = y + kdy[t], xx = px + kdx[t];
+          rb[s8][t] = (pv && yy >= 0 && yy < H && xx >= 0 && xx < W) ? xin[px + koff[t]] : 0.f;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) {
+        const float a0 = bf16_to_f32(ra0[s8]), a1 = bf16_to_f32(ra1[s8]);
+#pragma unroll
+        for (int t = 0; t < NKT; ++t) {
+          acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, rb[s8][t], acc[0][t], 0, 0, 0);
+          acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, rb[s8][t], acc[1][t], 0, 0, 0);
+        }
       }
     }
   }
