@@ -75,14 +75,26 @@ __global__ __launch_bounds__(256) void firstconv_fwd_kernel(const float* __restr
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[h][r] = 0.f;
-    for (int st = 0; st < KS; ++st) {
-      const int k = 2 * st + kk;
-      const int yy = y + tab.kdy[k], xx = px + tab.kdx[k];
-      float a = 0.f;
-      if (yy >= 0 && yy < H && xx >= 0 && xx < W) a = xin[tab.koff[k]];
-      const float b0 = sW[k * FC_CO + i], b1 = sW[k * FC_CO + 32 + i];
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+    // patch values of 6 k-steps are fetched before their MFMAs (the step-by-step loop paid one
+    // global round trip per 2 MFMAs)
+    for (int sb = 0; sb < KS; sb += 6) {
+      float ra[6];
+#pragma unroll
+      for (int s6 = 0; s6 < 6; ++s6) {
+        const int k = min(2 * (sb + s6) + kk, FC_KMAX - 1);  // (tables are zero-padded past KT)
+        const int yy = y + tab.kdy[k], xx = px + tab.kdx[k];
+        ra[s6] = (sb + s6 < KS && yy >= 0 && yy < H && xx >= 0 && xx < W) ? xin[tab.koff[k]] : 0.f;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s6 = 0; s6 < 6; ++s6) {
+        if (sb + s6 < KS) {
+          const int k = 2 * (sb + s6) + kk;
+          const float b0 = sW[k * FC_CO + i], b1 = sW[k * FC_CO + 32 + i];
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[s6], b0, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[s6], b1, acc[1], 0, 0, 0);
+        }
+      }
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
