@@ -407,7 +407,10 @@ def main():
   # N = 1: the whole step (sobel -> 2 forwards -> loss -> backward -> Adam) is captured once in a
   # HIP graph and replayed -- same kernels, same arithmetic, one launch call per step instead of
   # ~1100 from Python.  N > 1 keeps eager launches (RCCL collectives sit between the kernels).
-  use_graph = world == 1 and not args.no_graph and not args.with_augment
+  # N > 1: same graphs, cut at the collectives (issued eagerly between the segments); IIC_DIST_GRAPH=0
+  # or IIC_DIST_OVERLAP=1 select the eager launch modes.
+  dist_graph = world > 1 and os.environ.get("IIC_DIST_GRAPH", "1") != "0" and os.environ.get("IIC_DIST_OVERLAP", "0") != "1"
+  use_graph = (world == 1 or dist_graph) and not args.no_graph and not args.with_augment
   opt = Adam(net.parameters(), lr=1e-4, capturable=use_graph)
   # the second view (net(all_imgs_tf)) as a parallel graph branch: same kernels and arithmetic,
   # the tail of one view's launch is filled by the other view's next launch
@@ -476,13 +479,31 @@ def main():
       torch.distributed.barrier()
     torch.cuda.synchronize()
 
+  def finish():
+    if world > 1:
+      ops.fold_branch_grads(params)          # .grad += the side view's gradients (one foreach add)
+      idist.all_reduce_grads(params)
+    opt.step()
+
   run = step
+  launch_mode = None
   if use_branch:
     from iic_amd.graph import CapturedPairStep
-    run = CapturedPairStep(lambda: net.forward_packed(sobel_process(imgs, False)),
-                           lambda: net.forward_packed(sobel_process(imgs_tf, False)),
-                           loss_fn, opt.step, lambda: net.zero_grad(set_to_none=True),
-                           warmup=max(1, args.warmup))       # warm-up steps are real steps
+    try:
+      run = CapturedPairStep(lambda: net.forward_packed(sobel_process(imgs, False)),
+                             lambda: net.forward_packed(sobel_process(imgs_tf, False)),
+                             loss_fn, finish, lambda: net.zero_grad(set_to_none=True),
+                             warmup=max(1, args.warmup))       # warm-up steps are real steps
+      launch_mode = "hip-graph replay: %d linear graph segments, the two views on two streams%s" % (
+        4 + len(run.g_l.items) - run.g_l.cuts + len(run.g_opt.items) - run.g_opt.cuts,
+        ", %d collectives issued eagerly between them" % (run.g_l.cuts + run.g_opt.cuts) if world > 1 else "")
+    except Exception as e:      # (N > 1 only: every rank issues the same collectives in either mode)
+      if world == 1:
+        raise
+      sys.stderr.write("rank %d: graph capture failed (%r), eager launches instead\n" % (rank, e))
+      run, use_graph, use_branch = step, False, False
+      for _ in range(args.warmup):
+        last = step()
   elif use_graph:
     from iic_amd.graph import CapturedStep
     run = CapturedStep(step, warmup=max(1, args.warmup))
@@ -536,8 +557,7 @@ def main():
                  "global_batch_pairs": args.pairs * world, "input": "96x96x1 grey -> sobel 2ch",
                  "parallelism": "dp%d" % world, "final_loss": loss_val,
                  "streams": 2 if (use_branch or two_stream) else 1,
-                 "launch": ("hip-graph replay: 6 linear graphs, the two views on two streams" if use_branch
-                            else "hip-graph replay") if use_graph else "eager (python/ctypes)",
+                 "launch": (launch_mode if use_branch else "hip-graph replay") if use_graph else "eager (python/ctypes)",
                  "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps,
                  "host_cpu_ms_per_step": 1e3 * c_enq / args.steps},
     }

@@ -40,10 +40,22 @@ def rank():
   return dist.get_rank(_STATE["group"]) if enabled() else 0
 
 
+# While a train step is being captured into HIP graphs (iic_amd.graph.CapturedPairStep), a
+# collective cannot be recorded as a graph node portably: the capture is CUT there instead -- the
+# graph captured so far is closed, the collective is remembered as an eager call on the same
+# tensor, and a new graph is opened.  Replay = graph, collective, graph, ...  The hook is set by
+# the capturing code only for the duration of the capture.
+_CAPTURE_CUT = [None]
+
+
 def all_reduce_sum_(t):
   """In-place SUM all-reduce (no-op when not distributed)."""
   if enabled():
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_STATE["group"])
+    if _CAPTURE_CUT[0] is not None:
+      grp = _STATE["group"]
+      _CAPTURE_CUT[0](lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=grp))
+    else:
+      dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_STATE["group"])
   return t
 
 

@@ -53,8 +53,63 @@ class CapturedStep(object):
     return self.out
 
 
+class _Segmented(object):
+  """A capture that may be CUT by eager calls (collectives: iic_amd.dist.all_reduce_sum_): a list
+  of linear graphs sharing one memory pool with the eager calls between them, replayed in order
+  on one stream.  With no cut it is exactly one graph."""
+
+  def __init__(self, pool, stream, error_mode):
+    self.pool, self.stream, self.error_mode = pool, stream, error_mode
+    self.items = []
+    self._g = None
+
+  def _begin(self):
+    self._g = torch.cuda.CUDAGraph()
+    self._g.capture_begin(pool=self.pool, capture_error_mode=self.error_mode)
+
+  def _end(self):
+    self._g.capture_end()
+    self.items.append(self._g)
+    self._g = None
+
+  def cut(self, eager_fn):
+    self._end()
+    self.items.append(eager_fn)       # not executed now: its input is only produced at replay
+    self._begin()
+
+  def __enter__(self):
+    from . import dist as idist
+    torch.cuda.synchronize()
+    self._ctx = torch.cuda.stream(self.stream)
+    self._ctx.__enter__()
+    self._prev = idist._CAPTURE_CUT[0]
+    idist._CAPTURE_CUT[0] = self.cut
+    self._begin()
+    return self
+
+  def __exit__(self, et, ev, tb):
+    from . import dist as idist
+    idist._CAPTURE_CUT[0] = self._prev
+    try:
+      self._end()
+    finally:
+      self._ctx.__exit__(et, ev, tb)
+    return False
+
+  def replay(self):
+    for it in self.items:
+      if isinstance(it, torch.cuda.CUDAGraph):
+        it.replay()
+      else:
+        it()
+
+  @property
+  def cuts(self):
+    return sum(1 for it in self.items if not isinstance(it, torch.cuda.CUDAGraph))
+
+
 class CapturedPairStep(object):
-  """The paired step as FIVE linear graphs on two streams:
+  """The paired step as linear graphs on two streams:
 
       [ view A forward ]  ||  [ view B forward ]        (stream 1 || stream 2)
                  loss forward + backward                 (stream 1)
@@ -72,7 +127,14 @@ class CapturedPairStep(object):
 
   view_a(), view_b(): forward of one view -> output tensor (view_b runs as branch 1);
   loss_fn(xa, xb) -> scalar loss; finish(): optimiser step; zero_grad(): drop all gradients
-  (set_to_none).  Inputs are persistent tensors, as for CapturedStep."""
+  (set_to_none).  Inputs are persistent tensors, as for CapturedStep.
+
+  Data parallel (one process per GPU): loss_fn and finish may call iic_amd.dist collectives (the
+  raw-joint all-reduce inside the loss; fold + gradient all-reduce before the optimiser in
+  finish).  Their captures are cut at those calls and the collectives are issued eagerly on
+  stream 1 between the graph segments at replay: the host enqueues ~10 launches per step instead
+  of ~1100, and every rank issues the same collectives in the same order as the eager step does
+  (so a rank that fell back to eager launches stays compatible with ranks that replay)."""
 
   def __init__(self, view_a, view_b, loss_fn, finish, zero_grad, warmup=2):
     from . import ops
@@ -89,24 +151,31 @@ class CapturedPairStep(object):
     ops.clear_branch_grads()
     pool_a, pool_b = torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle()
     G = torch.cuda.CUDAGraph
-    self.g_fa, self.g_fb, self.g_l, self.g_ba, self.g_bb, self.g_opt = G(), G(), G(), G(), G(), G()
-    with torch.cuda.graph(self.g_fa, pool=pool_a, stream=s1):
+    self.g_fa, self.g_fb, self.g_ba, self.g_bb = G(), G(), G(), G()
+    # (a process group's watchdog thread polls events while we capture: thread-local error mode)
+    mode = "thread_local" if torch.distributed.is_available() and torch.distributed.is_initialized() else "global"
+    with torch.cuda.graph(self.g_fa, pool=pool_a, stream=s1, capture_error_mode=mode):
       xa = view_a()
-    with torch.cuda.graph(self.g_fb, pool=pool_b, stream=s2):
+    with torch.cuda.graph(self.g_fb, pool=pool_b, stream=s2, capture_error_mode=mode):
       with ops.on_branch(1, s2):
         xb = view_b()
-    with torch.cuda.graph(self.g_l, pool=pool_a, stream=s1):
+    # the loss and the optimiser phase may contain collectives (data parallel: the raw-joint
+    # all-reduce inside the loss, the gradient all-reduce before the optimiser): captured in
+    # segments cut at those calls (iic_amd.dist._CAPTURE_CUT), the collectives replayed eagerly
+    self.g_l = _Segmented(pool_a, s1, mode)
+    with self.g_l:
       ops.flush_deferred_running()
       xa_d, xb_d = xa.detach().requires_grad_(True), xb.detach().requires_grad_(True)
       loss = loss_fn(xa_d, xb_d)
       loss.backward()
       ga, gb = xa_d.grad, xb_d.grad
       self.out = loss.detach()
-    with torch.cuda.graph(self.g_ba, pool=pool_a, stream=s1):
+    with torch.cuda.graph(self.g_ba, pool=pool_a, stream=s1, capture_error_mode=mode):
       xa.backward(ga)
-    with torch.cuda.graph(self.g_bb, pool=pool_b, stream=s2):
+    with torch.cuda.graph(self.g_bb, pool=pool_b, stream=s2, capture_error_mode=mode):
       xb.backward(gb)
-    with torch.cuda.graph(self.g_opt, pool=pool_a, stream=s1):
+    self.g_opt = _Segmented(pool_a, s1, mode)
+    with self.g_opt:
       finish()
     self._keep = (xa, xb, xa_d, xb_d, ga, gb)     # buffers that cross graph boundaries
     cur.wait_stream(s1)

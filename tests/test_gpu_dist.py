@@ -1,8 +1,9 @@
 """The N > 1 bench path end to end on ONE GPU: two ranks (gloo) share cuda:0.  Functional, not a
 performance number: the sharded raw-joint all-reduce, the gradient all-reduce and the optimiser on
-real device tensors, in both launch modes -- two streams with the side view's gradients folded before
-ONE all-reduce (default) and one stream with the all-reduce overlapped with backward
-(IIC_DIST_OVERLAP=1).  Training is deterministic, so both must print the same final loss."""
+real device tensors, in all launch modes -- graph segments cut at the collectives (default), eager
+launches on two streams with the side view's gradients folded before ONE all-reduce
+(IIC_DIST_GRAPH=0), eager launches on one stream with the all-reduce overlapped with backward
+(IIC_DIST_OVERLAP=1).  Training is deterministic, so all must print the same final loss."""
 import json
 import os
 import socket
@@ -23,20 +24,29 @@ def _free_port():
   return p
 
 
-def _run(overlap):
-  env = dict(os.environ, IIC_DIST_BACKEND="gloo", IIC_DIST_OVERLAP="1" if overlap else "0", PYTHONPATH=ROOT)
+def _run(overlap, graph):
+  env = dict(os.environ, IIC_DIST_BACKEND="gloo", IIC_DIST_OVERLAP="1" if overlap else "0",
+             IIC_DIST_GRAPH="1" if graph else "0", PYTHONPATH=ROOT)
   r = subprocess.run([sys.executable, "-W", "ignore", "-m", "torch.distributed.run", "--nnodes=1",
                       "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
                       os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--pairs", "66",
                       "--no-roofline"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
   lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
   assert r.returncode == 0 and lines, r.stdout[-2000:] + r.stderr[-2000:]
+  assert "graph capture failed" not in r.stderr, r.stderr[-2000:]
   return json.loads(lines[-1])
 
 
 def test_two_rank_bench_modes_agree():
-  a, b = _run(False), _run(True)
-  assert a["n_gpus"] == 2 and a["config"]["streams"] == 2 and b["config"]["streams"] == 1
+  """graph segments with eager collectives between them (the N > 1 default), eager launches on two
+  streams, eager launches on one stream with the overlapped reducer: same training, same loss bits."""
+  g, a, b = _run(False, True), _run(False, False), _run(True, False)
+  assert g["n_gpus"] == 2 and g["config"]["streams"] == 2 and "collectives issued eagerly" in g["config"]["launch"]
+  assert a["n_gpus"] == 2 and a["config"]["streams"] == 2 and a["config"]["launch"].startswith("eager")
+  assert b["config"]["streams"] == 1
   assert a["config"]["global_batch_pairs"] == 132
-  la, lb = a["config"]["final_loss"], b["config"]["final_loss"]
-  assert la == la and la == lb, (la, lb)
+  lg, la, lb = g["config"]["final_loss"], a["config"]["final_loss"], b["config"]["final_loss"]
+  assert la == la and la == lb and lg == la, (lg, la, lb)
+  # (no timing assertion: two gloo ranks time-slicing ONE GPU stall for seconds inside the host-side
+  # collectives between graph segments -- an artefact of this rig; a single process with device-only
+  # stand-ins for the collectives enqueues the cut step in 0.5 ms: tools/graph_cut_probe.py)
