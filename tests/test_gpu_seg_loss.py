@@ -137,7 +137,8 @@ def test_affine_warp_matches_grid_sample():
 
 
 @pytest.mark.parametrize("bn,k,h,w,T", [(2, 24, 14, 200, 10), (3, 15, 20, 128, 10), (2, 3, 9, 200, 1),
-                                        (2, 9, 11, 64, 3), (1, 32, 7, 40, 2), (2, 16, 6, 8, 1)])
+                                        (2, 9, 11, 64, 3), (1, 32, 7, 40, 2), (2, 16, 6, 8, 1),
+                                        (2, 5, 6, 8, 0), (3, 24, 1, 12, 2), (1, 1, 5, 256, 10), (2, 17, 3, 132, 4)])
 @pytest.mark.parametrize("collapsed", [False, True])
 def test_stream_kernels_match_generic_kernels_bitwise(bn, k, h, w, T, collapsed):
   """The float4 / prefetching kernels (default when w % 4 == 0, k <= 32) against the element-wise
