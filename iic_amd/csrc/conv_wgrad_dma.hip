@@ -107,11 +107,17 @@ __device__ __forceinline__ void wd_walk_pixels(const WdWalk& w, const iic_conv_g
   pout = valid ? (n * g.out_Hp + y * g.ty + g.py) * g.out_Wp + x * g.tx + g.px : -1;
 }
 
-template <int COT, int WD_BM, int NBUF, bool ASMRD>
-__global__ __launch_bounds__(WD_THREADS) void conv_wgrad_dma_kernel(
+template <int COT, int WD_BM, int NBUF, bool ASMRD, bool PF>
+__global__ __launch_bounds__(PF ? 256 : WD_THREADS) void conv_wgrad_dma_kernel(
     const iic_conv_geom g, const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
-    float* __restrict__ partials, int nsplit, int num_ktiles, int xb_bytes, int max_tap_off) {
+    float* __restrict__ partials, int nsplit, int num_ktiles, int xb_bytes, int max_tap_off, int abl) {
   constexpr int CS = COT / 64;                  // 32-wide co sub-tiles per wave
+  // PF: 4 fat waves (one per SIMD), each with all 9 taps of its (co half, ci half): 11 operand
+  // fragments feed 18 MFMAs per k-step (22 transposing reads per 18 MFMAs instead of 10 per 6: the
+  // kernel is LDS-read-bound), the next k-step's fragments are read under the current MFMAs.
+  constexpr int NTG = PF ? 1 : 3;               // tap groups = waves / 4
+  constexpr int TPW = 9 / NTG;                  // taps per wave
+  constexpr int NTH = 256 * NTG;                // threads
   constexpr int DROW = COT * 2;                 // dY tile row bytes (256 | 128)
   constexpr int DB = WD_BM * DROW;              // dY tile bytes
   constexpr int DBLK = DB / 1024;
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_dma_kernel(
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tg = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+  const int tg = PF ? 0 : wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
   const int l31 = lane & 31;
   const int q = lane >> 4, i16 = lane & 15;
   const int ncit = g.Cin >> 6;
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_dma_kernel(
   const int kt1 = min(num_ktiles, kt0 + per);
   const int in_pixels = g.N * g.in_Hp * g.in_Wp;
   const int v_tapoff = g.tap_off[lane & (IIC_MAX_TAPS - 1)];
-  const int tfirst = tg * 3;                     // this wave's taps: tfirst .. tfirst + 2
+  const int tfirst = tg * TPW;                   // this wave's taps: tfirst .. tfirst + TPW - 1
 
   // lane constants of the transposing reads (see conv_wgrad.hip::frag_T)
   const int trow = 8 * (q >> 1) + (i16 >> 2);                         // + 16*ks (+4 for rd=1)
@@ -163,9 +169,9 @@ __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_dma_kernel(
   const uint32_t xoff = tsub + wn * 64;
   const int xs32 = wn ? -32 : 32;
 
-  f32x16 acc[3][CS];
+  f32x16 acc[TPW][CS];
 #pragma unroll
-  for (int t = 0; t < 3; ++t)
+  for (int t = 0; t < TPW; ++t)
 #pragma unroll
     for (int c = 0; c < CS; ++c)
 #pragma unroll
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_dma_kernel(
     // DMA of one K-tile: input patch (nblk 1-KB blocks) + dY rows (DBLK blocks) over 12 waves.
     // Every wave issues exactly NI instructions per tile (surplus ones re-fetch the tile's last
     // block: same data to the same address) so that vmcnt counts tiles.
-    const int NI = ((xb_bytes >> 10) + DBLK + WD_THREADS / 64 - 1) / (WD_THREADS / 64);
+    const int NI = ((xb_bytes >> 10) + DBLK + NTH / 64 - 1) / (NTH / 64);
     auto dma_issue = [&](int buf, int kt) {
       const int tab = kt & (WD_NTAB - 1);
       const int plo = __builtin_amdgcn_readfirstlane(s_plo[tab * 2]);
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_dma_kernel(
       unsigned char* const dX = sX + buf * xb_bytes;
       unsigned char* const dD = sD + buf * DB;
       for (int i = 0; i < NI; ++i) {
-        int b = wave + i * (WD_THREADS / 64);
+        int b = wave + i * (NTH / 64);
         b = b < nblk + DBLK ? b : nblk + DBLK - 1;
         if (b < nblk) {
           const int qq = b * 64 + lane;
@@ -253,7 +259,7 @@ __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_dma_kernel(
       const int ahead = min(NBUF - 2, kt1 - 1 - kt);
       wd_wait_vmcnt(ahead * NI);
       __syncthreads();                                    // everyone's share landed; tile kt-1 consumed
-      if (kt + NBUF - 1 < kt1) dma_issue((b + NBUF - 1) % NBUF, kt + NBUF - 1);
+      if (kt + NBUF - 1 < kt1 && !(abl & 1)) dma_issue((b + NBUF - 1) % NBUF, kt + NBUF - 1);   // abl 1: timing only
       tabulate(kt + NBUF);
       const unsigned short* prow = s_prow + (kt & (WD_NTAB - 1)) * WD_BM;
       const uint32_t xb = sXo + b * xb_bytes + xoff;
@@ -265,59 +271,97 @@ __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_dma_kernel(
         rr0[ks] = prow[ks * 16 + trow];
         rr1[ks] = prow[ks * 16 + trow + 4];
       }
+      if (!ASMRD && PF) {
+        // fragments of k-step ks+1 are read while the MFMAs of k-step ks run (two register sets,
+        // the loop is fully unrolled): a wave no longer sits out the LDS round trip of its 10
+        // transposing reads once per k-step
+        // pipeline unit = (k-step, group of 3 taps): dY fragments of the k-step + 3 input fragments.
+        // Unit u+1 is read while unit u's 6 MFMAs run; everything is unrolled (compile-time indices).
+        constexpr int NU = (WD_BM / 16) * 3;
+        bf16x8 fa[2][CS], fb[2][3];
+        auto load_unit = [&](int u) {
+          const int ks = u / 3, gq = u - 3 * ks;
+          if (gq == 0) {
 #pragma unroll
-      for (int ks = 0; ks < WD_BM / 16; ++ks) {
-        bf16x8 a[CS], bfr[3];
-        if (ASMRD) {
-          s16x4 ah[CS][2], bh[3][2];
-#pragma unroll
-          for (int c = 0; c < CS; ++c) {
-            wd_tr_issue(db + ks * 16 * DROW + aoff[c], ah[c][0]);
-            wd_tr_issue(db + (ks * 16 + 4) * DROW + aoff[c], ah[c][1]);
+            for (int c = 0; c < CS; ++c)
+              fa[ks & 1][c] = wd_frag(db + ks * 16 * DROW + aoff[c], db + (ks * 16 + 4) * DROW + aoff[c]);
           }
 #pragma unroll
           for (int t = 0; t < 3; ++t) {
-            const int toff = __builtin_amdgcn_readlane(v_tapoff, tfirst + t);
+            const int toff = __builtin_amdgcn_readlane(v_tapoff, tfirst + 3 * gq + t);
             const int R0 = rr0[ks] + toff, R1 = rr1[ks] + toff;
-            wd_tr_issue(xb + (R0 << 7) + (R0 & 2) * xs32, bh[t][0]);
-            wd_tr_issue(xb + (R1 << 7) + (R1 & 2) * xs32, bh[t][1]);
+            fb[u & 1][t] = wd_frag(xb + (R0 << 7) + (R0 & 2) * xs32, xb + (R1 << 7) + (R1 & 2) * xs32);
           }
-          // all reads of the k-step in flight; wait, and make every fragment depend on the wait
-          if (CS == 2)
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(ah[0][0]), "+v"(ah[0][1]), "+v"(ah[CS - 1][0]), "+v"(ah[CS - 1][1]));
-          else
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[0][0]), "+v"(ah[0][1]));
-          asm volatile("" : "+v"(bh[0][0]), "+v"(bh[0][1]), "+v"(bh[1][0]), "+v"(bh[1][1]),
-                            "+v"(bh[2][0]), "+v"(bh[2][1]));
+        };
+        load_unit(0);
 #pragma unroll
-          for (int c = 0; c < CS; ++c) a[c] = wd_pack(ah[c][0], ah[c][1]);
+        for (int u = 0; u < NU; ++u) {
+          if (u + 1 < NU) load_unit(u + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          const int ks = u / 3, gq = u - 3 * ks;
 #pragma unroll
-          for (int t = 0; t < 3; ++t) bfr[t] = wd_pack(bh[t][0], bh[t][1]);
-        } else {
+          for (int t = 0; t < 3; ++t)
 #pragma unroll
-          for (int c = 0; c < CS; ++c)
-            a[c] = wd_frag(db + ks * 16 * DROW + aoff[c], db + (ks * 16 + 4) * DROW + aoff[c]);
-#pragma unroll
-          for (int t = 0; t < 3; ++t) {
-            const int toff = __builtin_amdgcn_readlane(v_tapoff, tfirst + t);
-            const int R0 = rr0[ks] + toff, R1 = rr1[ks] + toff;
-            bfr[t] = wd_frag(xb + (R0 << 7) + (R0 & 2) * xs32, xb + (R1 << 7) + (R1 & 2) * xs32);
-          }
+            for (int c = 0; c < CS; ++c)
+              acc[3 * gq + t][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][c], fb[u & 1][t],
+                                                                         acc[3 * gq + t][c], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);   // all 10 transposing reads of the k-step in flight
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-          for (int c = 0; c < CS; ++c)
-            acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[c], bfr[t], acc[t][c], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+      } else {
+  #pragma unroll
+        for (int ks = 0; ks < WD_BM / 16; ++ks) {
+          bf16x8 a[CS], bfr[3];
+          if (ASMRD) {
+            s16x4 ah[CS][2], bh[3][2];
+  #pragma unroll
+            for (int c = 0; c < CS; ++c) {
+              wd_tr_issue(db + ks * 16 * DROW + aoff[c], ah[c][0]);
+              wd_tr_issue(db + (ks * 16 + 4) * DROW + aoff[c], ah[c][1]);
+            }
+  #pragma unroll
+            for (int t = 0; t < 3; ++t) {
+              const int toff = __builtin_amdgcn_readlane(v_tapoff, tfirst + t);
+              const int R0 = rr0[ks] + toff, R1 = rr1[ks] + toff;
+              wd_tr_issue(xb + (R0 << 7) + (R0 & 2) * xs32, bh[t][0]);
+              wd_tr_issue(xb + (R1 << 7) + (R1 & 2) * xs32, bh[t][1]);
+            }
+            // all reads of the k-step in flight; wait, and make every fragment depend on the wait
+            if (CS == 2)
+              asm volatile("s_waitcnt lgkmcnt(0)"
+                           : "+v"(ah[0][0]), "+v"(ah[0][1]), "+v"(ah[CS - 1][0]), "+v"(ah[CS - 1][1]));
+            else
+              asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[0][0]), "+v"(ah[0][1]));
+            asm volatile("" : "+v"(bh[0][0]), "+v"(bh[0][1]), "+v"(bh[1][0]), "+v"(bh[1][1]),
+                              "+v"(bh[2][0]), "+v"(bh[2][1]));
+  #pragma unroll
+            for (int c = 0; c < CS; ++c) a[c] = wd_pack(ah[c][0], ah[c][1]);
+  #pragma unroll
+            for (int t = 0; t < 3; ++t) bfr[t] = wd_pack(bh[t][0], bh[t][1]);
+          } else {
+  #pragma unroll
+            for (int c = 0; c < CS; ++c)
+              a[c] = wd_frag(db + ks * 16 * DROW + aoff[c], db + (ks * 16 + 4) * DROW + aoff[c]);
+  #pragma unroll
+            for (int t = 0; t < 3; ++t) {
+              const int toff = __builtin_amdgcn_readlane(v_tapoff, tfirst + t);
+              const int R0 = rr0[ks] + toff, R1 = rr1[ks] + toff;
+              bfr[t] = wd_frag(xb + (R0 << 7) + (R0 & 2) * xs32, xb + (R1 << 7) + (R1 & 2) * xs32);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);   // all 10 transposing reads of the k-step in flight
+  #pragma unroll
+          for (int t = 0; t < 3; ++t)
+  #pragma unroll
+            for (int c = 0; c < CS; ++c)
+              acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[c], bfr[t], acc[t][c], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
   }
   // partial[split][t][co][ci]
 #pragma unroll
-  for (int t = 0; t < 3; ++t) {
+  for (int t = 0; t < TPW; ++t) {
     float* dst = partials + (((long)split * g.ntaps + (tfirst + t)) * g.Cout + co0) * g.Cin + ci0;
 #pragma unroll
     for (int c = 0; c < CS; ++c)
@@ -341,6 +385,16 @@ static long wd_lds(int np, int cot, int bmk, int nbuf) {
 // the waves.  Default stays on the builtin; the switch is kept for the next experiments.
 static int g_wd_asm = 0;
 extern "C" void iic_debug_wgrad_asm(int v) { g_wd_asm = v; }
+// 1: "fat wave" variant -- 4 waves (one per SIMD) with all 9 taps each, 22 transposing reads per 18
+// MFMAs instead of 10 per 6, the next pipeline unit's fragments read under the current MFMAs.
+// Measured (tools/wgrad_ab.sh, per launch incl. the reduce pass): layer2-4 within 2 % of the 12-wave
+// kernel, layer1 28 % slower -- 27 % less LDS-read traffic buys nothing, i.e. the kernel is not
+// LDS-read-bound as round 1 assumed.  Default 0 (12 waves).
+// timing ablation (WRONG results): 1 = no DMA after the prologue (compute-only time of the K loop)
+static int g_wd_ablate = 0;
+extern "C" void iic_debug_wgrad_ablate(int v) { g_wd_ablate = v; }
+static int g_wd_prefetch = 0;
+extern "C" void iic_debug_wgrad_prefetch(int v) { g_wd_prefetch = v; }
 static int g_wd_enabled = 1;     // 0: register-staged kernel, 1: DMA kernel, 3: force 64-pixel K-tiles
 extern "C" void iic_debug_enable_wgrad_dma(int v) { g_wd_enabled = v; }
 
@@ -390,22 +444,25 @@ int iic_wgrad_dma_launch(const iic_conv_geom* g, const void* x, const void* dy, 
   for (int i = 0; i < g->ntaps; ++i) mto = g->tap_off[i] > mto ? g->tap_off[i] : mto;
   dim3 grid((g->Cout / cot) * (g->Cin / 64), nsplit);
   hipStream_t s = (hipStream_t)stream;
-#define WD_LAUNCH2(COT_, BMK_, NBUF_, ASM_)                                                      \
+#define WD_LAUNCH2(COT_, BMK_, NBUF_, ASM_, PF_)                                                 \
   do {                                                                                          \
     static bool attr = false;                                                                   \
     if (!attr) {                                                                                \
       (void)hipFuncSetAttribute(                                                                \
-          reinterpret_cast<const void*>(&conv_wgrad_dma_kernel<COT_, BMK_, NBUF_, ASM_>),       \
+          reinterpret_cast<const void*>(&conv_wgrad_dma_kernel<COT_, BMK_, NBUF_, ASM_, PF_>),  \
           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                              \
       attr = true;                                                                              \
     }                                                                                           \
-    hipLaunchKernelGGL((conv_wgrad_dma_kernel<COT_, BMK_, NBUF_, ASM_>), grid,                  \
-                       dim3(WD_THREADS), lds, s, *g, (const bf16_t*)x, (const bf16_t*)dy,       \
-                       partials, nsplit, kt, xb, mto);                                          \
+    hipLaunchKernelGGL((conv_wgrad_dma_kernel<COT_, BMK_, NBUF_, ASM_, PF_>), grid,             \
+                       dim3(PF_ ? 256 : WD_THREADS), lds, s, *g, (const bf16_t*)x,              \
+                       (const bf16_t*)dy,                                                       \
+                       partials, nsplit, kt, xb, mto, g_wd_ablate);                             \
   } while (0)
 #define WD_LAUNCH(COT_, BMK_, NBUF_)                                                             \
   do {                                                                                          \
-    if (g_wd_asm) WD_LAUNCH2(COT_, BMK_, NBUF_, true); else WD_LAUNCH2(COT_, BMK_, NBUF_, false); \
+    if (g_wd_asm) WD_LAUNCH2(COT_, BMK_, NBUF_, true, false);                                   \
+    else if (g_wd_prefetch) WD_LAUNCH2(COT_, BMK_, NBUF_, false, true);                         \
+    else WD_LAUNCH2(COT_, BMK_, NBUF_, false, false);                                           \
   } while (0)
   if (bmk == 64 && nbuf == 4) {
     if (cot == 128) WD_LAUNCH(128, 64, 4); else WD_LAUNCH(64, 64, 4);
