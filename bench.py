@@ -273,10 +273,19 @@ def bench_segmentation(args):
   mask = (torch.rand(bn, sz, sz, generator=g) < c["mask_p"]).float().to(dev)
   ev = []
 
+  # the two views of a step are independent until the loss: by default the first runs on a side
+  # stream (iic_amd.ops.branch; --no-branch = one stream); same kernels, same arithmetic
+  two_streams = not args.no_branch
+
   def step(timed=False):
     for head in ("A", "B"):
       net.zero_grad(set_to_none=True)
-      a = net(x, head=head)[0]
+      ops.clear_branch_grads()
+      if two_streams:
+        with ops.branch():
+          a = net(x, head=head)[0]
+      else:
+        a = net(x, head=head)[0]
       b = net(xt, head=head)[0]
       a_d, b_d = a.detach().requires_grad_(True), b.detach().requires_grad_(True)
       e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
@@ -321,7 +330,8 @@ def bench_segmentation(args):
                            "mask density %.1f, one head-A step + one head-B step per batch pair "
                            "(segmentation_twohead.py train step), bf16 MFMA convs / fp32 head + loss"
                            % (args.config, sz, sz, c["in_ch"], kA, c["k_B"], bn, T, c["mask_p"]),
-               "launch": "eager (python/ctypes)", "final_loss": float(last.detach())},
+               "launch": "eager (python/ctypes)", "streams": 2 if two_streams else 1,
+               "final_loss": float(last.detach())},
     "roofline": {"bound": "mfma", "kernel": "seg_joint_kernel + 2x seg_grad_kernel (P = sum x1(u+t) x2(u)^T over "
                                             "(2T+1)^2 shifts and its gradient; fp32 MFMA 16x16x4)",
                  "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS,
