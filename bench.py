@@ -514,6 +514,25 @@ def main():
       run, use_graph, use_branch = step, False, False
       for _ in range(args.warmup):
         last = step()
+    if world > 1 and use_branch and os.environ.get("IIC_DIST_GRAPH", "1") != "force":
+      # self-check before the timed region: a replayed step must not be slower than an eager one
+      # (seen only with two gloo ranks time-slicing ONE GPU, where the host-side collectives between
+      # graph segments stall for seconds); all ranks take the same decision
+      def timed2(fn):
+        fence()
+        t = time.perf_counter()
+        for _ in range(2):
+          fn()
+        fence()
+        return time.perf_counter() - t
+      t_graph, t_eager = timed2(run), timed2(step)
+      verdict = torch.tensor([1.0 if t_graph > 1.5 * t_eager else 0.0], device=dev)
+      torch.distributed.all_reduce(verdict, op=torch.distributed.ReduceOp.MAX)
+      if float(verdict) > 0:
+        if rank == 0:
+          sys.stderr.write("graph replay slower than eager launches here (%.1f vs %.1f ms per step): "
+                           "eager launches\n" % (500 * t_graph, 500 * t_eager))
+        run, use_graph, use_branch = step, False, False
   elif use_graph:
     from iic_amd.graph import CapturedStep
     run = CapturedStep(step, warmup=max(1, args.warmup))
