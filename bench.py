@@ -358,6 +358,8 @@ def main():
   ap.add_argument("--steps", type=int, default=10)
   ap.add_argument("--warmup", type=int, default=3)
   ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="pairs per GPU (default 660)")
+  ap.add_argument("--lr", type=float, default=1e-4,
+                  help="Adam learning rate (timing ablations that produce wrong gradients use 0 to keep the weights sane)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-roofline", action="store_true")
   ap.add_argument("--no-graph", action="store_true",
@@ -421,7 +423,7 @@ def main():
   # or IIC_DIST_OVERLAP=1 select the eager launch modes.
   dist_graph = world > 1 and os.environ.get("IIC_DIST_GRAPH", "1") != "0" and os.environ.get("IIC_DIST_OVERLAP", "0") != "1"
   use_graph = (world == 1 or dist_graph) and not args.no_graph and not args.with_augment
-  opt = Adam(net.parameters(), lr=1e-4, capturable=use_graph)
+  opt = Adam(net.parameters(), lr=args.lr, capturable=use_graph)
   # the second view (net(all_imgs_tf)) as a parallel graph branch: same kernels and arithmetic,
   # the tail of one view's launch is filled by the other view's next launch
   use_branch = use_graph and not args.no_branch
