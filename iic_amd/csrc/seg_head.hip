@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restri
 // Potsdam shapes) through a one-wave-per-tile GEMM with strided scalar loads; these kernels read
 // the bf16 window directly (bf16 -> fp32 is exact, products and sums stay fp32 on
 // v_mfma_f32_16x16x4_f32), keep W in LDS and write logits / bf16 feature gradients / per-chunk
-// weight-gradient partials straight from the accumulators.  C % 32 == 0, k <= 32.
+// weight-gradient partials straight from the accumulators.  C = 256 or 512, k <= 32.
 //   m = ((n * Hw) + wy) * Ww + wx   window row,  PT pixel (wy + off, wx + off)
 // ====================================================================================
 __device__ __forceinline__ f32x4 sh_mfma16(float a, float b, f32x4 c) {
@@ -377,11 +377,12 @@ int iic_bilinear_bwd(const float* dout_nchw, float* din_nhwc, int N, int Hl, int
 }
 
 
-/* Fused 10a head on the bf16 PT window (see the kernels): C % 128 == 0, C <= 512, k <= 32.
+/* Fused 10a head on the bf16 PT window (see the kernels): C = 256 or 512, k <= 32.
  * logits [M][k], dlog [M][k] fp32 row-major, M = N*Hw*Ww window rows; w [k][C] fp32.
  * iic_seg_head_wgrad writes iic_seg_head_wgrad_chunks(M) partial matrices [chunk][k][C] (fold them
  * with iic_colsum_f32).  iic_seg_head_bwd_dx writes the interior rows of pt_dx only.            */
-int iic_seg_head_supported(int C, int k) { return C % 128 == 0 && C <= 512 && k >= 1 && k <= 32; }
+// (each of the 4 waves owns C/4 channels in 64-channel groups: C = 256 or 512)
+int iic_seg_head_supported(int C, int k) { return C % 256 == 0 && C <= 512 && k >= 1 && k <= 32; }
 int iic_seg_head_wgrad_chunks(long M) { return (int)((M + SHW_ROWS - 1) / SHW_ROWS); }
 
 int iic_seg_head_fwd(const void* pt, const float* w, float* logits, int N, int Hw, int Ww, int Hp,

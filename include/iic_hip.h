@@ -298,8 +298,8 @@ int iic_seg_window_scatter(const float* in, void* pt, int N, int Hw, int Ww, int
                            int C, void* stream);
 /* Fused 10a head on the bf16 PT feature window (net10a.py:44-59: the 1x1 conv with padding 1, its
  * input gradient and its weight gradient) -- the window is read / written in place, W stays fp32,
- * products and sums are exact fp32 (v_mfma_f32_16x16x4_f32).  Supported: C % 128 == 0, C <= 512,
- * k <= 32 (iic_seg_head_supported); otherwise the gather + iic_gemm_f32 + scatter chain above.
+ * products and sums are exact fp32 (v_mfma_f32_16x16x4_f32).  Supported: C = 256 or 512, k <= 32
+ * (iic_seg_head_supported); otherwise the gather + iic_gemm_f32 + scatter chain above.
  * logits, dlog: fp32 [M][k] row-major, M = N*Hw*Ww; w: fp32 [k][C].
  * iic_seg_head_bwd_dx writes the window's interior rows of pt_dx (bf16) only -- the ring is the
  * conv's zero padding.  iic_seg_head_wgrad writes iic_seg_head_wgrad_chunks(M) partial matrices

@@ -42,15 +42,16 @@ def test_bilinear_forward_backward(Hl, S, k):
   assert float((din.cpu().permute(0, 3, 1, 2) - x.grad).abs().max()) <= 1e-4 * float(x.grad.abs().max())
 
 
-@pytest.mark.parametrize("k,Hf,fused", [(6, 8, True), (6, 8, False), (24, 9, True), (3, 7, True), (15, 10, True)])
-def test_seg_head_forward_backward(k, Hf, fused, monkeypatch):
+@pytest.mark.parametrize("k,Hf,fused,C", [(6, 8, True, 512), (6, 8, False, 512), (24, 9, True, 512), (3, 7, True, 512),
+                                          (15, 10, True, 512), (24, 6, True, 256), (5, 6, True, 128)])
+def test_seg_head_forward_backward(k, Hf, fused, C, monkeypatch):
   """fused: the three head GEMMs on the bf16 PT window (iic_seg_head_*); not fused: gather -> generic
   fp32 GEMM -> scatter.  Both against torch's conv2d(1x1, padding 1) + softmax + bilinear in fp32."""
   from iic_amd import ops
   from iic_amd.archs import seg as seg_mod
   from iic_amd.archs.seg import _SegHeadFn
   monkeypatch.setattr(seg_mod, "FUSED_HEAD", [fused])
-  N, C, S, P = 3, 512, 24, 3
+  N, S, P = 3, 24, 3        # (C = 128 is outside the fused kernels' range: takes the generic chain)
   rng = np.random.default_rng(3)
   f = torch.from_numpy(rng.standard_normal((N, C, Hf, Hf)).astype(np.float32)).relu().to(torch.bfloat16).float()
   w = torch.from_numpy((rng.standard_normal((k, C, 1, 1)) * 0.05).astype(np.float32))
@@ -70,7 +71,7 @@ def test_seg_head_forward_backward(k, Hf, fused, monkeypatch):
   assert _cos(gx, ft.grad) >= 0.9999
   assert xp.grad[:, :P].abs().max() == 0   # gradient of the conv's zero padding is dropped
   assert xp.grad[:, :, -P:].abs().max() == 0 and xp.grad[:, -P:].abs().max() == 0
-  if fused:                                 # the chunked weight gradient is order-fixed: bit-reproducible
+  if fused and C % 256 == 0:                # the chunked weight gradient is order-fixed: bit-reproducible
     xp2 = ops.pt_from_nchw(f.to(d), P).requires_grad_(True)
     wd2 = w.to(d).requires_grad_(True)
     _SegHeadFn.apply(xp2, wd2, P, S).backward(dy.to(d))
