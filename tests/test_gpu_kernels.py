@@ -111,6 +111,40 @@ def test_iid_loss_packed_heads_full_size_and_no_lamb_grad():
         assert np.linalg.norm(mine - ref) / nrm <= max(1e-5, np.linalg.norm(r32 - ref) / nrm)
 
 
+def test_iid_loss_full_size_invariances():
+  """Size-independent properties at the north-star size (660 x 70): the loss is symmetric in the two
+  views (the joint is symmetrised, IID_losses.py:44), invariant to a permutation of the batch rows
+  and to a common relabelling of the classes; the gradients transform accordingly."""
+  from iic_amd.losses import IID_loss
+  from oracle import iid_oracle
+  bn, k = 660, 70
+  z, zt = iid_oracle.make_softmax_pair(bn, k, "trained", 7)
+  Z, ZT = torch.from_numpy(z).to(dev()), torch.from_numpy(zt).to(dev())
+
+  def run(a, b):
+    a, b = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    l, ln = IID_loss(a, b, lamb=1.3)
+    (l + 0.5 * ln).backward()
+    return l.item(), ln.item(), a.grad, b.grad
+
+  l0, n0, ga, gb = run(Z, ZT)
+  tol = 1e-5 * abs(l0) + 2e-7
+  # swap the views
+  l1, n1, gb1, ga1 = run(ZT, Z)
+  assert abs(l1 - l0) <= tol and abs(n1 - n0) <= tol
+  assert float((ga1 - ga).norm() / ga.norm()) <= 1e-5 and float((gb1 - gb).norm() / gb.norm()) <= 1e-5
+  # permute the batch rows
+  perm = torch.randperm(bn, generator=torch.Generator().manual_seed(1)).to(dev())
+  l2, n2, ga2, gb2 = run(Z[perm], ZT[perm])
+  assert abs(l2 - l0) <= tol and abs(n2 - n0) <= tol
+  assert float((ga2 - ga[perm]).norm() / ga.norm()) <= 1e-5
+  # relabel the classes (same permutation in both views)
+  cp = torch.randperm(k, generator=torch.Generator().manual_seed(2)).to(dev())
+  l3, n3, ga3, gb3 = run(Z[:, cp].contiguous(), ZT[:, cp].contiguous())
+  assert abs(l3 - l0) <= tol and abs(n3 - n0) <= tol
+  assert float((gb3 - gb[:, cp]).norm() / gb.norm()) <= 1e-5
+
+
 def test_iid_loss_analytic_pins_and_no_grad():
   from iic_amd.losses import IID_loss
   from oracle import iid_oracle
