@@ -16,7 +16,7 @@ import torch.nn as nn
 from .. import geom as G
 from .. import ops
 from ..dist import shard_batch
-from .cluster import _ConvHolder, _HeadsFn, _bn_buffers, _bn_training
+from .cluster import FUSE_RED, _ConvHolder, _HeadsFn, _bn_buffers, _bn_training
 
 __all__ = ["ClusterNet6c", "ClusterNet6cTwoHead"]
 
@@ -25,7 +25,9 @@ class _StageFn(torch.autograd.Function):
   """conv + BN + ReLU (+ maxpool).  x: NCHW fp32 image (first stage) or PT bf16."""
 
   @staticmethod
-  def forward(ctx, x, w, gamma, beta, st):
+  def forward(ctx, x, w, gamma, beta, st, prev=None, link=None):
+    """prev / link: _Link objects of the trunk's forward (run_stages) -- `prev` describes the stage
+    whose output is this stage's input, `link` is filled in for the next stage."""
     P = st.P
     dev = x.device
     bn = st.bn
@@ -72,6 +74,17 @@ class _StageFn(torch.autograd.Function):
       ctx.branch, ctx.pt_dtype = ops.BRANCH[0], ops.PT_DTYPE[0]
       ctx.dims = (N, H, W, Ho, Wo)
       ctx.training = training
+      ctx.dout_prereduced = False
+      # fused BatchNorm-backward reduction (cluster.FUSE_RED): this stage's backward-data conv produces
+      # the output gradient of the PREVIOUS stage; when that stage has no pool in between, the conv
+      # takes the previous BatchNorm's two sums in its epilogue and the previous stage skips its
+      # reduction pass
+      ctx.red_prev = None
+      if (FUSE_RED[0] and prev is not None and prev.ctx is not None and training and not st.first
+          and ops.PT_DTYPE[0] is not torch.float32):
+        ctx.red_prev = prev
+      if link is not None and training and not st.pool:
+        link.ctx, link.y, link.coef, link.st = ctx, y, coef, st
       ctx.save_for_backward(x, w, gamma, y, a, coef, out if st.pool else None)
     else:
       ops.POOL.release(y)
@@ -98,7 +111,8 @@ class _StageFn(torch.autograd.Function):
       da = dout
     sums = st.holder.stats(dev, "bwd")
     # a = relu(bn(y)) exactly: the ReLU mask is recomputed from (y, coef), a is not read here
-    ops.bn_bwd_reduce(da, None, y, sums, N, Ho, Wo, P, C, mask_coef=coef)
+    if not ctx.dout_prereduced:      # else: the next stage's backward-data conv took these sums
+      ops.bn_bwd_reduce(da, None, y, sums, N, Ho, Wo, P, C, mask_coef=coef)
     bcoef, dgamma, dbeta = ops.bn_bwd_finalize(sums, gamma.detach(), coef, C, cnt)
     dy = ops.pt_alloc(N, Ho, Wo, C, P, dev)
     ops.bn_bwd_apply(da, None, y, bcoef, dy, N, Ho, Wo, P, C, mask_coef=coef)
@@ -112,12 +126,25 @@ class _StageFn(torch.autograd.Function):
     else:
       gf, gb = st.holder.geoms(N, H, W)
       dx = ops.pt_alloc(N, H, W, st.cin, P, dev)
+      w_t = st.holder.weights()[1]
+      red, pl = None, ctx.red_prev
+      if pl is not None and len(gb) == 1 and ops.red_supported(gb[0], w_t):
+        red = (pl.y, pl.coef, pl.st.holder.stats(dev, "bwd"), None, None)
+        pl.ctx.dout_prereduced = True
       for g in gb:
-        ops.conv_igemm(g, dy, st.holder.weights()[1], dx)
+        ops.conv_igemm(g, dy, w_t, dx, red=red)
       dW = ops.conv_wgrad(gf, x, dy, st.K * st.K, True).view(C, st.cin, st.K, st.K)
     for t in (da, dy, y, a):
       ops.POOL.release(t)
-    return dx, dW, dgamma, dbeta, None
+    return dx, dW, dgamma, dbeta, None, None, None
+
+
+class _Link(object):
+  """Per trunk forward: what the next stage needs to know about the stage before it."""
+  __slots__ = ("ctx", "y", "coef", "st")
+
+  def __init__(self):
+    self.ctx = self.y = self.coef = self.st = None
 
 
 class _Stage(object):
@@ -183,8 +210,11 @@ class VGGTrunkHIP(nn.Module):
 
   def run_stages(self, x):
     x = shard_batch(x, self)          # unchanged scripts under torchrun: this rank's pairs only
+    prev = None
     for st in self._stages:
-      x = _StageFn.apply(x, ops.pv(st.conv.weight), ops.pv(st.bn.weight), ops.pv(st.bn.bias), st)
+      link = _Link()
+      x = _StageFn.apply(x, ops.pv(st.conv.weight), ops.pv(st.bn.weight), ops.pv(st.bn.bias), st, prev, link)
+      prev = link
     return x
 
 
