@@ -65,73 +65,107 @@ __device__ __forceinline__ void bl_src(int d, float scale, int in, int& i0, int&
   lam = s - (float)i0;
 }
 
-// out[n][c][y][x] = bilinear(in[n][.][.][c])
+// out[n][c][y][x] = bilinear(in[n][.][.][c]).  One workgroup per output row (n, y): the two input
+// rows it blends are staged in LDS (pixel-major, as they come), then every thread produces outputs
+// that are consecutive in x for one class -- coalesced stores of the NCHW result, which is 4x the
+// input.  (The first version gathered 4 strided values per output element from global memory.)
 __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restrict__ in,
                                                            float* __restrict__ out, int N, int Hl,
                                                            int Wl, int k, int S) {
-  const long total = (long)N * k * S * S;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* s0 = reinterpret_cast<float*>(smem_raw);            // [Wl][k] row y0
+  float* s1 = s0 + Wl * k;                                   // [Wl][k] row y1
   const float sy = (float)Hl / (float)S, sx = (float)Wl / (float)S;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long)gridDim.x * blockDim.x) {
-    const int x = (int)(i % S);
-    long r = i / S;
-    const int y = (int)(r % S);
-    r /= S;
-    const int c = (int)(r % k), n = (int)(r / k);
-    int y0, y1, x0, x1;
-    float ly, lx;
-    bl_src(y, sy, Hl, y0, y1, ly);
+  const int n = blockIdx.x / S, y = blockIdx.x - n * S;
+  int y0, y1;
+  float ly;
+  bl_src(y, sy, Hl, y0, y1, ly);
+  const float* r0 = in + ((long)n * Hl + y0) * Wl * k;
+  const float* r1 = in + ((long)n * Hl + y1) * Wl * k;
+  for (int i = threadIdx.x; i < Wl * k; i += blockDim.x) {
+    s0[i] = r0[i];
+    s1[i] = r1[i];
+  }
+  __syncthreads();
+  float* o = out + (long)n * k * S * S + (long)y * S;
+  for (int i = threadIdx.x; i < k * S; i += blockDim.x) {
+    const int c = i / S, x = i - c * S;
+    int x0, x1;
+    float lx;
     bl_src(x, sx, Wl, x0, x1, lx);
-    const float* b = in + (long)n * Hl * Wl * k + c;
-    const float v00 = b[((long)y0 * Wl + x0) * k], v01 = b[((long)y0 * Wl + x1) * k];
-    const float v10 = b[((long)y1 * Wl + x0) * k], v11 = b[((long)y1 * Wl + x1) * k];
-    out[i] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+    const float v00 = s0[x0 * k + c], v01 = s0[x1 * k + c];
+    const float v10 = s1[x0 * k + c], v11 = s1[x1 * k + c];
+    o[(long)c * S * S + x] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
   }
 }
 
-// din[n][yl][xl][c] = sum over the output pixels whose footprint touches (yl, xl)
+// din[n][yl][xl][c] = sum over the output pixels whose footprint touches (yl, xl).  One workgroup
+// per input row (n, yl): threads walk (class, xl) with xl fastest, so the rows of dout they read are
+// contiguous in x; the results go through LDS to be written pixel-major.  Same summation order per
+// element as the first version (y outer, x inner).
 __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restrict__ dout,
                                                            float* __restrict__ din, int N, int Hl,
                                                            int Wl, int k, int S) {
-  const long total = (long)N * Hl * Wl * k;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* sres = reinterpret_cast<float*>(smem_raw);          // [Wl][k]
   const float sy = (float)Hl / (float)S, sx = (float)Wl / (float)S;
   const float ry = (float)S / (float)Hl, rx = (float)S / (float)Wl;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % k);
-    long r = i / k;
-    const int xl = (int)(r % Wl);
-    r /= Wl;
-    const int yl = (int)(r % Hl), n = (int)(r / Hl);
-    // candidate destination range: src(d) in (l-1, l+1)
-    int ya = (int)floorf(((float)yl - 1.f + 0.5f) * ry - 0.5f) - 1, yb = (int)ceilf(((float)yl + 1.f + 0.5f) * ry - 0.5f) + 1;
-    int xa = (int)floorf(((float)xl - 1.f + 0.5f) * rx - 0.5f) - 1, xb = (int)ceilf(((float)xl + 1.f + 0.5f) * rx - 0.5f) + 1;
-    if (ya < 0) ya = 0;
-    if (xa < 0) xa = 0;
-    if (yb > S - 1) yb = S - 1;
-    if (xb > S - 1) xb = S - 1;
-    const float* g = dout + ((long)n * k + c) * S * S;
-    float acc = 0.f;
-    for (int y = ya; y <= yb; ++y) {
+  const int n = blockIdx.x / Hl, yl = blockIdx.x - n * Hl;
+  // candidate destination rows: src(d) in (yl-1, yl+1)
+  int ya = (int)floorf(((float)yl - 1.f + 0.5f) * ry - 0.5f) - 1, yb = (int)ceilf(((float)yl + 1.f + 0.5f) * ry - 0.5f) + 1;
+  if (ya < 0) ya = 0;
+  if (yb > S - 1) yb = S - 1;
+  // row weights of the candidate rows (the same for the whole workgroup), column weights once per
+  // thread: the footprint loop itself is then multiply-adds only
+  constexpr int BLW = 12;                      // candidate rows / columns per input pixel: < 2 S/Hl + 5
+  float wyv[BLW];
+#pragma unroll
+  for (int j = 0; j < BLW; ++j) {
+    const int y = ya + j;
+    float wy = 0.f;
+    if (y <= yb) {
       int y0, y1;
       float ly;
       bl_src(y, sy, Hl, y0, y1, ly);
-      float wy = 0.f;
       if (y0 == yl) wy += 1.f - ly;
       if (y1 == yl) wy += ly;
-      if (wy == 0.f) continue;
-      for (int x = xa; x <= xb; ++x) {
+    }
+    wyv[j] = wy;
+  }
+  for (int i = threadIdx.x; i < k * Wl; i += blockDim.x) {
+    const int c = i / Wl, xl = i - c * Wl;
+    int xa = (int)floorf(((float)xl - 1.f + 0.5f) * rx - 0.5f) - 1, xb = (int)ceilf(((float)xl + 1.f + 0.5f) * rx - 0.5f) + 1;
+    if (xa < 0) xa = 0;
+    if (xb > S - 1) xb = S - 1;
+    float wxv[BLW];
+#pragma unroll
+    for (int j = 0; j < BLW; ++j) {
+      const int x = xa + j;
+      float wx = 0.f;
+      if (x <= xb) {
         int x0, x1;
         float lx;
         bl_src(x, sx, Wl, x0, x1, lx);
-        float wx = 0.f;
         if (x0 == xl) wx += 1.f - lx;
         if (x1 == xl) wx += lx;
-        if (wx != 0.f) acc += wy * wx * g[(long)y * S + x];
       }
+      wxv[j] = wx;
     }
-    din[i] = acc;
+    const float* g = dout + ((long)n * k + c) * S * S;
+    float acc = 0.f;
+#pragma unroll
+    for (int jy = 0; jy < BLW; ++jy) {
+      if (wyv[jy] == 0.f) continue;
+      const float* gr = g + (long)(ya + jy) * S + xa;
+#pragma unroll
+      for (int jx = 0; jx < BLW; ++jx)
+        if (wxv[jx] != 0.f) acc += wyv[jy] * wxv[jx] * gr[jx];
+    }
+    sres[xl * k + c] = acc;
   }
+  __syncthreads();
+  float* o = din + ((long)n * Hl + yl) * Wl * k;
+  for (int i = threadIdx.x; i < Wl * k; i += blockDim.x) o[i] = sres[i];
 }
 
 // ====================================================================================
@@ -363,19 +397,30 @@ int iic_seg_window_scatter(const float* in, void* pt, int N, int Hw, int Ww, int
 int iic_bilinear_fwd(const float* in_nhwc, float* out_nchw, int N, int Hl, int Wl, int k, int S,
                      void* stream) {
   if (!in_nhwc || !out_nchw || N <= 0 || Hl <= 0 || Wl <= 0 || k <= 0 || S <= 0) return IIC_ERR_ARG;
-  hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(grid_for((long)N * k * S * S)), dim3(256), 0,
-                     (hipStream_t)stream, in_nhwc, out_nchw, N, Hl, Wl, k, S);
+  const size_t lds = (size_t)2 * Wl * k * sizeof(float);
+  if (lds > 64 * 1024) return IIC_ERR_UNSUPPORTED;
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bilinear_fwd_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(N * S), dim3(256), lds, (hipStream_t)stream, in_nhwc,
+                     out_nchw, N, Hl, Wl, k, S);
   return iic_launch_status();
 }
 
 int iic_bilinear_bwd(const float* dout_nchw, float* din_nhwc, int N, int Hl, int Wl, int k, int S,
                      void* stream) {
   if (!dout_nchw || !din_nhwc || N <= 0 || Hl <= 0 || Wl <= 0 || k <= 0 || S <= 0) return IIC_ERR_ARG;
-  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(grid_for((long)N * Hl * Wl * k)), dim3(256), 0,
-                     (hipStream_t)stream, dout_nchw, din_nhwc, N, Hl, Wl, k, S);
+  const size_t lds = (size_t)Wl * k * sizeof(float);
+  if (lds > 64 * 1024) return IIC_ERR_UNSUPPORTED;
+  // (the kernel tabulates 12 candidate rows / columns per input pixel: up-sampling factors up to 3.5)
+  if (2 * S > 7 * Hl || 2 * S > 7 * Wl) return IIC_ERR_UNSUPPORTED;
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bilinear_bwd_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(N * Hl), dim3(256), lds, (hipStream_t)stream,
+                     dout_nchw, din_nhwc, N, Hl, Wl, k, S);
   return iic_launch_status();
 }
-
 
 /* Fused 10a head on the bf16 PT window (see the kernels): C = 256 or 512, k <= 32.
  * logits [M][k], dlog [M][k] fp32 row-major, M = N*Hw*Ww window rows; w [k][C] fp32.
