@@ -152,6 +152,45 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
   for (int j = lane; j < k; j += 64) dlogits[row * k + j] = p[j] * (dp[j] - s);
 }
 
+// k <= 32: G = next power of two >= k lanes per row, 64 / G rows per wave.  The butterflies run
+// over the G lanes of a group only; with the other lanes of the 64-lane version holding 0 / -inf
+// that is the same sequence of additions, so the results are bit-identical to the kernels above
+// (k = 24: 2 rows per wave, k = 3: 16).
+template <int G>
+__global__ __launch_bounds__(256) void softmax_fwd_grouped_kernel(const float* __restrict__ logits,
+                                                                  float* __restrict__ probs, long rows,
+                                                                  int k) {
+  constexpr int RPW = 64 / G;
+  const int lane = threadIdx.x & 63, j = lane % G;
+  const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / G;
+  const bool v = row < rows && j < k;
+  const float x = v ? logits[row * k + j] : -INFINITY;
+  float m = x;
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  const float e = v ? expf(x - m) : 0.f;
+  float s = e;
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (v) probs[row * k + j] = e * (1.f / s);
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void softmax_bwd_grouped_kernel(const float* __restrict__ probs,
+                                                                  const float* __restrict__ dprobs,
+                                                                  float* __restrict__ dlogits, long rows,
+                                                                  int k) {
+  constexpr int RPW = 64 / G;
+  const int lane = threadIdx.x & 63, j = lane % G;
+  const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / G;
+  const bool v = row < rows && j < k;
+  const float p = v ? probs[row * k + j] : 0.f, dp = v ? dprobs[row * k + j] : 0.f;
+  float s = p * dp;
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (v) dlogits[row * k + j] = p * (dp - s);
+}
+
 // out[c] (+)= sum_r A[r][c]
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A,
                                                      float* __restrict__ out, int rows, int cols,
@@ -204,16 +243,26 @@ int iic_gemm_f32_splitk(const float* A, long sam, long sak, const float* B, long
 
 int iic_softmax_fwd(const float* logits, float* probs, int rows, int k, void* stream) {
   if (!logits || !probs || rows <= 0 || k <= 0) return IIC_ERR_ARG;
-  hipLaunchKernelGGL(softmax_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                     logits, probs, rows, k);
+#define SMF(G_)                                                                                   \
+  hipLaunchKernelGGL((softmax_fwd_grouped_kernel<G_>), dim3((rows + 4 * (64 / G_) - 1) / (4 * (64 / G_))), \
+                     dim3(256), 0, (hipStream_t)stream, logits, probs, (long)rows, k)
+  if (k <= 4) SMF(4); else if (k <= 8) SMF(8); else if (k <= 16) SMF(16); else if (k <= 32) SMF(32);
+  else
+    hipLaunchKernelGGL(softmax_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                       logits, probs, rows, k);
   return iic_launch_status();
 }
 
 int iic_softmax_bwd(const float* probs, const float* dprobs, float* dlogits, int rows, int k,
                     void* stream) {
   if (!probs || !dprobs || !dlogits || rows <= 0 || k <= 0) return IIC_ERR_ARG;
-  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                     probs, dprobs, dlogits, rows, k);
+#define SMB(G_)                                                                                   \
+  hipLaunchKernelGGL((softmax_bwd_grouped_kernel<G_>), dim3((rows + 4 * (64 / G_) - 1) / (4 * (64 / G_))), \
+                     dim3(256), 0, (hipStream_t)stream, probs, dprobs, dlogits, (long)rows, k)
+  if (k <= 4) SMB(4); else if (k <= 8) SMB(8); else if (k <= 16) SMB(16); else if (k <= 32) SMB(32);
+  else
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                       probs, dprobs, dlogits, rows, k);
   return iic_launch_status();
 }
 

@@ -680,6 +680,25 @@ def test_heads_forward_backward():
   assert torch.equal(xp2.grad, torch.where(xp.detach() > 0, xp.grad, torch.zeros_like(xp.grad)))
 
 
+@pytest.mark.parametrize("k", [1, 3, 4, 7, 15, 16, 24, 32, 33, 70])
+def test_softmax_rows_forward_backward(k):
+  """Row softmax of the heads (net5g.py:69-71, net10a.py Softmax2d as rows of k): grouped kernels for
+  k <= 32 (several rows per wave), one wave per row above; against torch in float64."""
+  from iic_amd import ops
+  rows = 1000 + k
+  g = torch.Generator().manual_seed(k)
+  x = (torch.randn(rows, k, generator=g) * 3).to(dev())
+  dp = torch.randn(rows, k, generator=g).to(dev())
+  p = ops.softmax_fwd(x, rows, k)
+  dx = ops.softmax_bwd(p, dp, rows, k)
+  x64 = x.double().cpu().requires_grad_(True)
+  p64 = torch.softmax(x64, 1)
+  p64.backward(dp.double().cpu())
+  assert float((p.cpu().double() - p64.detach()).abs().max()) <= 2e-7
+  assert float((p.sum(1) - 1).abs().max()) <= 1e-6
+  assert float((dx.cpu().double() - x64.grad).abs().max()) <= 1e-6 * float(x64.grad.abs().max() + 1)
+
+
 def test_adam_matches_torch():
   from iic_amd.optim import Adam
   d = dev()
