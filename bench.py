@@ -275,13 +275,13 @@ def bench_segmentation(args):
 
   # the two views of a step are independent until the loss: by default the first runs on a side
   # stream (iic_amd.ops.branch; --no-branch = one stream); same kernels, same arithmetic
-  two_streams = not args.no_branch
+  two_streams = [not args.no_branch]
 
   def step(timed=False):
     for head in ("A", "B"):
       net.zero_grad(set_to_none=True)
       ops.clear_branch_grads()
-      if two_streams:
+      if two_streams[0]:
         with ops.branch():
           a = net(x, head=head)[0]
       else:
@@ -304,14 +304,30 @@ def bench_segmentation(args):
   for _ in range(args.warmup):
     step()
   torch.cuda.synchronize()
-  conv = ConvTimer()
-  conv.install()
   t0 = time.perf_counter()
   for _ in range(args.steps):
-    last = step(True)
+    last = step()
   torch.cuda.synchronize()
   dt = (time.perf_counter() - t0) / args.steps
+  # kernel-level rooflines: HIP events around the contraction and around every conv launch, in extra
+  # ONE-stream steps after the timed region (with two streams an event pair also spans whatever the
+  # other view has in flight, and the event records cost GPU bubbles)
+  n_inst = 0 if args.no_roofline else min(args.steps, 2)
+  streams_timed = 2 if two_streams[0] else 1
+  two_streams[0] = False
+  conv = ConvTimer()
+  conv.install()
+  for _ in range(n_inst):
+    step(True)
+  torch.cuda.synchronize()
   conv.uninstall()
+  if n_inst == 0:
+    print(json.dumps({"metric": "paired-images/sec, %s SegmentationNet10aTwoHead + IID_segmentation_loss_uncollapsed" % args.config,
+                      "value": bn / dt, "unit": "paired-images/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                      "ms_per_step": 1e3 * dt, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                      "dtype": "bf16", "data": "synthetic",
+                      "config": {"workload": args.config, "streams": streams_timed, "final_loss": float(last.detach())}}))
+    return
   kA = c["k_A"]
   f_joint = 2.0 * kA * kA * (2 * T + 1) ** 2 * bn * sz * sz          # 2 k^2 (2T+1)^2 bn h w
   ms_f = sum(e[0].elapsed_time(e[1]) for e in ev) / len(ev)
@@ -330,7 +346,7 @@ def bench_segmentation(args):
                            "mask density %.1f, one head-A step + one head-B step per batch pair "
                            "(segmentation_twohead.py train step), bf16 MFMA convs / fp32 head + loss"
                            % (args.config, sz, sz, c["in_ch"], kA, c["k_B"], bn, T, c["mask_p"]),
-               "launch": "eager (python/ctypes)", "streams": 2 if two_streams else 1,
+               "launch": "eager (python/ctypes)", "streams": streams_timed,
                "final_loss": float(last.detach())},
     "roofline": {"bound": "mfma", "kernel": "seg_joint_kernel + 2x seg_grad_kernel (P = sum x1(u+t) x2(u)^T over "
                                             "(2T+1)^2 shifts and its gradient; fp32 MFMA 16x16x4)",
@@ -338,13 +354,15 @@ def bench_segmentation(args):
                  "traffic": None, "algorithmic_flops_per_launch": f_joint,
                  "algorithmic_bytes": abytes, "arithmetic_intensity_flop_per_byte": 3.0 * f_joint / abytes,
                  "joint_fwd_ms": ms_f, "grad_bwd_ms": ms_b,
+                 "timed_in": "%d instrumented one-stream steps after the timed region" % n_inst,
                  "hbm_floor_ms": abytes / 8e12 * 1e3, "mfma_floor_ms": 3.0 * f_joint / (FP32_MFMA_PEAK_TFLOPS * 1e12) * 1e3},
   }
   if cs:
     out["roofline_conv"] = {"bound": "mfma", "kernel": "conv_igemm family (fwd + bwd-data), bf16 MFMA",
                             "achieved": cs["tflops"], "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": cs["tflops"] / BF16_PEAK_TFLOPS, "launches_timed": cs["launches"],
-                            "kernel_ms_per_step": cs["total_ms"] / args.steps}
+                            "kernel_ms_per_step": cs["total_ms"] / n_inst,
+                            "timed_in": "%d instrumented one-stream steps after the timed region" % n_inst}
   print(json.dumps(out))
 
 
