@@ -436,7 +436,7 @@ def main():
       torch.distributed.broadcast(p.data, 0)
   # N = 1: the whole step (sobel -> 2 forwards -> loss -> backward -> Adam) is captured once in a
   # HIP graph and replayed -- same kernels, same arithmetic, one launch call per step instead of
-  # ~1100 from Python.  N > 1 keeps eager launches (RCCL collectives sit between the kernels).
+  # ~1100 from Python.
   # N > 1: same graphs, cut at the collectives (issued eagerly between the segments); IIC_DIST_GRAPH=0
   # or IIC_DIST_OVERLAP=1 select the eager launch modes.
   dist_graph = world > 1 and os.environ.get("IIC_DIST_GRAPH", "1") != "0" and os.environ.get("IIC_DIST_OVERLAP", "0") != "1"
@@ -448,8 +448,8 @@ def main():
   # weak scaling: every rank owns `pairs` pairs (its shard of the global batch of pairs*world)
   imgs, imgs_tf = make_batch(args.pairs, INPUT_SZ, dev, seed=rank)
   params = list(net.parameters())
-  # N > 1: gradient all-reduce overlapped with backward (IIC_DIST_OVERLAP=0: after backward)
-  # N > 1 (eager launches): by default the two views run on two streams (measured at N = 1:
+  # N > 1 with eager launches (IIC_DIST_GRAPH=0, or after a failed capture / self-check): by default
+  # the two views run on two streams (measured at N = 1:
   # 42.0 -> 38.0 ms without graphs); the side view's gradients are folded into .grad after backward
   # and ONE bucketed SUM all-reduce follows.  IIC_DIST_OVERLAP=1 selects the round-1 mode instead:
   # one stream, gradient all-reduce overlapped with backward through post-accumulate hooks.
