@@ -81,9 +81,20 @@ __global__ __launch_bounds__(GATHER ? 256 : 768) void conv_wgrad_kernel(
   const int l31 = lane & 31, g5 = lane >> 5;
   const int q = lane >> 4, i16 = lane & 15;
   const int ncit = g.Cin >> 6;
-  const int cot = blockIdx.x / ncit, cit = blockIdx.x - cot * ncit;
+  // XCD-aware work mapping (as in conv_wgrad_dma.hip): workgroups are dealt to the 8 XCDs round-robin
+  // by linear id, and all (co, ci) tiles of one K-split read the same input patch / dY rows -- when
+  // the split count divides by 8, one XCD walks the tiles of a split before moving to its next
+  // split, so those re-reads hit its L2 (measured at the 10a shapes: 2.6 GB of HBM traffic per
+  // launch for ~1 GB of operands before the remap)
+  int tile = blockIdx.x, split = blockIdx.y;
+  if ((gridDim.y & 7) == 0) {
+    const int L = blockIdx.y * gridDim.x + blockIdx.x;
+    const int xcd = L & 7, j = L >> 3;
+    tile = j % (int)gridDim.x;
+    split = xcd + 8 * (j / (int)gridDim.x);
+  }
+  const int cot = tile / ncit, cit = tile - cot * ncit;
   const int co0 = cot * COT, ci0 = cit * 64;
-  const int split = blockIdx.y;
   const int per = (num_ktiles + nsplit - 1) / nsplit;
   const int kt0 = split * per;
   const int kt1 = min(num_ktiles, kt0 + per);
