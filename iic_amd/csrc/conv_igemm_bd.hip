@@ -21,9 +21,23 @@
 #include "conv_tile.h"
 #include "../../include/iic_hip.h"
 
+// B-fragment loads as inline asm: invisible to hipcc's vmcnt bookkeeping, so that the K loop can keep
+// exactly 8 of them in flight behind hand-counted waits while its LDS reads sit BETWEEN the MFMAs (a
+// compiler-visible load would be waited for conservatively at the loop header, see bd_bwait).
+__device__ __forceinline__ void bd_bload(u32x4& d, const unsigned char* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory");
+}
+// wait until at most N vector-memory operations of this wave are outstanding; `d` (the fragment the
+// wait is for) becomes opaque here, so no consumer of it can be scheduled above the wait
+template <int N>
+__device__ __forceinline__ void bd_bwait(u32x4& d) {
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(d) : "i"(N) : "memory");
+}
+
 #define BD_BM 256
 #define BD_BN 128
 #define BD_THREADS 256
+#define BD_PROF_SLOTS 16
 #ifndef BD_STORE_UB
 #define BD_STORE_UB 8      // rows per thread whose epilogue loads are in flight together (16 per tile)
 #endif
@@ -56,8 +70,29 @@ __global__ __launch_bounds__(BD_THREADS, (MS == 4 ? 2 : 3)) void conv_igemm_bd_k
     bf16_t* __restrict__ out, float* __restrict__ stats, const bf16_t* __restrict__ res_grad,
     const bf16_t* __restrict__ res_act, int accumulate, int num_mtiles, int lds_a_bytes,
     int dense_key, const bf16_t* __restrict__ red_y, const float* __restrict__ red_coef,
-    const bf16_t* __restrict__ red_y2, float* __restrict__ red_stats, float* __restrict__ red_stats2) {
+    const bf16_t* __restrict__ red_y2, float* __restrict__ red_stats, float* __restrict__ red_stats2,
+    unsigned long long* __restrict__ prof, int stagger) {
   constexpr int CLD = BD_BN + 8;
+  constexpr bool PROF = (ABL & 128) != 0;
+  constexpr bool NEWORD = (ABL & 256) == 0;     // ABL bit 256: the round-2 K-loop order (A/B runs)
+  // PROF (ABL bit 128, results CORRECT): wave 0 stamps s_memtime at the phase boundaries of its tile
+  // into prof[blockIdx][BD_PROF_SLOTS] (tools/bd_timeline.py decodes them)
+  unsigned long long t_stamp[8];
+  unsigned long long t_bsum = 0, t_b0 = 0;
+  int t_nb = 0;
+  if (PROF) t_stamp[0] = __builtin_readcyclecounter();
+  // Stagger (stagger > 0 cycles): the two workgroups that share a CU start together and do identical
+  // work, so their prologues, chunk-boundary reloads and epilogues coincide instead of hiding behind
+  // each other's MFMA loops.  The workgroup in the odd threadgroup slot of its CU (HW_ID.TG_ID) of the
+  // FIRST dispatch round waits `stagger` cycles once; later workgroups inherit the offset from the
+  // slot they take over.
+  if (stagger > 0 && (int)blockIdx.x < 2 * 256) {
+    const unsigned hw = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 16 << 6 | 4);     // HW_ID.TG_ID
+    if (hw & 1u) {
+      const unsigned long long t_go = __builtin_readcyclecounter() + (unsigned long long)stagger;
+      while (__builtin_readcyclecounter() < t_go) __builtin_amdgcn_s_sleep(16);
+    }
+  }
   constexpr int BM = MS * 64, WR = MS * 32;     // workgroup tile rows, rows per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned char* sA = smem_raw;                                   // [NP256][ROWB]
@@ -153,6 +188,7 @@ __global__ __launch_bounds__(BD_THREADS, (MS == 4 ? 2 : 3)) void conv_igemm_bd_k
   };
 
   // ---- prologue ------------------------------------------------------------------------
+  if (PROF) t_stamp[1] = __builtin_readcyclecounter();
   u32x4 Bc[4][2];
   {
     const unsigned char* p = frag_ptr(0, 0);
@@ -160,7 +196,8 @@ __global__ __launch_bounds__(BD_THREADS, (MS == 4 ? 2 : 3)) void conv_igemm_bd_k
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int ns = 0; ns < 2; ++ns)
-        Bc[ks][ns] = *reinterpret_cast<const u32x4*>(p + ns * 4096 + ks * 1024);
+        if (NEWORD) bd_bload(Bc[ks][ns], p + ns * 4096 + ks * 1024);
+        else Bc[ks][ns] = *reinterpret_cast<const u32x4*>(p + ns * 4096 + ks * 1024);
   }
   if (DMA) {
     dma_patch(0);
@@ -169,6 +206,7 @@ __global__ __launch_bounds__(BD_THREADS, (MS == 4 ? 2 : 3)) void conv_igemm_bd_k
     igemm_load_patch<GATHER, BD_THREADS, 16>(sA, in, g.Cin, 0, p_lo, npix, in_pixels, s_pin, tid);
   }
   __syncthreads();
+  if (PROF) t_stamp[2] = __builtin_readcyclecounter();
 
   // ---- main loop: flat (chunk, tap) iterations; barriers only when the chunk changes ------
   // Software pipeline, explicit so that the register allocator cannot fold it away:
@@ -217,21 +255,50 @@ __global__ __launch_bounds__(BD_THREADS, (MS == 4 ? 2 : 3)) void conv_igemm_bd_k
         knext[ms] = 0;
       }
     }
+    auto a_read = [&](int ks, int nxt, int cur, int ms) {
+      if (!(ABL & 16)) {
+        if (DMA)
+          a[nxt][ms] = (ks < 3) ? *reinterpret_cast<const bf16x8*>(sA + pcur[ms] + (((ks + 1) << 5) ^ kcur[ms]))
+                                : *reinterpret_cast<const bf16x8*>(sA + pnext[ms] + knext[ms]);
+        else
+          a[nxt][ms] = (ks < 3) ? *reinterpret_cast<const bf16x8*>(sA + pcur[ms] + (ks + 1) * 32)
+                                : *reinterpret_cast<const bf16x8*>(sA + pnext[ms]);
+      } else {
+        a[nxt][ms] = a[cur][ms];
+      }
+    };
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int cur = ks & 1, nxt = cur ^ 1;
+      if (NEWORD) {
+        // Round 3 (tools/mfma_feed.py): [4 reads][8 MFMAs][2 loads] blocks leave the matrix pipe idle
+        // while a wave works through its feeder block; one LDS read between consecutive MFMAs keeps
+        // both pipes issuing (+5...14 % in the staged microbenchmark at these loop lengths).
+        // ns-major MFMA order: Bc[ks][0] is free after the first MS MFMAs and is re-filled there.
+        // In flight at the top of a k-step: the 8 loads of the next four k-steps, oldest first.
+        bd_bwait<7>(Bc[ks][0]);
+        __builtin_amdgcn_sched_barrier(0);
+        const bf16x8 b0 = __builtin_bit_cast(bf16x8, Bc[ks][0]);
 #pragma unroll
-      for (int ms = 0; ms < MS; ++ms)
-        if (!(ABL & 16)) {
-          if (DMA)
-            a[nxt][ms] = (ks < 3) ? *reinterpret_cast<const bf16x8*>(sA + pcur[ms] + (((ks + 1) << 5) ^ kcur[ms]))
-                                  : *reinterpret_cast<const bf16x8*>(sA + pnext[ms] + knext[ms]);
-          else
-            a[nxt][ms] = (ks < 3) ? *reinterpret_cast<const bf16x8*>(sA + pcur[ms] + (ks + 1) * 32)
-                                  : *reinterpret_cast<const bf16x8*>(sA + pnext[ms]);
-        } else {
-          a[nxt][ms] = a[cur][ms];
+        for (int ms = 0; ms < MS; ++ms) {
+          acc[ms][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][ms], b0, acc[ms][0], 0, 0, 0);
+          a_read(ks, nxt, cur, ms);
+          __builtin_amdgcn_sched_barrier(0);
         }
+        bd_bwait<6>(Bc[ks][1]);
+        bd_bload(Bc[ks][0], nb + ks * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+        const bf16x8 b1 = __builtin_bit_cast(bf16x8, Bc[ks][1]);
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+          acc[ms][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][ms], b1, acc[ms][1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        bd_bload(Bc[ks][1], nb + 4096 + ks * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+        continue;
+      }
+#pragma unroll
+      for (int ms = 0; ms < MS; ++ms) a_read(ks, nxt, cur, ms);
       __builtin_amdgcn_sched_barrier(0);   // reads of the NEXT k-step issue before these MFMAs
       const bf16x8 b0 = __builtin_bit_cast(bf16x8, Bc[ks][0]);
       const bf16x8 b1 = __builtin_bit_cast(bf16x8, Bc[ks][1]);
@@ -250,6 +317,7 @@ __global__ __launch_bounds__(BD_THREADS, (MS == 4 ? 2 : 3)) void conv_igemm_bd_k
       kcur[ms] = knext[ms];
     }
     if (more && tn == 0 && !(ABL & 8)) {       // next iteration starts a new channel chunk
+      if (PROF) t_b0 = __builtin_readcyclecounter();
       __syncthreads();           // everyone is done reading the patch
       if (!(ABL & 1)) {
         if (DMA)
@@ -258,6 +326,7 @@ __global__ __launch_bounds__(BD_THREADS, (MS == 4 ? 2 : 3)) void conv_igemm_bd_k
           igemm_load_patch<GATHER, BD_THREADS, BD_RELOAD_NB>(sA, in, g.Cin, cn * 64, p_lo, npix, in_pixels, s_pin, tid);
       }
       __syncthreads();
+      if (PROF) { t_bsum += __builtin_readcyclecounter() - t_b0; ++t_nb; }
 #pragma unroll
       for (int ms = 0; ms < MS; ++ms)
         a[0][ms] = *reinterpret_cast<const bf16x8*>(sA + pcur[ms] + (DMA ? kcur[ms] : 0));
@@ -266,7 +335,11 @@ __global__ __launch_bounds__(BD_THREADS, (MS == 4 ? 2 : 3)) void conv_igemm_bd_k
     chunk = cn;
   }
 
+  // the ring re-fills unconditionally (the last iteration's loads are never used): hipcc does not know
+  // about them and would hand their destination registers to the epilogue while they are in flight
+  if (NEWORD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   // ---- epilogue ------------------------------------------------------------------------
+  if (PROF) t_stamp[3] = __builtin_readcyclecounter();
   if (ABL & 4) {
     float t = 0.f;   // keep every accumulator live
 #pragma unroll
@@ -328,6 +401,7 @@ __global__ __launch_bounds__(BD_THREADS, (MS == 4 ? 2 : 3)) void conv_igemm_bd_k
         sC[row * CLD + col] = f32_to_bf16(acc[ms][ns][r]);
       }
   __syncthreads();
+  if (PROF) t_stamp[4] = __builtin_readcyclecounter();
   TileRed tr;
   if (RED) tile_red_zero(tr);
   if (!(ABL & 32))
@@ -336,6 +410,16 @@ __global__ __launch_bounds__(BD_THREADS, (MS == 4 ? 2 : 3)) void conv_igemm_bd_k
   if (RED)
     igemm_red_finish<BD_BN, BD_THREADS, RED>(tr, reinterpret_cast<float*>(smem_raw), red_stats, red_stats2,
                                              g.Cout, n0, tid);
+  if (PROF && prof && tid == 0) {
+    unsigned long long* q = prof + (long)blockIdx.x * BD_PROF_SLOTS;
+    const unsigned long long t_end = __builtin_readcyclecounter();
+    q[0] = t_stamp[0]; q[1] = t_stamp[1]; q[2] = t_stamp[2]; q[3] = t_stamp[3]; q[4] = t_stamp[4];
+    q[5] = t_end; q[6] = t_bsum; q[7] = (unsigned long long)t_nb;
+    q[8] = (unsigned long long)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4)     // HW_REG_HW_ID
+           | ((unsigned long long)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) << 32);  // XCC_ID
+    q[9] = (unsigned long long)tix;
+    q[10] = __builtin_amdgcn_s_memrealtime();
+  }
 }
 
 // fp32 OIHW -> bf16 MFMA-B-fragment order.  mode 0 (forward operand): GEMM N = Cout, K = Cin;
@@ -366,6 +450,12 @@ int iic_p64_launch(const iic_conv_geom* g, const void* in, const void* wfrag, vo
                    const void* res_grad, const void* res_act, int accumulate, const void* red_y,
                    const float* red_coef, const void* red_y2, float* red_stats, float* red_stats2,
                    void* stream);
+// conv_igemm_bd2.hip: third generation (half-chunk double-buffered patch, interleaved K loop)
+int iic_bd2_supported(const iic_conv_geom* g, int ms);
+int iic_bd2_launch(const iic_conv_geom* g, const void* in, const void* wfrag, void* out, float* stats,
+                   const void* res_grad, const void* res_act, int accumulate, const void* red_y,
+                   const float* red_coef, const void* red_y2, float* red_stats, float* red_stats2,
+                   int dense_key, unsigned long long* prof, void* stream);
 static int g_bd_one_wg = 1;      // also take LDS footprints that leave room for only one workgroup per CU
                                  // (large-image segmentation layers: still 15-20 % faster than conv_igemm_kernel)
 extern "C" void iic_debug_bd_one_wg(int v) { g_bd_one_wg = v; }
@@ -376,6 +466,11 @@ extern "C" void iic_debug_p64_red(int v) { g_p64_red = v; }
 
 extern "C" {
 
+static unsigned long long* g_bd_prof = nullptr;   // iic_debug_set_ablate(128): per-workgroup phase stamps go here
+extern "C" void iic_debug_bd_prof(void* buf) { g_bd_prof = (unsigned long long*)buf; }
+extern "C" int iic_debug_bd_prof_slots(void) { return BD_PROF_SLOTS; }
+static int g_bd_stagger = 0;    // cycles per tap by which odd-slot workgroups of the first round start late (0 = off)
+extern "C" void iic_debug_bd_stagger(int v) { g_bd_stagger = v; }
 static int g_bd_dma = 1;        // 1: LDS-DMA patch loads (128-B swizzled rows), 0: register-staged (144-B rows)
 extern "C" void iic_debug_bd_dma(int v) { g_bd_dma = v; }
 
@@ -455,6 +550,12 @@ int iic_conv_igemm_frag_red(const iic_conv_geom* g, const void* in, const void* 
     return iic_p64_launch(g, in, wfrag, out, stats, res_grad, res_act, accumulate, red_y, red_coef, red_y2,
                           red_stats, red_stats2, stream);
   }
+  {
+    const int abl = iic_debug_get_ablate();
+    if (g->ntaps > 1 && g_bd_dma && g_bd_ms != 2 && (abl == 0 || abl == 128) && iic_bd2_supported(g, 4))
+      return iic_bd2_launch(g, in, wfrag, out, stats, res_grad, res_act, accumulate, red_y, red_coef, red_y2,
+                            red_stats, red_stats2, g_bd_dense_key, abl == 128 ? g_bd_prof : nullptr, stream);
+  }
   const long M = igemm_rows_host(g);
   if (M <= 0) return IIC_ERR_ARG;
   if (M >= (1L << 31) || (long)g->N * g->in_Hp * g->in_Wp >= (1L << 31)) return IIC_ERR_UNSUPPORTED;
@@ -479,15 +580,15 @@ int iic_conv_igemm_frag_red(const iic_conv_geom* g, const void* in, const void* 
                        (const unsigned char*)wfrag, (bf16_t*)out, stats, (const bf16_t*)res_grad, \
                        (const bf16_t*)res_act, accumulate, mt, la, g_bd_dense_key,               \
                        (const bf16_t*)red_y, red_coef, (const bf16_t*)red_y2, red_stats,         \
-                       red_stats2);                                                              \
+                       red_stats2, g_bd_prof, g_bd_stagger * (g->ntaps > 1 ? g->ntaps : 0));     \
   } while (0)
 #define BD_LAUNCH3(GA_, AB_, DM_, MS_)                                                            \
   do {                                                                                           \
-    if (AB_ != 0 || GA_ || red == 0) {                                                           \
+    if ((AB_ != 0 && AB_ != 128 && AB_ != 256) || GA_ || red == 0) {                                           \
       if (red != 0) return IIC_ERR_UNSUPPORTED;                                                  \
       BD_LAUNCH4(GA_, AB_, DM_, MS_, 0);                                                         \
-    } else if (red == 1) BD_LAUNCH4(false, 0, DM_, MS_, 1);                                      \
-    else BD_LAUNCH4(false, 0, DM_, MS_, 2);                                                      \
+    } else if (red == 1) BD_LAUNCH4(false, (AB_ == 128 || AB_ == 256 ? AB_ : 0), DM_, MS_, 1);                 \
+    else BD_LAUNCH4(false, (AB_ == 128 || AB_ == 256 ? AB_ : 0), DM_, MS_, 2);                                 \
   } while (0)
 #define BD_LAUNCH2(GA_, AB_, DM_)                                                                 \
   do {                                                                                           \
@@ -510,6 +611,8 @@ int iic_conv_igemm_frag_red(const iic_conv_geom* g, const void* in, const void* 
     case 32: BD_LAUNCH(false, 32); break;
     case 64: BD_LAUNCH(false, 64); break;
     case 96: BD_LAUNCH(false, 96); break;
+    case 128: BD_LAUNCH(false, 128); break;
+    case 256: BD_LAUNCH(false, 256); break;
     default: BD_LAUNCH(false, 0); break;
   }
   return iic_launch_status();

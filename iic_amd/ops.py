@@ -130,6 +130,8 @@ class branch(object):
     BRANCH[0] = 0
     self.ctx.__exit__(*exc)
     _PENDING_JOIN.append((self.main, self.side))    # joined later: the main view runs meanwhile
+    if exc and exc[0] is not None:
+      join()            # the forward raised: nobody downstream will join -- do not leave the fork pending
     return False
 
 
@@ -162,13 +164,25 @@ class on_branch(object):
 # the outputs of the first forward must not be consumed by anything but this library's losses
 # before the join (true of every reference script); evaluation / no_grad forwards never branch.
 AUTO_BRANCH = [os.environ.get("IIC_AUTO_BRANCH", "0") == "1"]
+# forwards that hand back FEATURES (semisup heads: sup_head5.py:34-35, net6c_two_head.py:78-94,
+# k-means feature extraction) are consumed by modules outside this library, which know nothing about
+# the side stream: they never branch
+_FEATURE_FLAGS = ("trunk_features", "penultimate_features", "kmeans_use_features")
+# running-statistic updates postponed by branch forwards (bn_finalize): flushed at every join; the
+# optimiser and the losses join.  A caller that does neither would grow the list without bound and
+# evaluate on stale running statistics -- past this many entries the next forward joins by itself.
+_DEFERRED_LIMIT = 1024
 
 
 def auto_branch(fwd):
   """Decorator for the architectures' forward()."""
   def wrapped(self, x, *a, **k):
+    if BRANCH[0] == 0 and (_PENDING_JOIN or _DEFERRED_RUNNING) and (
+        not self.training or not torch.is_grad_enabled() or len(_DEFERRED_RUNNING) > _DEFERRED_LIMIT):
+      join()      # evaluation must see up-to-date running statistics; bound the postponed list
     if (AUTO_BRANCH[0] and self.training and torch.is_grad_enabled() and BRANCH[0] == 0
-        and not _PENDING_JOIN and torch.is_tensor(x) and x.is_cuda):
+        and not _PENDING_JOIN and torch.is_tensor(x) and x.is_cuda
+        and not any(k.get(f) for f in _FEATURE_FLAGS)):
       with branch(proxies=False) as br:
         x.record_stream(br.side)         # allocated on the caller's stream, consumed on the side stream
         return fwd(self, x, *a, **k)

@@ -88,13 +88,13 @@ class Adam(torch.optim.Optimizer):
     VP = ctypes.c_void_p * n
     LP = ctypes.c_long * n
     g2 = [Adam._branch_grad(p) for p in grp]
-    keep = [t for t in g2 if t is not None]       # (alive until the launch is enqueued)
-    return (n, VP(*[p.data_ptr() for p in grp]),
-            VP(*[p.grad.data_ptr() if p.grad is not None else None for p in grp]),
-            VP(*[t.data_ptr() if t is not None else None for t in g2]) if keep else None,
-            VP(*[state[p]["exp_avg"].data_ptr() for p in grp]),
-            VP(*[state[p]["exp_avg_sq"].data_ptr() for p in grp]),
-            LP(*[p.numel() for p in grp]))
+    keep = [t for t in g2 if t is not None]       # contiguous copies must outlive the launch call
+    return keep, (n, VP(*[p.data_ptr() for p in grp]),
+                  VP(*[p.grad.data_ptr() if p.grad is not None else None for p in grp]),
+                  VP(*[t.data_ptr() if t is not None else None for t in g2]) if keep else None,
+                  VP(*[state[p]["exp_avg"].data_ptr() for p in grp]),
+                  VP(*[state[p]["exp_avg_sq"].data_ptr() for p in grp]),
+                  LP(*[p.numel() for p in grp]))
 
   def _counter_groups(self, ps):
     """Capturable mode: partition `ps` into groups that share one device step counter.  A
@@ -122,12 +122,22 @@ class Adam(torch.optim.Optimizer):
       groups.append((c, grp))
     return groups
 
+  def zero_grad(self, set_to_none=True):
+    """Also drops the gradients the side branches accumulated through the parameters' leaf aliases
+    (iic_amd.ops.branch): a branched step followed by an un-branched one must not see them again."""
+    super(Adam, self).zero_grad(set_to_none=set_to_none)
+    ops.clear_branch_grads()
+
   @torch.no_grad()
   def step(self, closure=None):
     loss = None
     if closure is not None:
       with torch.enable_grad():
         loss = closure()
+    # a forward forked by ops.branch / ops.auto_branch that no loss of this library consumed (e.g. a
+    # semi-supervised head with cross-entropy) is joined here at the latest: the side stream's
+    # gradients must have landed, and its postponed running-statistic updates are applied
+    ops.join()
     for group in self.param_groups:
       ps = [p for p in group["params"] if p.grad is not None or ops.branch_grads(p)]
       if not ps:
@@ -138,8 +148,9 @@ class Adam(torch.optim.Optimizer):
                float(group["eps"]))
       if self.capturable:
         for counter, grp in self._counter_groups(ps):
-          check(lib().iic_adam_step_dev(*self._tables(grp, self.state), *hyper,
-                                        counter.data_ptr(), stream_ptr()), "iic_adam_step_dev")
+          keep, tab = self._tables(grp, self.state)
+          check(lib().iic_adam_step_dev(*tab, *hyper, counter.data_ptr(), stream_ptr()), "iic_adam_step_dev")
+          del keep
         continue
       # torch.optim.Adam keeps a step count PER PARAMETER: a two-head net only produces
       # gradients for the head that was used (net5g_two_head.py:62-81), so head-A and head-B
@@ -149,8 +160,9 @@ class Adam(torch.optim.Optimizer):
         by_step.setdefault(self.state[p]["step"], []).append(p)
       for step0, grp in by_step.items():
         step = step0 + 1
-        check(lib().iic_adam_step(*self._tables(grp, self.state), *hyper, step, stream_ptr()),
-              "iic_adam_step")
+        keep, tab = self._tables(grp, self.state)
+        check(lib().iic_adam_step(*tab, *hyper, step, stream_ptr()), "iic_adam_step")
+        del keep
         for p in grp:
           self.state[p]["step"] = step
     bump_weights_epoch()
