@@ -65,13 +65,13 @@ __device__ __forceinline__ void bd_bwait(u32x4& d) {
 // per-tile prologue / epilogue where the K loop is short, i.e. few input channels).
 // RED: fused BatchNorm-backward reduction over the stored tile (conv_tile.h), 0 = off.
 template <bool GATHER, int ABL, bool DMA, int MS, int RED>
-__global__ __launch_bounds__(BD_THREADS, (MS == 4 ? 2 : 3)) void conv_igemm_bd_kernel(
-    const iic_conv_geom g, const bf16_t* __restrict__ in, const unsigned char* __restrict__ wfrag,
+__device__ __forceinline__ void bd_tile(
+    const iic_conv_geom& g, const bf16_t* __restrict__ in, const unsigned char* __restrict__ wfrag,
     bf16_t* __restrict__ out, float* __restrict__ stats, const bf16_t* __restrict__ res_grad,
-    const bf16_t* __restrict__ res_act, int accumulate, int num_mtiles, int lds_a_bytes,
+    const bf16_t* __restrict__ res_act, int accumulate, int lds_a_bytes,
     int dense_key, const bf16_t* __restrict__ red_y, const float* __restrict__ red_coef,
     const bf16_t* __restrict__ red_y2, float* __restrict__ red_stats, float* __restrict__ red_stats2,
-    unsigned long long* __restrict__ prof, int stagger) {
+    unsigned long long* __restrict__ prof, int stagger, int blk_in_class, int nwg_class, int m_base) {
   constexpr int CLD = BD_BN + 8;
   constexpr bool PROF = (ABL & 128) != 0;
   constexpr bool NEWORD = (ABL & 256) == 0;     // ABL bit 256: the round-2 K-loop order (A/B runs)
@@ -108,10 +108,10 @@ __global__ __launch_bounds__(BD_THREADS, (MS == 4 ? 2 : 3)) void conv_igemm_bd_k
   const int l31 = lane & 31, g5 = lane >> 5;
 
   const int nt = g.Cout / BD_BN;
-  const int tix = xcd_tile_index(blockIdx.x, num_mtiles * nt);
+  const int tix = xcd_tile_index(blk_in_class, nwg_class);
   const int mtile = tix / nt, ntile = tix - mtile * nt;
   const int n0 = ntile * BD_BN;
-  const int m0 = mtile * BM;
+  const int m0 = m_base + mtile * BM;
   const int in_pixels = g.N * g.in_Hp * g.in_Wp;
 
   const int v_tapoff = g.tap_off[lane & (IIC_MAX_TAPS - 1)];
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(BD_THREADS, (MS == 4 ? 2 : 3)) void conv_igemm_bd_k
   }
   __syncthreads();
   const int p_lo = s_pin[0];
-  const int npix = GATHER ? BM : (MS == 4 ? g.NP256 : g.NP);
+  const int npix = GATHER ? BM : (MS >= 3 ? g.NP256 : g.NP);      // (192-row tiles: bound checked by the host)
   // swizzle key of a pixel (see the header): D = p - J * (p / in_Wp); J must be even so that D keeps
   // the row parity (the 128-B half of the 256-B bank window is the physical row parity)
   const int jskip = (dense_key && !GATHER && g.sx == 1 && ((g.in_Wp - g.MX) & 1) == 0) ? g.in_Wp - g.MX : 0;
@@ -422,6 +422,31 @@ __global__ __launch_bounds__(BD_THREADS, (MS == 4 ? 2 : 3)) void conv_igemm_bd_k
   }
 }
 
+// Launch shape.  Tiles are equal work, so a launch runs in whole rounds over the chip's workgroup slots
+// (2 per CU): 1 612 layer-2 tiles take 4 rounds for 3.15 rounds of work, 872 layer-3 tiles 2 for 1.70
+// (tools/bd_timeline.py: slot occupancy 0.79 / 0.85).  MS2 != 0: the tiles of the last, partial round are
+// MS2 * 64 rows high instead of 256, sized so that they still fit ONE round (host: the split below): the
+// first n_big workgroups take 256-row tiles of rows [0, m_split), the others MS2-tiles of the rest.
+// Results per output row are unchanged (same K order); only the grouping of the statistics partials differs.
+template <bool GATHER, int ABL, bool DMA, int MS, int RED, int MS2>
+__global__ __launch_bounds__(BD_THREADS, ((MS == 4 || MS2 != 0) ? 2 : 3)) void conv_igemm_bd_kernel(
+    const iic_conv_geom g, const bf16_t* __restrict__ in, const unsigned char* __restrict__ wfrag,
+    bf16_t* __restrict__ out, float* __restrict__ stats, const bf16_t* __restrict__ res_grad,
+    const bf16_t* __restrict__ res_act, int accumulate, int num_mtiles, int lds_a_bytes,
+    int dense_key, const bf16_t* __restrict__ red_y, const float* __restrict__ red_coef,
+    const bf16_t* __restrict__ red_y2, float* __restrict__ red_stats, float* __restrict__ red_stats2,
+    unsigned long long* __restrict__ prof, int stagger, int n_big, int m_split) {
+  if (MS2 == 0 || (int)blockIdx.x < n_big) {
+    bd_tile<GATHER, ABL, DMA, MS, RED>(g, in, wfrag, out, stats, res_grad, res_act, accumulate, lds_a_bytes,
+                                       dense_key, red_y, red_coef, red_y2, red_stats, red_stats2, prof, stagger,
+                                       (int)blockIdx.x, MS2 == 0 ? num_mtiles * (g.Cout / BD_BN) : n_big, 0);
+  } else {
+    bd_tile<GATHER, ABL, DMA, (MS2 == 0 ? MS : MS2), RED>(
+        g, in, wfrag, out, stats, res_grad, res_act, accumulate, lds_a_bytes, dense_key, red_y, red_coef, red_y2,
+        red_stats, red_stats2, prof, stagger, (int)blockIdx.x - n_big, (int)gridDim.x - n_big, m_split);
+  }
+}
+
 // fp32 OIHW -> bf16 MFMA-B-fragment order.  mode 0 (forward operand): GEMM N = Cout, K = Cin;
 // mode 1 (backward-data operand): N = Cin, K = Cout.
 //   out[tap][kchunk][n/32][ks][lane][e] = W[n = j*32 + (lane & 31)][k = kchunk*64 + ks*16 + (lane>>5)*8 + e][tap]
@@ -484,6 +509,18 @@ static long bd_lds_a(const iic_conv_geom* g, int ms) {
   return (m + 15) & ~15L;
 }
 
+// input pixel of GEMM row m (conv_tile.h igemm_row_pixels, host side)
+static long bd_row_pin_host(const iic_conv_geom* g, long m) {
+  const long plane = (long)g->MY * g->MX, mp = g->MP > 0 ? g->MP : plane;
+  long n = m / mp, r = m - n * mp;
+  if (n >= g->N) { n = g->N - 1; r = plane - 1; }
+  r = r < plane ? r : plane - 1;
+  const long y = r / g->MX, x = r - y * g->MX;
+  return (n * g->in_Hp + y * g->sy + g->oy) * g->in_Wp + x * g->sx + g->ox;
+}
+static int g_bd_mixed = 0;      // 1: last partial round in smaller tiles. Per launch alone -5 % (layer 2 / 3), but inside the
+                                // two-stream step the other view already fills those tails: 38.0 vs 37.7 ms/step (r03 A/B) => off
+extern "C" void iic_debug_bd_mixed(int v) { g_bd_mixed = v; }
 static int g_bd_dense_key = 1;  // 0: swizzle key from the raw pixel index (A/B: conflicts at row ends)
 extern "C" void iic_debug_bd_dense_key(int v) { g_bd_dense_key = v; }
 static long bd_key_bytes(const iic_conv_geom* g, int ms) {    // swizzle-key table of the DMA patch (1 B / row)
@@ -562,25 +599,61 @@ int iic_conv_igemm_frag_red(const iic_conv_geom* g, const void* in, const void* 
   const int ms = bd_pick_ms(g);
   const int bm = ms * 64;
   const int mt = (int)((M + bm - 1) / bm);
-  const int grid = mt * (g->Cout / BD_BN);
+  const int nt = g->Cout / BD_BN;
+  int grid = mt * nt;
   const int la = (int)bd_lds_a(g, ms);
   const long lds = bd_lds_total(g, ms);
+  // last partial round in smaller tiles (see conv_igemm_bd_kernel)
+  int ms2 = 0, n_big = 0, m_split = 0;
+  if (g_bd_mixed && ms == 4 && g->ntaps > 1 && g_bd_dma && iic_debug_get_ablate() == 0) {
+    const int slots = (lds <= 80 * 1024 ? 2 : 1) * 256;
+    const int per_round = slots / nt;                       // m-tiles per round
+    const int full = per_round > 0 ? mt / per_round : 0;    // whole rounds of 256-row tiles
+    if (full >= 1 && mt % per_round != 0) {
+      const long rem = M - (long)full * per_round * 256;
+      for (int c = 2; c <= 3 && ms2 == 0; ++c)
+        if ((rem + 64 * c - 1) / (64 * c) <= per_round) ms2 = c;
+      if (ms2 != 0) {
+        // the small tiles stage their patch in the 256-row tile's LDS image: every span must fit it
+        // (128-row tiles at multiples of 128 rows are covered by g->NP by construction)
+        int max_tap = 0;
+        for (int t = 0; t < g->ntaps; ++t) max_tap = g->tap_off[t] > max_tap ? g->tap_off[t] : max_tap;
+        const long bound = ms2 == 2 ? g->NP : g->NP256;
+        for (long m0 = (long)full * per_round * 256; m0 < M && ms2 != 0; m0 += 64 * ms2) {
+          const long m1 = (m0 + 64 * ms2 < M ? m0 + 64 * ms2 : M) - 1;
+          if (bd_row_pin_host(g, m1) - bd_row_pin_host(g, m0) + max_tap + 1 > bound) ms2 = 0;
+        }
+      }
+      if (ms2 != 0) {
+        n_big = full * per_round * nt;
+        m_split = full * per_round * 256;
+        grid = n_big + (int)((rem + 64 * ms2 - 1) / (64 * ms2)) * nt;
+      }
+    }
+  }
   hipStream_t s = (hipStream_t)stream;
-#define BD_LAUNCH4(GA_, AB_, DM_, MS_, RD_)                                                       \
+#define BD_LAUNCH5(GA_, AB_, DM_, MS_, RD_, M2_)                                                  \
   do {                                                                                           \
     static bool attr = false;                                                                    \
     if (!attr) {                                                                                 \
       (void)hipFuncSetAttribute(                                                                 \
-          reinterpret_cast<const void*>(&conv_igemm_bd_kernel<GA_, AB_, DM_, MS_, RD_>),         \
+          reinterpret_cast<const void*>(&conv_igemm_bd_kernel<GA_, AB_, DM_, MS_, RD_, M2_>),    \
           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                               \
       attr = true;                                                                               \
     }                                                                                            \
-    hipLaunchKernelGGL((conv_igemm_bd_kernel<GA_, AB_, DM_, MS_, RD_>), dim3(grid),              \
+    hipLaunchKernelGGL((conv_igemm_bd_kernel<GA_, AB_, DM_, MS_, RD_, M2_>), dim3(grid),         \
                        dim3(BD_THREADS), lds, s, *g, (const bf16_t*)in,                          \
                        (const unsigned char*)wfrag, (bf16_t*)out, stats, (const bf16_t*)res_grad, \
                        (const bf16_t*)res_act, accumulate, mt, la, g_bd_dense_key,               \
                        (const bf16_t*)red_y, red_coef, (const bf16_t*)red_y2, red_stats,         \
-                       red_stats2, g_bd_prof, g_bd_stagger * (g->ntaps > 1 ? g->ntaps : 0));     \
+                       red_stats2, g_bd_prof, g_bd_stagger * (g->ntaps > 1 ? g->ntaps : 0),      \
+                       n_big, m_split);                                                          \
+  } while (0)
+#define BD_LAUNCH4(GA_, AB_, DM_, MS_, RD_)                                                       \
+  do {                                                                                           \
+    if (AB_ == 0 && !GA_ && DM_ && MS_ == 4 && ms2 == 2) BD_LAUNCH5(false, 0, true, 4, RD_, 2);  \
+    else if (AB_ == 0 && !GA_ && DM_ && MS_ == 4 && ms2 == 3) BD_LAUNCH5(false, 0, true, 4, RD_, 3); \
+    else BD_LAUNCH5(GA_, AB_, DM_, MS_, RD_, 0);                                                 \
   } while (0)
 #define BD_LAUNCH3(GA_, AB_, DM_, MS_)                                                            \
   do {                                                                                           \
