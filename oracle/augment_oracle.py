@@ -283,6 +283,31 @@ def np_pipeline(img_u8, crop_xy, crop_sz, out_sz, include_rgb, flip=False, order
   return _normalize(np.concatenate([np.transpose(lut[a], (2, 0, 1)), grey[None]], 0), norm)
 
 
+def params_from_log(log, src_hw):
+  """Translate the draw log of oracle/tv021_shim.py (the random draws the reference's own Compose objects
+  made for one image, tests/golden/augment.npz) into pil_pipeline / np_pipeline keyword arguments."""
+  H, W = src_hw
+  kw = dict(flip=False, order=(), factors=None, angle=None, cutout_box=None)
+  for kind, val in log:
+    if kind == "angle":
+      kw["angle"] = float(val)
+    elif kind == "crop":
+      kw["crop_xy"], kw["crop_sz"] = (int(val[0]), int(val[1])), int(val[2])
+    elif kind == "center_crop":
+      kw["crop_sz"] = int(val)
+      kw["crop_xy"] = center_crop_xy(W, H, int(val))
+    elif kind == "paste":
+      kw["cutout_box"] = tuple(int(v) for v in val)
+    elif kind == "flip":
+      kw["flip"] = bool(val)
+    elif kind == "jitter":
+      kw["order"] = [int(op) for op, _ in val]
+      kw["factors"] = {int(op): float(f) for op, f in val}
+    else:
+      assert kind in ("apply", "choice"), kind         # implied by the entries that follow them
+  return kw
+
+
 def random_params(rng, n, src_hw, crop_sz, jitter=(0.4, 0.4, 0.4, 0.125)):
   """Explicit parameter draws with the distributions of RandomCrop.get_params,
   RandomHorizontalFlip and ColorJitter.get_params (torchvision 0.2.1)."""

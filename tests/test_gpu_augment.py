@@ -199,3 +199,68 @@ def test_sobel_pipeline_variants_bit_exact_vs_pil(variant):
       assert (ip[:, 19] != 0).sum() > 20
     if mode == "jittered" and variant == "fluid_warp":
       assert (ip[:, 11] == 1).sum() > 10 and len(set(ip[:, 10])) == 3
+
+
+def _iparams_from_log(aug, log, src_index, H, W):
+  """The draws the reference's transforms made (oracle/tv021_shim.py log) as one iic_augment parameter row."""
+  from iic_amd.augment import FPARAMS, IPARAMS, hue_shift, rotation_fixed_point
+  kw = ao.params_from_log(log, (H, W))
+  ip = np.zeros(IPARAMS, np.int32)
+  fp = np.zeros(FPARAMS, np.float32)
+  ip[0] = src_index
+  ip[1], ip[2] = kw["crop_xy"]
+  ip[3] = int(kw["flip"])
+  ip[10] = aug.crop_szs.index(kw["crop_sz"])
+  if kw["order"]:
+    ip[4] = len(kw["order"])
+    ip[5:5 + len(kw["order"])] = kw["order"]
+    for op, f in kw["factors"].items():
+      fp[op] = f
+    if ao.OP_HUE in kw["factors"]:
+      ip[9] = hue_shift(float(kw["factors"][ao.OP_HUE]))
+  if kw["angle"] is not None and kw["angle"] % 360.0 != 0:
+    ip[11] = 1
+    ip[12:18] = rotation_fixed_point(float(kw["angle"]), W, H)
+  if kw["cutout_box"] is not None:
+    l, u, r, lo = kw["cutout_box"]
+    if r > l and lo > u:
+      ip[18] = l | (u << 16)
+      ip[19] = r | (lo << 16)
+  return ip, fp
+
+
+def test_kernel_replays_reference_transform_fixtures():
+  """csrc/augment.hip on the draws recorded while the reference's OWN sobel_make_transforms /
+  greyscale_make_transforms (code/utils/cluster/transforms.py:107-334) ran in the build container
+  (tests/golden/augment.npz, oracle/gen_golden_augment.py): bit-equal float32 tensors for every
+  configuration (STL10 / CIFAR flag sets, --cutout, --fluid_warp, --demean, the MNIST flag set)."""
+  import ast
+  import json
+  import types
+  from iic_amd.augment import GreyscaleAugmenter, PairedAugmenter
+  z = np.load(os.path.join(os.path.dirname(__file__), "golden", "augment.npz"), allow_pickle=False)
+  total = 0
+  for name in [str(n) for n in z["names"]]:
+    meta = json.loads(str(z[name + "/meta"]))
+    cfg = types.SimpleNamespace(**meta["config"])
+    imgs = z[name + "/images"]
+    dev_imgs = torch.from_numpy(imgs).cuda()
+    H, W = imgs.shape[1:3]
+    if meta["kind"] == "sobel":
+      aug = PairedAugmenter(dev_imgs, cfg.rand_crop_sz, cfg.input_sz, cfg.include_rgb, cutout=cfg.cutout,
+                            cutout_p=getattr(cfg, "cutout_p", 0.5), cutout_max_box=getattr(cfg, "cutout_max_box", 0.5),
+                            fluid_warp=cfg.fluid_warp, rot_val=getattr(cfg, "rot_val", 0.0),
+                            rand_crop_szs_tf=getattr(cfg, "rand_crop_szs_tf", ()), demean=cfg.demean,
+                            data_mean=getattr(cfg, "data_mean", ()), data_std=getattr(cfg, "data_std", ()))
+    else:
+      aug = GreyscaleAugmenter(dev_imgs, cfg)
+    for which in (1, 2, 3):
+      ref = z[name + "/tf%d" % which]
+      rows = [_iparams_from_log(aug, ast.literal_eval(str(s)), i, H, W)
+              for i, s in enumerate(z[name + "/log%d" % which])]
+      got = aug.apply(np.stack([r[0] for r in rows]), np.stack([r[1] for r in rows])).cpu().numpy()
+      assert got.shape == ref.shape, (name, which, got.shape, ref.shape)
+      bad = [i for i in range(ref.shape[0]) if not np.array_equal(got[i], ref[i])]
+      assert not bad, (name, which, bad, float(np.abs(got - ref).max()))
+      total += ref.shape[0]
+  assert total == 3 * 6 * len(z["names"])
