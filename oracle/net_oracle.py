@@ -304,6 +304,18 @@ def make_paired_batch(n_pairs, input_sz=96, num_dataloaders=3, seed=0):
   return all_imgs.contiguous(), all_imgs_tf.contiguous()
 
 
+def make_mild_pair(n_pairs, input_sz=64, num_dataloaders=3, seed=0):
+  """Like make_paired_batch, but the second view is a MILD transform of the first (gain in [0.9, 1.1],
+  noise 0.01, no flip): a randomly initialised trunk is not flip-invariant, so only a mild transform
+  leaves the two views' features correlated -- the whole-net fixtures that need a loss well away from
+  MI = 0 (tests/golden/net5g_large.npz) use this pair."""
+  all_imgs, _ = make_paired_batch(n_pairs, input_sz, num_dataloaders, seed)
+  rng1 = np.random.default_rng(seed + 1)
+  gain = torch.from_numpy(rng1.uniform(0.9, 1.1, (n_pairs, 1, 1, 1)).astype(np.float32))
+  noise = torch.from_numpy((rng1.standard_normal(all_imgs.shape) * 0.01).astype(np.float32))
+  return all_imgs.contiguous(), torch.clamp(all_imgs * gain + noise, 0.0, 1.0).contiguous()
+
+
 def net5g_train_step_loss(params, all_imgs, all_imgs_tf, lamb=1.0, input_sz=96,
                           num_sub_heads=5, head="head"):
   """cluster_sobel.py:235-253: sobel x2, two train-mode forwards, mean IID_loss."""

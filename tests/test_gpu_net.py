@@ -108,11 +108,9 @@ def test_net5g_small_vs_reference_golden(use_tr):
     f.write("%s\n" % report)
   assert mean_emu <= 3.0 * mean_inherent + 2e-3, report
   assert (out.argmax(-1) == eout.argmax(-1)).mean() >= 0.9, report
-  # run-to-run the loss takes a few discrete values (-0.01492 ... -0.01590 over 16 runs: the order
-  # of the fp32 atomics behind the BN statistics differs, one pooling arg-max / ReLU flips, and the
-  # 24-image batch-stat net amplifies it): 10 % like the criterion against the fp32 reference
-  # (round 2: statistics are accumulated exactly, the run is bit-reproducible: measured 2.3 % from
-  # the emulation and 1.8 % from the fp32 reference, every run)
+  # The statistics are accumulated exactly (round 2), so the run is bit-reproducible: the loss is
+  # -0.014923 on every run -- 2.3 % from the bf16 emulation, 1.8 % from the fp32 reference (MI ~ 0 on
+  # this 24-image fixture: the loss itself is a difference of nearly equal terms); 5 % gates.
   assert abs(report["loss"] - report["loss_bf16emu"]) < 5e-2 * abs(report["loss_bf16emu"]), report
   assert abs(report["loss"] - report["loss_fp32_reference"]) < 5e-2 * abs(report["loss_fp32_reference"]), report
   # gradients vs the bf16-emulating oracle (straight-through rounding)
@@ -307,6 +305,13 @@ def test_replica_deduplication():
   assert float((o3.cpu() - ref).abs().mean()) < 6e-3, float((o3.cpu() - ref).abs().mean())
   assert torch.equal(o3[:64], o3[64:128]) and torch.equal(o3[:64], o3[128:])
   assert float((o1 - o3).abs().mean()) < 4e-3 and abs(l1 - l3) < 3e-4, (l1, l3)    # loss ~ -4e-4 here
+  # Gradients of the bf16 production path: the two runs differ by where bf16 rounding happens (the
+  # de-duplicated backward sums three replicas' upstream gradients before they enter the trunk), and
+  # the loss of this fixture is ~ -4e-4 (MI ~ 0: dL/dz is a difference of nearly equal terms), so
+  # element-level agreement is not meaningful in bf16 -- the EXACT statement (outputs, loss and every
+  # parameter gradient of the de-duplicated path against the reference's own fp32 golden of the
+  # replicated batch) is test_replica_dedup_fp32_mode_vs_reference_golden below; here only the
+  # summary is recorded and loosely bounded.
   names = [n for n in g1 if float(g1[n].norm()) > 1e-8]
   cs = {n: _cos(g1[n], g3[n]) for n in names}
   rs = {n: float(g3[n].norm() / g1[n].norm()) for n in names}
@@ -314,14 +319,163 @@ def test_replica_deduplication():
   with open("gpurun_out/dedup_grads.txt", "w") as f:
     for n in names:
       f.write("%-45s cos %.4f  norm ratio %.4f\n" % (n, cs[n], rs[n]))
-  assert np.median(list(cs.values())) > 0.8 and min(cs.values()) > 0.6, \
-      (float(np.median(list(cs.values()))), min(cs.values()))
-  # the loss is ~ -4e-4 (random-init net, MI ~ 0): dL/dz is a difference of nearly equal terms, so
-  # bf16 / atomic-order noise moves every parameter gradient by a COMMON factor between two runs of
-  # the same path already (measured medians 0.93 ... 1.10); (a) above is the exactness check
   assert abs(np.median(list(rs.values())) - 1.0) < 0.25, float(np.median(list(rs.values())))
   k = "trunk.bn1.running_var"
   assert torch.allclose(s1[k], s3[k], rtol=1e-4, atol=1e-6), (s1[k] - s3[k]).abs().max()
+
+
+def test_net5g_bf16_large_batch_vs_reference_golden():
+  """The bf16 PRODUCTION kernels (MFMA convolutions, bf16 activations, fused epilogues) across the whole
+  ClusterNet5g against the reference's own fp32 result on a fixture OUTSIDE the chaotic regime
+  (VERDICT r2 weak #3 / next 4c): 96 images (32 x 3 replicas), 64 x 64, 2 sub-heads, loss -0.40
+  (tests/golden/net5g_large.npz, oracle/gen_golden_large.py).  The 24-image 32 x 32 fixture above has
+  MI ~ 0 and only supports robust aggregates; here the loss is held to 1 % and every parameter
+  gradient to a cosine against the reference's gradient (complete for small parameters, a fixed
+  strided 16 384-element sample for the large convolution weights)."""
+  from iic_amd import archs
+  from iic_amd.losses import IID_loss
+  from iic_amd.transforms import sobel_process
+  from oracle import net_oracle
+  from oracle.gen_golden_large import HEADS, INPUT_SZ, K, N_PAIRS, sample_stride
+  g = np.load(os.path.join(G, "net5g_large.npz"))
+  params = net_oracle.make_net5g_params(2, K, HEADS, True, seed=13, randomize_bn=True, head_std=0.03)
+  for k in g.files:
+    if k.startswith("param/"):
+      params[k[6:]] = torch.from_numpy(g[k])
+  net = archs.ClusterNet5g(_cfg(input_sz=INPUT_SZ, num_sub_heads=HEADS, output_k=K))
+  net.load_state_dict(params, strict=True)
+  net.to(dev()).train()
+  imgs, imgs_tf = net_oracle.make_mild_pair(N_PAIRS, INPUT_SZ, 3, seed=21)
+  xo = net(sobel_process(imgs.to(dev()), False))
+  xt = net(sobel_process(imgs_tf.to(dev()), False))
+  tot = None
+  for i in range(HEADS):
+    l, _ = IID_loss(xo[i], xt[i], lamb=1.0)
+    tot = l if tot is None else tot + l
+  tot = tot / HEADS
+  tot.backward()
+  torch.cuda.synchronize()
+  out = np.stack([o.detach().cpu().numpy() for o in xo])
+  out_tf = np.stack([o.detach().cpu().numpy() for o in xt])
+  lref = float(g["loss"][0])
+  # the bf16-storage emulation of the oracle on the same fixture (CPU, no HIP code): the yardstick for
+  # what bf16 activations alone do to a 33-BatchNorm net, and -- same rounding points as the HIP path --
+  # the tight reference for the gradients
+  from oracle import iid_oracle
+  eparams = {k: v.clone() for k, v in params.items()}
+  for k, v in eparams.items():
+    if v.dtype.is_floating_point and "running" not in k:
+      v.requires_grad_(True)
+  exo = net_oracle.net5g_forward_bf16emu(eparams, net_oracle.sobel_process(imgs, False), True, INPUT_SZ, "head", HEADS)
+  ext = net_oracle.net5g_forward_bf16emu(eparams, net_oracle.sobel_process(imgs_tf, False), True, INPUT_SZ, "head", HEADS)
+  eloss = sum(iid_oracle.IID_loss(exo[i], ext[i], 1.0)[0] for i in range(HEADS)) / HEADS
+  eloss.backward()
+  eout = np.stack([o.detach().numpy() for o in exo])
+  rows, cs, rs, ce, cy = [], [], [], [], []
+  for n, p in net.named_parameters():
+    gd = p.grad.detach().flatten()
+    st = sample_stride(gd.numel())
+    ours = gd[::st].double().cpu()
+    ref = torch.from_numpy(g["grad/" + n]).double()
+    emu = eparams[n].grad.detach().flatten()
+    gn = float(g["gnorm/" + n][0])
+    if gn < 1e-9:
+      continue
+    c, r = _cos(ours, ref), float(gd.double().norm()) / gn
+    c_emu = _cos(gd.double().cpu(), emu.double())             # vs the emulation: the FULL gradient
+    c_yard = _cos(emu[::st].double(), ref)                    # emulation vs fp32 reference (no HIP code)
+    rows.append((n, c, r, c_emu, c_yard))
+    cs.append(c); rs.append(r); ce.append(c_emu); cy.append(c_yard)
+  cs, rs, ce, cy = np.array(cs), np.array(rs), np.array(ce), np.array(cy)
+  os.makedirs("gpurun_out", exist_ok=True)
+  with open("gpurun_out/net5g_large_report.txt", "w") as f:
+    f.write("loss %.6f, bf16-emulating oracle %.6f, fp32 reference %.6f (rel %.2e); mean|dprob| vs reference %.2e / %.2e "
+            "(emulation vs reference %.2e), vs emulation %.2e; argmax agreement %.3f\n" % (
+      float(tot.detach()), float(eloss), lref, abs(float(tot.detach()) - lref) / abs(lref), np.abs(out - g["out"]).mean(),
+      np.abs(out_tf - g["out_tf"]).mean(), np.abs(eout - g["out"]).mean(), np.abs(out - eout).mean(),
+      float((out.argmax(-1) == g["out"].argmax(-1)).mean())))
+    f.write("gradient cosine vs fp32 reference: median %.4f min %.4f (bf16 emulation vs reference: median %.4f min %.4f); "
+            "vs bf16 emulation: median %.4f min %.4f; norm ratio vs reference median %.4f min %.4f max %.4f\n" % (
+      np.median(cs), cs.min(), np.median(cy), cy.min(), np.median(ce), ce.min(), np.median(rs), rs.min(), rs.max()))
+    for n, c, r, c_emu, c_yard in rows:
+      f.write("%-45s cos vs ref %.4f (emulation vs ref %.4f)  vs emulation %.4f  norm ratio %.4f\n" % (n, c, c_yard, c_emu, r))
+  assert abs(float(tot.detach()) - lref) <= 1e-2 * abs(lref), (float(tot.detach()), lref)
+  assert abs(float(tot.detach()) - float(eloss)) <= 5e-3 * abs(lref), (float(tot.detach()), float(eloss))
+  assert np.abs(out - g["out"]).mean() <= 1.5 * np.abs(eout - g["out"]).mean() + 5e-4
+  assert np.abs(out - eout).mean() <= 6e-3, float(np.abs(out - eout).mean())
+  assert (out.argmax(-1) == g["out"].argmax(-1)).mean() >= 0.97
+  # against the fp32 reference bf16 STORAGE itself costs cosine (emulation vs reference, no HIP code involved:
+  # median 0.88, min 0.77 on this fixture); the HIP path must be in the emulation's class there ...
+  assert np.median(cs) >= np.median(cy) - 0.02 and cs.min() >= cy.min() - 0.10, (float(np.median(cs)), float(np.median(cy)), cs.min(), cy.min())
+  assert abs(np.median(rs) - 1.0) <= 0.03 and rs.min() >= 0.85 and rs.max() <= 1.15, (float(np.median(rs)), rs.min(), rs.max())
+  # ... and in the same class against the emulation itself.  Measured: median 0.92, min 0.86 -- and the
+  # emulation run on two different CPUs (BLAS summation order) differs from ITSELF by about as much
+  # (loss -0.402629 in the build container, -0.402053 on the GPU box's host): at 96 images a 1-ulp
+  # difference in accumulation order still flips bf16 rounding decisions that 33 batch-statistics
+  # BatchNorm layers amplify, so a cosine of 0.97 between two valid bf16 executions of this net does not
+  # exist; gradient NORMS (median ratio 1.000), the loss (0.14 %) and the probabilities (4e-3) are the
+  # quantities bf16 storage preserves.  Exact gradient parity is the fp32-mode test (1e-3, every parameter).
+  assert np.median(ce) >= 0.88 and ce.min() >= 0.75, (float(np.median(ce)), float(ce.min()))
+
+
+def test_replica_dedup_fp32_mode_vs_reference_golden():
+  """SURVEY.md 8f rank 3, exact form.  tests/golden/nets.npz was produced by the
+  reference's own ClusterNet5g + IID_loss on a batch whose first view is 8 base images replicated 3x
+  (net_oracle.make_paired_batch(24, 32, 3): exactly cluster_sobel.py:215-226).  The de-duplicated
+  forward (`with replicated(3)`: the trunk sees the 8 unique images, features are repeated, autograd
+  sums the replicas' gradients, BatchNorm's unbiased running-variance factor uses the true batch size)
+  runs here on the exact-fp32 kernels (`ops.fp32_mode()`), so nothing but fp32 summation order
+  separates it from the reference's full 24-image forward: outputs, loss, EVERY parameter gradient
+  and the running statistics must agree with the golden of the replicated batch."""
+  from iic_amd import archs, ops
+  from iic_amd.archs import cluster as cl
+  from iic_amd.losses import IID_loss
+  from iic_amd.transforms import sobel_process
+  from oracle import net_oracle
+  g = np.load(os.path.join(G, "nets.npz"))
+  params = net_oracle.make_net5g_params(2, 10, 2, True, seed=3, randomize_bn=True, head_std=0.3)
+  net = archs.ClusterNet5g(_cfg(input_sz=32, num_sub_heads=2, output_k=10))
+  net.load_state_dict(params, strict=True)
+  net.to(dev()).train()
+  imgs, imgs_tf = net_oracle.make_paired_batch(24, 32, 3, seed=5)
+  assert torch.equal(imgs[:8], imgs[8:16]) and torch.equal(imgs[:8], imgs[16:])
+  with ops.fp32_mode():
+    with cl.replicated(3):
+      xo = net(sobel_process(imgs.to(dev()), False))          # trunk runs on the 8 unique images
+    xt = net(sobel_process(imgs_tf.to(dev()), False))
+  tot = None
+  for i in range(2):
+    l, _ = IID_loss(xo[i], xt[i], lamb=1.0)
+    tot = l if tot is None else tot + l
+  tot = tot / 2
+  tot.backward()
+  torch.cuda.synchronize()
+  out = np.stack([o.detach().cpu().numpy() for o in xo])
+  out_tf = np.stack([o.detach().cpu().numpy() for o in xt])
+  assert np.abs(out - g["net5g_out"]).max() <= 2e-4, np.abs(out - g["net5g_out"]).max()
+  assert np.abs(out_tf - g["net5g_out_tf"]).max() <= 2e-4
+  assert np.array_equal(out[:, :8], out[:, 8:16]) and np.array_equal(out[:, :8], out[:, 16:])
+  lref = float(g["net5g_loss"][0])
+  assert abs(float(tot.detach()) - lref) <= 1e-3 * abs(lref), (float(tot.detach()), lref)
+  worst = 0.0
+  for n, p in net.named_parameters():
+    gn, gs, g0 = g["net5g_grad/" + n]
+    gd = p.grad.detach().double()
+    rel = abs(float(gd.norm()) - gn) / max(gn, 1e-12)
+    assert rel <= 1e-3 or abs(float(gd.norm()) - gn) <= 1e-9, (n, float(gd.norm()), gn)
+    rms = gn / max(gd.numel() ** 0.5, 1)
+    assert abs(float(gd.flatten()[0]) - g0) <= 3e-2 * max(rms, abs(g0)) + 1e-9, (n, float(gd.flatten()[0]), g0)
+    assert abs(float(gd.sum()) - gs) <= 3e-2 * (abs(gs) + gn), (n, float(gd.sum()), gs)
+    worst = max(worst, rel)
+  sd = net.state_dict()
+  assert np.abs(sd["trunk.bn1.running_mean"].cpu().numpy() - g["net5g_rm_bn1"]).max() <= 1e-5
+  assert np.allclose(sd["trunk.bn1.running_var"].cpu().numpy(), g["net5g_rv_bn1"], rtol=1e-4, atol=1e-7)
+  assert np.allclose(sd["trunk.layer4.2.bn2.running_var"].cpu().numpy(), g["net5g_rv_l4"], rtol=1e-3, atol=1e-7)
+  os.makedirs("gpurun_out", exist_ok=True)
+  with open("gpurun_out/dedup_fp32_mode.txt", "w") as f:
+    f.write("max|dprob| %.3e, loss %.9f vs %.9f, worst grad-norm rel err %.3e over %d parameters\n"
+            % (np.abs(out - g["net5g_out"]).max(), float(tot.detach()), lref, worst,
+               len(list(net.named_parameters()))))
 
 
 def test_north_star_full_size_properties():
