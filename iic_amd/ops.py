@@ -195,6 +195,7 @@ def auto_branch(fwd):
     return fwd(self, x, *a, **k)
   wrapped.__name__ = getattr(fwd, "__name__", "forward")
   wrapped.__doc__ = fwd.__doc__
+  wrapped.__wrapped__ = fwd          # inspect.signature() shows the architecture's own parameters
   return wrapped
 
 

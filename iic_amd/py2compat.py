@@ -196,7 +196,15 @@ class _ImportOnlyModule(types.ModuleType):
     if full in sys.modules:
       return sys.modules[full]
 
-    class _Missing(object):
+    class _MissingMeta(type):
+      # `torchvision.datasets.MNIST` at module level of a script (cluster_greyscale_twohead.py:133) must
+      # evaluate; only USING the result raises
+      def __getattr__(cls, name):
+        if name.startswith("__"):
+          raise AttributeError(name)
+        return _MissingMeta(name, (cls,), {})
+
+    class _Missing(object, metaclass=_MissingMeta):
       def __init__(s, *a, **k):
         raise ImportError("%s is not installed in this image (iic_amd.py2compat provides an "
                           "import-only stand-in; the reference's data layer is out of scope)" % full)
@@ -227,6 +235,30 @@ class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
 _STATE = {"finder": None, "stubs": None}
 
 
+def torch04_shims():
+  """The reference was written against PyTorch 0.4.1 (package_versions.txt), where byte tensors were the
+  mask type.  Its evaluation code selects with uint8 masks (code/utils/segmentation/segmentation_eval.py:
+  58-60,126-128: `flat_preds.masked_select(mask=mask_all)` with a torch.uint8 mask), which current
+  PyTorch rejects ("expected BoolTensor for mask").  masked_select is re-bound to accept byte masks
+  with their 0.4.1 meaning (non-zero = selected); bool masks pass through untouched.  Idempotent."""
+  import torch
+  if getattr(torch.Tensor.masked_select, "__iic_torch04__", False):
+    return
+  orig_method, orig_fn = torch.Tensor.masked_select, torch.masked_select
+
+  def _as_bool(mask):
+    return mask != 0 if torch.is_tensor(mask) and mask.dtype == torch.uint8 else mask
+
+  def masked_select(self, mask):
+    return orig_method(self, _as_bool(mask))
+
+  def masked_select_fn(input, mask, **kw):
+    return orig_fn(input, _as_bool(mask), **kw)
+  masked_select.__iic_torch04__ = True
+  torch.Tensor.masked_select = masked_select
+  torch.masked_select = masked_select_fn
+
+
 def py2_builtins():
   """Names the Python-2 reference uses that survive lib2to3 untouched when they are reached
   dynamically (``itertools.izip`` as an attribute, ``xrange`` in eval'd strings)."""
@@ -251,6 +283,7 @@ def enable(root=None):
                       "directory that contains code/ on PYTHONPATH")
   root = os.path.abspath(root)
   py2_builtins()
+  torch04_shims()
   f = _STATE["finder"]
   if f is not None and f.root != root:
     disable()

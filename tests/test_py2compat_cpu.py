@@ -155,20 +155,88 @@ def test_install_strict_raises_when_a_name_cannot_be_rebound(tmp_path):
   assert "RAISED" in r.stdout and "cannot rebind" in r.stdout, r.stdout + r.stderr
 
 
-@needs_ref
-def test_unchanged_cluster_sobel_script_runs_two_batches(tmp_path):
+def _drive(tmp_path, script):
   env = dict(os.environ, PYTHONPATH=ROOT, IIC_REFERENCE=REF, MPLBACKEND="Agg", OMP_NUM_THREADS="8")
   r = subprocess.run([sys.executable, "-W", "ignore", os.path.join(ROOT, "tests", "ref_script_driver.py"),
-                      str(tmp_path)], env=env, capture_output=True, text=True, timeout=900)
+                      str(tmp_path), script], env=env, capture_output=True, text=True, timeout=1200)
   line = [l for l in r.stdout.splitlines() if l.startswith("IIC_DRIVER_RESULT ")]
   assert line, r.stdout[-3000:] + r.stderr[-3000:]
   res = json.loads(line[0][len("IIC_DRIVER_RESULT "):])
-  b, c = res["bound"], res["calls"]
-  assert b["arch"] and b["loss"] and b["opt"] and b["eval"] and b["n_patched"] == b["n_patches"] + 1
-  assert res["exit"] == 0                               # exit(0) under --test_code
+  assert res["error"] is None, (res["error"], r.stderr[-3000:])
+  b = res["bound"]
+  assert b["arch"] and b["loss"] and b["seg_loss"] and b["opt"] and b["eval"] and b["sobel_eval"]
+  assert b["n_patched"] == b["n_patches"] + 1
+  assert res["exit"] == 0                               # the scripts leave through exit(0) under --test_code
+  assert "plots.png" in res["files"] and "config.pickle" in res["files"]
+  return res, r.stdout
+
+
+@needs_ref
+def test_unchanged_cluster_sobel_script_runs_two_batches(tmp_path):
+  res, out = _drive(tmp_path, "cluster_sobel")
+  c = res["calls"]
   # 2 train batches x 2 views + evaluation forwards (2 eval passes x 2 loaders x 2 batches)
   assert c["net_init"] == 1 and c["opt_step"] == 2 and c["loss"] == 2 * 2
   assert c["net_fwd"] == 2 * 2 + 2 * 2 * 2 and c["sobel"] == c["net_fwd"]
   assert c["match"] == 2 * 2 and c["acc"] >= 2 * 2
-  assert "plots.png" in res["files"] and "config.pickle" in res["files"]
-  assert "Model ind 7 epoch 1 batch: 1" in r.stdout     # the script's own progress line
+  assert "Model ind 7 epoch 1 batch: 1" in out          # the script's own progress line
+
+
+@needs_ref
+def test_unchanged_cluster_sobel_twohead_script(tmp_path):
+  """cluster_sobel_twohead.py:265-359: head A then head B (--head_A_first), `net(x, head=head)`,
+  sub-head selection on the loss and the double evaluation."""
+  res, out = _drive(tmp_path, "cluster_sobel_twohead")
+  c = res["calls"]
+  assert c["net_init"] == 1 and c["opt_step"] == 2 * 2
+  assert c["train_fwd_heads"] == ["A"] * 4 + ["B"] * 4               # 2 batches x 2 views per head
+  assert c["loss"] >= 2 * 2 * 2 and c["sobel"] == c["net_fwd"]        # + get_subhead_using_loss's evaluations
+  assert c["match"] >= 4 and c["acc"] >= 4
+  assert "head A head_i_epoch 0 batch 1" in out and "head B head_i_epoch 0 batch 1" in out   # the script's own lines
+
+
+@needs_ref
+def test_unchanged_cluster_greyscale_script(tmp_path):
+  res, _ = _drive(tmp_path, "cluster_greyscale")
+  c = res["calls"]
+  assert c["net_init"] == 1 and c["opt_step"] == 2 and c["loss"] == 2 * 2 and c["sobel"] == 0
+  assert c["train_fwd_heads"] == ["<default>"] * 4
+
+
+@needs_ref
+def test_unchanged_cluster_greyscale_twohead_script_keeps_the_missing_head_argument(tmp_path):
+  """cluster_greyscale_twohead.py:342-343 calls `net(all_imgs)` WITHOUT head= in BOTH head loops, so the
+  reference always trains through ClusterNet6cTwoHead's default head "B" (net6c_two_head.py:75): the
+  quirk must survive -- the product's default is checked to be the reference's."""
+  res, _ = _drive(tmp_path, "cluster_greyscale_twohead")
+  c, b = res["calls"], res["bound"]
+  assert b["default_head_6c"] == "B" == b["default_head_ref_6c"]
+  assert c["train_fwd_heads"] == ["<default>"] * 8                   # 2 heads x 2 batches x 2 views, none passes head=
+  assert c["net_init"] == 1 and c["opt_step"] == 4 and c["loss"] == 2 * 2 * 2 and c["sobel"] == 0
+
+
+@needs_ref
+def test_unchanged_segmentation_script(tmp_path):
+  res, _ = _drive(tmp_path, "segmentation")
+  c = res["calls"]
+  assert c["net_init"] == 1 and c["opt_step"] == 2 and c["seg_loss"] == 2 and c["loss"] == 0
+  assert c["seg_loss_positional"] == 2
+  assert c["seg_loss_kwargs"] == ["all_affine2_to_1", "all_mask_img1", "half_T_side_dense", "half_T_side_sparse_max",
+                                  "half_T_side_sparse_min", "lamb"]
+  assert c["sobel"] == c["net_fwd"] and c["match"] >= 2
+
+
+@needs_ref
+def test_unchanged_segmentation_twohead_script_keyword_loss_call(tmp_path):
+  """segmentation_twohead.py:262-361: both heads, and the loss called as
+  loss_fn(x1_outs[i], x2_outs[i], all_affine2_to_1=..., all_mask_img1=..., lamb=..., half_T_side_dense=...,
+  half_T_side_sparse_min=..., half_T_side_sparse_max=...) (:318-325) -- the HIP losses take exactly these
+  keywords (checked against their signature)."""
+  res, _ = _drive(tmp_path, "segmentation_twohead")
+  c, b = res["calls"], res["bound"]
+  assert c["train_fwd_heads"] == ["A"] * 4 + ["B"] * 4
+  assert c["net_init"] == 1 and c["opt_step"] == 4 and c["seg_loss"] == 4
+  assert c["seg_loss_positional"] == 2
+  assert set(c["seg_loss_kwargs"]) <= set(b["seg_loss_params"][2:])
+  assert b["seg_loss_params"][:2] == ["x1_outs", "x2_outs"]
+  assert "best.pytorch" in res["files"] or "latest.pytorch" in res["files"]
