@@ -366,9 +366,128 @@ def bench_segmentation(args):
   print(json.dumps(out))
 
 
+C6_CONFIGS = {
+  # BASELINE.json configs[0] on the GPU: MNIST 24x24 ClusterNet6cTwoHead, k_A 50 / k_B 10, batch 700, 5 sub-heads
+  # (cluster_greyscale_twohead.py, commands.txt:30): one head-A step + one head-B step per batch
+  "mnist6c": dict(bn=700, sz=24, in_ch=1, sobel=False, heads=("A", "B"), k=(50, 10)),
+  # configs[2] per-GPU shape: CIFAR 24x24, --include_rgb (RGB + Sobel = 5 channels), ClusterNet6c, output_k 280
+  # (commands.txt:41 trains with batch 2800 over 5 dataloaders; 700 here, as in round 1's measurement)
+  "cifar6c": dict(bn=700, sz=24, in_ch=5, sobel=True, heads=(None,), k=(280,)),
+}
+# ClusterNet6c forward FLOPs per image at 24x24 (net6c.py:10-88, vgg.py:8-35: 5x5 convs 1/5->64 @24, 64->128
+# @12, 128->256 @6, 256->512 @3): 2 * (576*25*c*64 + 144*25*64*128 + 36*25*128*256 + 9*25*256*512)
+def _c6_flops(in_ch):
+  return 2.0 * (576 * 25 * in_ch * 64 + 144 * 25 * 64 * 128 + 36 * 25 * 128 * 256 + 9 * 25 * 256 * 512)
+
+
+def bench_6c(args):
+  """`--config mnist6c|cifar6c`: the ClusterNet6c configs (VERDICT r2 missing #2).  The train step of the
+  reference script (forward x2 -> IID_loss x 5 sub-heads -> backward -> Adam; per head for the two-head net)
+  replayed as captured HIP graphs with the two views on two streams (iic_amd.graph.CapturedPairStep), as at
+  the north star: at 24 x 24 the step is ~600 small launches and eager Python is launch-bound (round 1:
+  10.1 ms per MNIST A+B step).  `roofline`: the conv family (HIP events, one-stream eager steps after the
+  timed region) and the step's algorithmic rate (3 passes x 2 views x forward FLOPs)."""
+  from iic_amd import archs
+  from iic_amd.graph import CapturedPairStep
+  from iic_amd.losses import IID_loss_heads
+  from iic_amd.optim import Adam
+  from iic_amd.transforms import sobel_process
+  c = C6_CONFIGS[args.config]
+  dev = torch.device("cuda", 0)
+  torch.cuda.set_device(0)
+  torch.manual_seed(0)
+  two = len(c["heads"]) == 2
+  if two:
+    cfg = types.SimpleNamespace(in_channels=c["in_ch"], input_sz=c["sz"], batchnorm_track=True, num_sub_heads=SUB_HEADS,
+                                output_k_A=c["k"][0], output_k_B=c["k"][1])
+    net = archs.ClusterNet6cTwoHead(cfg).to(dev).train()
+  else:
+    cfg = types.SimpleNamespace(in_channels=c["in_ch"], input_sz=c["sz"], batchnorm_track=True, num_sub_heads=SUB_HEADS,
+                                output_k=c["k"][0])
+    net = archs.ClusterNet6c(cfg).to(dev).train()
+  use_graph = not args.no_graph
+  opt = Adam(net.parameters(), lr=args.lr, capturable=use_graph)
+  g = torch.Generator().manual_seed(0)
+  bn, sz = c["bn"], c["sz"]
+  raw_ch = c["in_ch"] - 1 if c["sobel"] else c["in_ch"]          # RGB + grey as the loaders emit it
+  x = torch.rand(bn, raw_ch, sz, sz, generator=g).to(dev)
+  xt = torch.clamp(torch.flip(x, dims=[3]) * 0.9 + 0.05, 0, 1).contiguous()
+
+  def inp(t):
+    return sobel_process(t, True) if c["sobel"] else t
+
+  def fwd(t, head):
+    return net.forward_packed(inp(t), head=head) if two else net.forward_packed(inp(t))
+
+  def loss_fn(a, b):
+    return IID_loss_heads(a, b, lamb=1.0)[0].mean()
+
+  def eager_head(head):
+    net.zero_grad(set_to_none=True)
+    loss = loss_fn(fwd(x, head), fwd(xt, head))
+    loss.backward()
+    opt.step()
+    return loss
+
+  def eager_step():
+    for h in c["heads"]:
+      last = eager_head(h)
+    return last
+  if use_graph:
+    caps = [CapturedPairStep((lambda h=h: fwd(x, h)), (lambda h=h: fwd(xt, h)), loss_fn, opt.step,
+                             lambda: net.zero_grad(set_to_none=True), warmup=max(1, args.warmup))
+            for h in c["heads"]]
+
+    def run():
+      for cap in caps:
+        last = cap()
+      return last
+  else:
+    run = eager_step
+    for _ in range(args.warmup):
+      eager_step()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    last = run()
+  t_enq = time.perf_counter() - t0
+  torch.cuda.synchronize()
+  dt = (time.perf_counter() - t0) / args.steps
+  n_inst = 0 if args.no_roofline else min(args.steps, 3)
+  conv = ConvTimer()
+  conv.install()
+  for _ in range(n_inst):
+    eager_step()
+  torch.cuda.synchronize()
+  conv.uninstall()
+  fl_step = len(c["heads"]) * 3 * 2 * bn * _c6_flops(c["in_ch"])
+  out = {
+    "metric": "paired-images/sec, %s" % ("MNIST 24x24 ClusterNet6cTwoHead+IID_loss (head-A step + head-B step)"
+                                         if two else "CIFAR 24x24x5 ClusterNet6c+IID_loss"),
+    "value": bn / dt, "unit": "paired-images/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+    "ms_per_step": 1e3 * dt, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+    "data": "synthetic",
+    "config": {"workload": "%s: %dx%dx%d, batch %d, 5 sub-heads, k %s, bf16 MFMA convs / fp32 first layer + heads + loss, "
+                           "fused HIP Adam" % (args.config, sz, sz, c["in_ch"], bn, "/".join(str(k) for k in c["k"])),
+               "launch": ("hip-graph replay: %d captured pair steps (6 linear graph segments each), the two views on two "
+                          "streams" % len(c["heads"])) if use_graph else "eager (python/ctypes)",
+               "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps, "final_loss": float(last.detach())},
+  }
+  cs = conv.summary() if n_inst else None
+  if cs:
+    out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm family (5x5 fwd + bwd-data implicit GEMM, bf16 MFMA)",
+                       "achieved": cs["tflops"], "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                       "frac": cs["tflops"] / BF16_PEAK_TFLOPS, "traffic": None, "launches_timed": cs["launches"],
+                       "avg_launch_us": cs["avg_us"], "kernel_ms_per_step": cs["total_ms"] / n_inst,
+                       "timed_in": "%d instrumented one-stream eager steps after the timed region" % n_inst,
+                       "step_algorithmic_tflops": fl_step / dt / 1e12,
+                       "step_frac_of_peak": fl_step / dt / 1e12 / BF16_PEAK_TFLOPS}
+  print(json.dumps(out))
+
+
 def main():
   ap = argparse.ArgumentParser()
-  ap.add_argument("--config", default="stl10_5g", choices=["stl10_5g"] + sorted(SEG_CONFIGS),
+  ap.add_argument("--config", default="stl10_5g", choices=["stl10_5g"] + sorted(SEG_CONFIGS) + sorted(C6_CONFIGS),
                   help="stl10_5g = the BASELINE metric (default); potsdam3 / coco3 = secondary "
                        "measurements of the segmentation configs with their own roofline object")
   ap.add_argument("--T", type=int, default=None, help="half_T_side_dense override for the segmentation configs")
@@ -398,6 +517,8 @@ def main():
                        "dataset, as cluster_sobel.py:205-232 does from its dataloaders; the default "
                        "(off) is the metric's own timed region, which excludes data loading")
   args = ap.parse_args()
+  if args.config in C6_CONFIGS:
+    return bench_6c(args)
   if args.config != "stl10_5g":
     if args.steps == 10 and args.warmup == 3:
       args.steps, args.warmup = 3, 1

@@ -117,6 +117,62 @@ __global__ __launch_bounds__(64) void gemm_f32_kernel(const float* __restrict__ 
   }
 }
 
+// The same product with KW waves per 32x32 tile: wave w owns a contiguous slice of K, the partial tiles
+// are folded through LDS in wave order (fixed order: bit-reproducible, no atomics).  For the long-K,
+// few-tile products of the VGG-style heads (ClusterNet6c: logits [700 x 250] over K = 4608 is only 176
+// tiles -- one wave each left 5/6 of the SIMDs idle for 125 us; round-3 profile r03_6c_kernel_stats).
+template <int KW>
+__global__ __launch_bounds__(64 * KW) void gemm_f32_kw_kernel(const float* __restrict__ A, long sam, long sak,
+                                                               const float* __restrict__ B, long sbk, long sbn,
+                                                               const float* __restrict__ bias,
+                                                               float* __restrict__ Cm, long scm, int M, int Nn,
+                                                               int K, int accumulate) {
+  __shared__ float part[KW][32 * 32];
+  const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = lane & 31, kk = lane >> 5;
+  const bool vm = (m0 + i) < M, vn = (n0 + i) < Nn;
+  const float* ap = A + (long)(m0 + i) * sam;
+  const float* bp = B + (long)(n0 + i) * sbn;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int per = (((K + KW - 1) / KW) + 7) & ~7;
+  int k = w * per;
+  const int kend = min(K, k + per);
+  for (; k + 8 <= kend; k += 8) {
+    float a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int kq = k + 2 * u + kk;
+      a[u] = vm ? ap[(long)kq * sak] : 0.f;
+      b[u] = vn ? bp[(long)kq * sbk] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+  }
+  for (; k < kend; k += 2) {
+    const int kq = k + kk;
+    const float a = (vm && kq < kend) ? ap[(long)kq * sak] : 0.f;
+    const float b = (vn && kq < kend) ? bp[(long)kq * sbk] : 0.f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) part[w][mfma32_row(r, lane) * 32 + i] = acc[r];
+  __syncthreads();
+  for (int e = threadIdx.x; e < 32 * 32; e += 64 * KW) {
+    const int row = m0 + (e >> 5), col = n0 + (e & 31);
+    if (row < M && col < Nn) {
+      float v = part[0][e];
+#pragma unroll
+      for (int q = 1; q < KW; ++q) v += part[q][e];
+      if (bias) v += bias[col];
+      float* o = Cm + (long)row * scm + col;
+      if (accumulate) v += *o;
+      *o = v;
+    }
+  }
+}
+
 // one wave per row of k logits
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ logits,
                                                           float* __restrict__ probs, int rows,
@@ -191,15 +247,26 @@ __global__ __launch_bounds__(256) void softmax_bwd_grouped_kernel(const float* _
   if (v) dlogits[row * k + j] = p * (dp - s);
 }
 
-// out[c] (+)= sum_r A[r][c]
+// out[c] (+)= sum_r A[r][c].  A block owns 32 columns; its 8 row groups (r = g, g + 8, ...) are summed
+// by 8 x 32 threads -- 128-byte row segments per access -- and folded through LDS in group order (fixed
+// order).  (One thread per column walked all rows alone: 114 us for a [700 x 250] matrix.)
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A,
                                                      float* __restrict__ out, int rows, int cols,
                                                      int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
+  __shared__ float part[8][32];
+  const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   float s = 0.f;
-  for (int r = 0; r < rows; ++r) s += A[(long)r * cols + c];
-  out[c] = accumulate ? out[c] + s : s;
+  if (c < cols)
+    for (int r = g; r < rows; r += 8) s += A[(long)r * cols + c];
+  part[g][cl] = s;
+  __syncthreads();
+  if (g == 0 && c < cols) {
+    float t = part[0][cl];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) t += part[q][cl];
+    out[c] = accumulate ? out[c] + t : t;
+  }
 }
 
 extern "C" {
@@ -225,8 +292,17 @@ int iic_gemm_f32(const float* A, long sam, long sak, const float* B, long sbk, l
                  void* stream) {
   if (!A || !B || !C || M <= 0 || Nn <= 0 || K <= 0) return IIC_ERR_ARG;
   dim3 grid((M + 31) / 32, (Nn + 31) / 32);
-  hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(64), 0, (hipStream_t)stream, A, sam, sak, B, sbk,
-                     sbn, bias, C, scm, M, Nn, K, accumulate);
+  const long tiles = (long)grid.x * grid.y;
+  // long K and too few tiles to fill 1024 SIMDs: split K over the waves of a block
+  if (K >= 1024 && tiles * 8 <= 2048)
+    hipLaunchKernelGGL((gemm_f32_kw_kernel<8>), grid, dim3(512), 0, (hipStream_t)stream, A, sam, sak, B, sbk, sbn,
+                       bias, C, scm, M, Nn, K, accumulate);
+  else if (K >= 512 && tiles * 4 <= 2048)
+    hipLaunchKernelGGL((gemm_f32_kw_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, A, sam, sak, B, sbk, sbn,
+                       bias, C, scm, M, Nn, K, accumulate);
+  else
+    hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(64), 0, (hipStream_t)stream, A, sam, sak, B, sbk,
+                       sbn, bias, C, scm, M, Nn, K, accumulate);
   return iic_launch_status();
 }
 
@@ -268,7 +344,7 @@ int iic_softmax_bwd(const float* probs, const float* dprobs, float* dlogits, int
 
 int iic_colsum_f32(const float* A, float* out, int rows, int cols, int accumulate, void* stream) {
   if (!A || !out || rows <= 0 || cols <= 0) return IIC_ERR_ARG;
-  hipLaunchKernelGGL(colsum_kernel, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, A,
+  hipLaunchKernelGGL(colsum_kernel, dim3((cols + 31) / 32), dim3(256), 0, (hipStream_t)stream, A,
                      out, rows, cols, accumulate);
   return iic_launch_status();
 }
