@@ -183,7 +183,7 @@ def cpu_baseline_mnist(batch=700, budget_s=40.0):
                     % (imgs.size(0), len(times) - 1)}
 
 
-def reference_api_rate(cfg, dev, imgs, imgs_tf, pairs, steps, auto_branch=False):
+def reference_api_rate(cfg, dev, imgs, imgs_tf, pairs, steps, auto_branch=False, graph_forward=False):
   """The same step through the reference's OWN call sequence (cluster_sobel.py:235-272 as the
   unchanged script issues it): net(x) -> python list of sub-head tensors, IID_loss once per
   sub-head, `+=` / `/=` averaging, stock torch.optim.Adam, `.item()` reads of the loss
@@ -194,9 +194,14 @@ def reference_api_rate(cfg, dev, imgs, imgs_tf, pairs, steps, auto_branch=False)
   from iic_amd.transforms import sobel_process
   torch.manual_seed(0)
   net = archs.ClusterNet5g(cfg).to(dev).train()
-  opt = torch.optim.Adam(net.parameters(), lr=1e-4)
-  prev_auto = ops.AUTO_BRANCH[0]
+  if graph_forward:      # what `python -m iic_amd.run` sets up: get_opt("Adam") is rebound to the fused HIP Adam
+    from iic_amd.optim import Adam
+    opt = Adam(net.parameters(), lr=1e-4)
+  else:
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+  prev_auto, prev_graph = ops.AUTO_BRANCH[0], ops.GRAPH_FORWARD[0]
   ops.AUTO_BRANCH[0] = bool(auto_branch)
+  ops.GRAPH_FORWARD[0] = bool(graph_forward)
 
   def step():
     net.zero_grad()
@@ -216,7 +221,7 @@ def reference_api_rate(cfg, dev, imgs, imgs_tf, pairs, steps, auto_branch=False)
     avg.backward()
     opt.step()
     return v
-  for _ in range(2):
+  for _ in range(4 if graph_forward else 2):      # (a shape is captured after it has been seen twice)
     step()
   torch.cuda.synchronize()
   t0 = time.perf_counter()
@@ -224,12 +229,17 @@ def reference_api_rate(cfg, dev, imgs, imgs_tf, pairs, steps, auto_branch=False)
     v = step()
   torch.cuda.synchronize()
   dt = (time.perf_counter() - t0) / steps
-  ops.AUTO_BRANCH[0] = prev_auto
-  return {"paired_images_per_sec": pairs / dt, "ms_per_step": 1e3 * dt, "final_loss": v,
-          "what": "list-returning net(x), IID_loss per sub-head, torch.optim.Adam, loss .item() "
-                  "every step, eager launches -- the unchanged script's call sequence"
-                  + (", its two forwards on two streams (what `python -m iic_amd.run` does: "
-                     "iic_amd.ops.auto_branch)" if auto_branch else ", one stream")}
+  ops.AUTO_BRANCH[0], ops.GRAPH_FORWARD[0] = prev_auto, prev_graph
+  what = ("list-returning net(x), IID_loss per sub-head, %s, loss .item() every step -- the unchanged script's "
+          "call sequence" % ("the fused HIP Adam behind get_opt" if graph_forward else "torch.optim.Adam"))
+  if graph_forward:
+    what += (", its two forwards on two streams and each forward / backward replayed as a captured HIP graph "
+             "(iic_amd/graphed.py: what `python -m iic_amd.run` does by default)")
+  elif auto_branch:
+    what += ", eager launches, its two forwards on two streams (iic_amd.ops.auto_branch)"
+  else:
+    what += ", eager launches, one stream"
+  return {"paired_images_per_sec": pairs / dt, "ms_per_step": 1e3 * dt, "final_loss": v, "what": what}
 
 
 SEG_CONFIGS = {
@@ -706,6 +716,8 @@ def main():
   if world == 1 and not args.no_reference_api:
     ref_api = reference_api_rate(cfg, dev, imgs, imgs_tf, args.pairs, args.steps)
     ref_api["two_streams"] = reference_api_rate(cfg, dev, imgs, imgs_tf, args.pairs, args.steps, auto_branch=True)
+    ref_api["graphed"] = reference_api_rate(cfg, dev, imgs, imgs_tf, args.pairs, args.steps, auto_branch=True,
+                                            graph_forward=True)
   loss_val = float(last.detach())
   if world > 1:
     t = torch.tensor([dt], device=dev, dtype=torch.float64)

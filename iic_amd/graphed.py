@@ -1,0 +1,200 @@
+"""HIP-graph replay for the DROP-IN path: the training forwards (and their backwards) of an architecture
+driven by an UNCHANGED reference script.
+
+iic_amd.graph.CapturedStep / CapturedPairStep capture a whole step, which needs the step as ONE callable --
+bench.py has that, the reference's scripts do not: between `net(all_imgs)`, `net(all_imgs_tf)`, the
+per-sub-head `IID_loss` calls, `.item()`, `backward()` and `optimiser.step()`
+(/root/reference/code/scripts/cluster/cluster_sobel.py:235-272) runs the script's own Python.  But ~95 % of
+a step's ~1100 launches sit inside the two forwards and their two backwards, which the script enters through
+OUR forward and autograd.  So each training forward of a given (input shape, head, position in the step) is
+captured once -- after WARMUP eager occurrences -- as two HIP graphs:
+
+    forward graph :  static input  -> the architecture's forward (weight re-layout, convs, BN, heads)
+    backward graph:  static output gradients -> torch.autograd.grad w.r.t. every parameter
+
+and a later call is `copy_ into the static input -> replay -> static outputs` inside an autograd.Function
+whose backward is `copy_ the incoming gradients -> replay -> return the static parameter gradients` (autograd
+accumulates them into .grad as in the eager run).  The losses, the optimiser and everything the script does
+in between stay eager -- so `update_lr` (code/utils/cluster/general.py:20-23, an in-place edit of
+optimiser.param_groups) keeps working with no device-side learning rate, and a shape the graph was not
+captured for (the last, smaller batch of an epoch) simply runs eager.
+
+Works under iic_amd.ops.auto_branch (the first forward of a step on a side stream): the BatchNorm
+running-statistic updates a branch forward postpones to the join (ops._DEFERRED_RUNNING) are recorded at
+capture time and re-queued at every replay; both positions re-lay their own bf16 weight operands inside
+their forward graph (one operand set per branch, ops / archs.cluster._ConvHolder.weights).
+
+Switch: ops.GRAPH_FORWARD[0] (env IIC_GRAPH_FORWARD; `python -m iic_amd.run` turns it on).
+"""
+import sys
+
+import torch
+
+from . import ops
+from .archs import cluster as _cl
+
+WARMUP = 2          # eager occurrences of a key before it is captured
+_FAILED = object()
+
+
+def _flat(out):
+  if torch.is_tensor(out):
+    return [out], None
+  assert isinstance(out, (list, tuple)) and all(torch.is_tensor(t) for t in out), \
+      "graphed forward: the architecture must return a tensor or a list of tensors"
+  return list(out), type(out)
+
+
+class _ViewGraph(object):
+  def __init__(self, fwd, mod, x, args, kwargs, res_branch):
+    self.params = [p for p in mod.parameters() if p.requires_grad]
+    self.static_in = x.detach().clone()
+    cur = torch.cuda.current_stream()
+    self.cap = torch.cuda.Stream()
+    self.cap.wait_stream(cur)
+    pool = torch.cuda.graph_pool_handle()
+    mode = "thread_local" if torch.distributed.is_available() and torch.distributed.is_initialized() else "global"
+    n_def = len(ops._DEFERRED_RUNNING)
+    _cl.bump_weights_epoch()                 # the bf16 operand re-layout belongs INSIDE the forward graph
+    # The captured forward sees the parameters through leaf ALIASES created on the capture stream (same
+    # storage): the parameters' own AccumulateGrad nodes live on the stream the script's warm-up steps
+    # ran on -- usually the legacy default stream --, and the captured backward touching them makes the
+    # autograd engine synchronise the capture stream with that stream, which ends the capture with a
+    # crash in hipStreamEndCapture (tools/graphed_probe.py: fine when the warm-up ran on a side stream).
+    with torch.cuda.stream(self.cap):
+      self.leaves = [p.detach().requires_grad_(True) for p in self.params]
+    self.g_f = torch.cuda.CUDAGraph()
+    ops._CAPTURE_PROXIES[0] = {id(p): q for p, q in zip(self.params, self.leaves)}
+    # Resource namespace (PT buffer pool, statistic accumulators, scratch, weight operands are keyed by
+    # ops.BRANCH): the forward and the backward of a view are captured back to back, so the pool believes the
+    # view's saved activations are free again when the NEXT position is captured -- although at replay the
+    # other view's forward runs between this view's forward and backward.  Positions that share a real
+    # branch (one-stream runs) therefore get a namespace of their own.
+    prev_branch = ops.BRANCH[0]
+    ops.BRANCH[0] = res_branch
+    try:
+      with torch.cuda.graph(self.g_f, pool=pool, stream=self.cap, capture_error_mode=mode):
+        with torch.enable_grad():
+          out = fwd(mod, self.static_in, *args, **kwargs)
+    finally:
+      ops._CAPTURE_PROXIES[0] = None
+      ops.BRANCH[0] = prev_branch
+    self.outs, self.out_type = _flat(out)
+    # running-statistic updates this forward postponed to the join (branch mode): the same (static) tensors
+    # at every replay
+    self.deferred = list(ops._DEFERRED_RUNNING[n_def:])
+    self.gouts = [torch.zeros_like(o) for o in self.outs]
+    self.g_b = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(self.g_b, pool=pool, stream=self.cap, capture_error_mode=mode):
+      grads = torch.autograd.grad(self.outs, self.leaves, self.gouts, allow_unused=True)
+    self.grads = list(grads)
+    cur.wait_stream(self.cap)
+    self.static_outs = [o.detach() for o in self.outs]
+    self.first = True
+
+
+class _GraphedFn(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, vg, x, *params):
+    vg.static_in.copy_(x)
+    vg.g_f.replay()
+    if not vg.first:                         # (at capture the forward itself queued them)
+      ops._DEFERRED_RUNNING.extend(vg.deferred)
+    vg.first = False
+    ctx.vg = vg
+    return tuple(o.detach() for o in vg.static_outs)       # fresh tensor objects over the static storage
+
+  @staticmethod
+  def backward(ctx, *gouts):
+    vg = ctx.vg
+    # a .grad that still aliases our static buffer (gradient accumulation over several backward passes,
+    # or zero_grad(set_to_none=False)) must not be overwritten by the replay
+    for p, g in zip(vg.params, vg.grads):
+      if g is not None and p.grad is not None and p.grad.data_ptr() == g.data_ptr():
+        p.grad = p.grad.clone()
+    for s, g in zip(vg.gouts, gouts):
+      if g is None:
+        s.zero_()
+      else:
+        s.copy_(g)
+    vg.g_b.replay()
+    # fresh aliases of the static gradient buffers: AccumulateGrad takes the first arrival as .grad without
+    # a copy (it owns the only reference to the alias) and adds the second view's in place
+    return (None, None) + tuple(None if g is None else g.detach() for g in vg.grads)
+
+
+def _state(mod):
+  st = mod.__dict__.get("_iic_graphed")
+  if st is None:
+    st = {"epoch": None, "pos": 0, "graphs": {}, "warm": {}, "res": {}}
+    mod.__dict__["_iic_graphed"] = st
+  return st
+
+
+def eligible(mod, x, args, kwargs):
+  return (ops.GRAPH_FORWARD[0] and mod.training and torch.is_grad_enabled() and torch.is_tensor(x) and x.is_cuda
+          and not x.requires_grad and not args and set(kwargs) <= {"head"}
+          and (ops.BRANCH[0] == 0 or ops.BRANCH[0] in ops._NO_PROXY_BRANCHES)    # (parameters, not leaf aliases)
+          and ops.PT_DTYPE[0] is ops.BF16 and not torch.cuda.is_current_stream_capturing())
+
+
+def _epoch(mod):
+  """Changes whenever the optimiser has stepped: iic_amd.optim.Adam bumps the weights epoch (its kernels write
+  through raw pointers), a torch optimiser bumps the parameters' version counters."""
+  p = next((q for q in mod.parameters() if q.requires_grad), None)
+  return (_cl._WEIGHTS_EPOCH[0], None if p is None else p._version)
+
+
+def forward(fwd, mod, x, args, kwargs):
+  """Called by ops.auto_branch's wrapper for an eligible training forward (inside the branch context when
+  there is one).  Returns the forward's result, from a replayed graph when this key has been captured."""
+  st = _state(mod)
+  ep = _epoch(mod)
+  if st["epoch"] != ep:                      # the optimiser stepped: a new step begins
+    st["epoch"], st["pos"] = ep, 0
+  pos = st["pos"]
+  st["pos"] += 1
+  key = (tuple(x.shape), x.dtype, x.device.index, kwargs.get("head"), pos, ops.BRANCH[0])
+  # resource namespace of this position (see _ViewGraph): its real branch, unless an earlier position of the
+  # step lives there already (one-stream runs) -- the eager warm-up occurrences use the same namespace, so
+  # that its PT buffers exist (zero-filled ONCE) before the capture; a buffer first allocated inside a
+  # capture would be zero-filled by every replay (measured: 1.2 ms per step for one view's activations)
+  res = st["res"].get(key)
+  if res is None:
+    b = ops.BRANCH[0]
+    clash = any(k[:4] == key[:4] and k[4] < pos and r == b for k, r in st["res"].items())
+    res = st["res"][key] = (100 + pos) if clash else b
+    if clash:
+      ops._NO_PROXY_BRANCHES.add(res)        # a namespace, not a stream branch: parameters stay themselves
+
+  def eager():
+    if res == ops.BRANCH[0]:
+      return fwd(mod, x, *args, **kwargs)
+    prev = ops.BRANCH[0]
+    ops.BRANCH[0] = res
+    try:
+      return fwd(mod, x, *args, **kwargs)
+    finally:
+      ops.BRANCH[0] = prev
+  vg = st["graphs"].get(key)
+  if vg is _FAILED:
+    return eager()
+  if vg is None:
+    n = st["warm"].get(key, 0)
+    if n < WARMUP:
+      st["warm"][key] = n + 1
+      return eager()
+    try:
+      vg = _ViewGraph(fwd, mod, x, args, kwargs, res)
+    except Exception as e:                   # noqa: BLE001 -- never take a run down over an optimisation
+      sys.stderr.write("[iic_amd.graphed] capture failed for %r (%s: %s): eager launches for this shape\n"
+                       % (key, type(e).__name__, e))
+      st["graphs"][key] = _FAILED
+      return eager()
+    st["graphs"][key] = vg
+    # the capture bumped the weights epoch (so that the re-layout kernels are part of the graph); this
+    # forward still belongs to the step that was running
+    st["epoch"] = _epoch(mod)
+  outs = _GraphedFn.apply(vg, x, *vg.params)
+  outs = list(outs)
+  return outs[0] if vg.out_type is None else vg.out_type(outs)

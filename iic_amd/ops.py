@@ -51,8 +51,16 @@ USE_PROXIES = [os.environ.get("IIC_BRANCH_PROXIES", "1") != "0"]
 _NO_PROXY_BRANCHES = set()
 
 
+_CAPTURE_PROXIES = [None]   # iic_amd.graphed: {id(param): leaf alias} while a view's graphs are captured
+
+
 def pv(p):
   """Parameter as seen by the current branch (the parameter itself on the main branch)."""
+  cp = _CAPTURE_PROXIES[0]
+  if cp is not None and p is not None:
+    q = cp.get(id(p))
+    if q is not None:
+      return q
   b = BRANCH[0]
   if b == 0 or p is None or not p.requires_grad or not USE_PROXIES[0] or b in _NO_PROXY_BRANCHES:
     return p
@@ -174,25 +182,36 @@ _FEATURE_FLAGS = ("trunk_features", "penultimate_features", "kmeans_use_features
 _DEFERRED_LIMIT = 1024
 
 
+# Graph replay of the training forwards / backwards for unchanged scripts (iic_amd/graphed.py);
+# `python -m iic_amd.run` switches it on (IIC_GRAPH_FORWARD=0 keeps eager launches).
+GRAPH_FORWARD = [os.environ.get("IIC_GRAPH_FORWARD", "0") == "1"]
+
+
 def auto_branch(fwd):
   """Decorator for the architectures' forward()."""
   def wrapped(self, x, *a, **k):
     if BRANCH[0] == 0 and (_PENDING_JOIN or _DEFERRED_RUNNING) and (
         not self.training or not torch.is_grad_enabled() or len(_DEFERRED_RUNNING) > _DEFERRED_LIMIT):
       join()      # evaluation must see up-to-date running statistics; bound the postponed list
+    run = fwd
+    if GRAPH_FORWARD[0]:
+      from . import graphed
+      if graphed.eligible(self, x, a, k):
+        def run(self_, x_, *a_, **k_):      # captured-graph replay once this (shape, head, position) is warm
+          return graphed.forward(fwd, self_, x_, a_, k_)
     if (AUTO_BRANCH[0] and self.training and torch.is_grad_enabled() and BRANCH[0] == 0
         and not _PENDING_JOIN and torch.is_tensor(x) and x.is_cuda
         and not any(k.get(f) for f in _FEATURE_FLAGS)):
       with branch(proxies=False) as br:
         x.record_stream(br.side)         # allocated on the caller's stream, consumed on the side stream
-        return fwd(self, x, *a, **k)
+        return run(self, x, *a, **k)
     if not torch.is_grad_enabled():
       mark = POOL.mark()                 # evaluation: nothing will release the activations later
       try:
         return fwd(self, x, *a, **k)
       finally:
         POOL.sweep(mark)
-    return fwd(self, x, *a, **k)
+    return run(self, x, *a, **k)
   wrapped.__name__ = getattr(fwd, "__name__", "forward")
   wrapped.__doc__ = fwd.__doc__
   wrapped.__wrapped__ = fwd          # inspect.signature() shows the architecture's own parameters

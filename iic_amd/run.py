@@ -95,6 +95,9 @@ def main(argv=None):
   # the two forwards of the scripts' train step on two streams (iic_amd.ops.auto_branch);
   # IIC_AUTO_BRANCH=0 keeps everything on one stream
   ops.AUTO_BRANCH[0] = os.environ.get("IIC_AUTO_BRANCH", "1") != "0"
+  # ... and each of them (with its backward) replayed as a captured HIP graph once its shape has been seen
+  # twice (iic_amd/graphed.py); IIC_GRAPH_FORWARD=0 keeps eager launches
+  ops.GRAPH_FORWARD[0] = os.environ.get("IIC_GRAPH_FORWARD", "1") != "0"
   if int(os.environ.get("WORLD_SIZE", "1")) > 1:
     import torch
     import torch.distributed as dist

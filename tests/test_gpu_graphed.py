@@ -1,0 +1,103 @@
+"""iic_amd/graphed.py: the drop-in path's training forwards / backwards replayed as captured HIP graphs.
+The reference script's own call sequence (cluster_sobel.py:235-272: net(x) -> list, IID_loss per sub-head,
+`+=` / `/=`, .item(), backward, optimiser.step, zero_grad) must give BIT-IDENTICAL losses, parameters and
+running statistics with and without the replay, with one and two streams; a learning-rate edit in the
+style of update_lr (code/utils/cluster/general.py:20-23) must take effect on the next replayed step; a
+batch of another shape (the last batch of an epoch) must fall back to eager launches."""
+import types
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(graph, auto_branch, steps=7, lr_cut_at=None, odd_batch_at=None, two_head=False):
+  from iic_amd import archs, ops
+  from iic_amd.losses import IID_loss
+  from iic_amd.optim import Adam
+  from iic_amd.transforms import sobel_process
+  dev = torch.device("cuda:0")
+  torch.manual_seed(0)
+  if two_head:
+    cfg = types.SimpleNamespace(in_channels=2, input_sz=32, batchnorm_track=True, num_sub_heads=2,
+                                output_k_A=12, output_k_B=5)
+    net = archs.ClusterNet5gTwoHead(cfg).to(dev).train()
+  else:
+    cfg = types.SimpleNamespace(in_channels=2, input_sz=32, batchnorm_track=True, num_sub_heads=2, output_k=10)
+    net = archs.ClusterNet5g(cfg).to(dev).train()
+  opt = Adam(net.parameters(), lr=1e-3)
+  g = torch.Generator().manual_seed(1)
+  base = torch.rand(8, 1, 32, 32, generator=g)
+  imgs = base.repeat(3, 1, 1, 1).to(dev)
+  imgs_tf = (torch.flip(imgs, dims=[3]) * 0.9 + 0.03).clamp(0, 1)
+  prev = ops.AUTO_BRANCH[0], ops.GRAPH_FORWARD[0]
+  ops.AUTO_BRANCH[0], ops.GRAPH_FORWARD[0] = auto_branch, graph
+  losses = []
+  try:
+    for s in range(steps):
+      if lr_cut_at is not None and s == lr_cut_at:
+        for grp in opt.param_groups:          # update_lr (general.py:20-23)
+          grp["lr"] *= 0.1
+      a, b = imgs, imgs_tf
+      if odd_batch_at is not None and s == odd_batch_at:
+        a, b = imgs[:18], imgs_tf[:18]
+      for head in (("A", "B") if two_head else (None,)):
+        net.zero_grad()
+        kw = {} if head is None else {"head": head}
+        xo = net(sobel_process(a, False), **kw)
+        xt = net(sobel_process(b, False), **kw)
+        avg = None
+        for i in range(2):
+          l, _ = IID_loss(xo[i], xt[i], lamb=1.0)
+          avg = l if avg is None else avg + l
+        avg = avg / 2
+        losses.append(avg.item())
+        avg.backward()
+        opt.step()
+    torch.cuda.synchronize()
+    graphs = net.__dict__.get("_iic_graphed", {"graphs": {}})["graphs"]
+    return losses, {k: v.detach().clone() for k, v in net.state_dict().items()}, len(graphs)
+  finally:
+    ops.AUTO_BRANCH[0], ops.GRAPH_FORWARD[0] = prev
+    ops.join()
+
+
+@pytest.mark.parametrize("auto_branch", [False, True])
+def test_graphed_forward_is_bit_identical_to_eager(auto_branch):
+  l0, s0, n0 = _run(False, auto_branch)
+  l1, s1, n1 = _run(True, auto_branch)
+  assert n0 == 0 and n1 == 2                       # two positions (first / second forward of a step) captured
+  assert l0 == l1, (l0, l1)
+  for k in s0:
+    assert torch.equal(s0[k], s1[k]), k
+  assert s1["trunk.bn1.num_batches_tracked"].item() == 2 * 7
+
+
+def test_graphed_two_head_net_keys_graphs_by_head():
+  l0, s0, _ = _run(False, True, two_head=True)
+  l1, s1, n1 = _run(True, True, two_head=True)
+  assert n1 == 4                                   # (head A, head B) x (first, second forward)
+  assert l0 == l1
+  for k in s0:
+    assert torch.equal(s0[k], s1[k]), k
+
+
+def test_update_lr_changes_the_next_replayed_step():
+  """The optimiser is not part of the captured graphs: an in-place learning-rate edit (update_lr) between two
+  replayed steps changes the very next update, exactly as in the eager run."""
+  la, sa, _ = _run(True, True, lr_cut_at=5)
+  lb, sb, _ = _run(True, True)
+  le, se, _ = _run(False, True, lr_cut_at=5)
+  assert la[:6] == lb[:6] and la[6] != lb[6]       # step 5's update used the new rate: step 6's loss differs
+  assert la == le
+  for k in sa:
+    assert torch.equal(sa[k], se[k]), k
+
+
+def test_other_batch_shape_falls_back_to_eager_launches():
+  la, sa, na = _run(True, True, odd_batch_at=5)
+  le, se, _ = _run(False, True, odd_batch_at=5)
+  assert na == 2 and la == le
+  for k in sa:
+    assert torch.equal(sa[k], se[k]), k

@@ -239,4 +239,3 @@ def test_unchanged_segmentation_twohead_script_keyword_loss_call(tmp_path):
   assert c["seg_loss_positional"] == 2
   assert set(c["seg_loss_kwargs"]) <= set(b["seg_loss_params"][2:])
   assert b["seg_loss_params"][:2] == ["x1_outs", "x2_outs"]
-  assert "best.pytorch" in res["files"] or "latest.pytorch" in res["files"]
