@@ -86,6 +86,8 @@ _SIGNATURES = {
   "iic_avgpool_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
   "iic_avgpool_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
   "iic_gemm_f32": (c_int, [_P, c_long, c_long, _P, c_long, c_long, _P, _P, c_long, c_int, c_int, c_int, c_int, _P]),
+  "iic_gemm_f32_ws_floats": (c_long, [c_long, c_long, c_long, c_long, c_int, c_int, c_int]),
+  "iic_gemm_f32_ws": (c_int, [_P, c_long, c_long, _P, c_long, c_long, _P, _P, c_long, c_int, c_int, c_int, c_int, _P, c_long, _P]),
   "iic_gemm_f32_splitk": (c_int, [_P, c_long, c_long, _P, c_long, c_long, _P, c_long, c_int, c_int, c_int, c_int, _P]),
   "iic_seg_window_gather": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
   "iic_seg_window_scatter": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),

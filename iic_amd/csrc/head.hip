@@ -173,6 +173,126 @@ __global__ __launch_bounds__(64 * KW) void gemm_f32_kw_kernel(const float* __res
   }
 }
 
+
+// LDS-tiled fp32 GEMM (same contract as gemm_f32_kernel): 64 x 64 tile per 4-wave block, K-tiles of 32 staged
+// through double-buffered LDS with COALESCED global loads -- the one-wave kernels above read their operands
+// with one 4-byte load per lane at the row stride (32 different lines per instruction), which made the long-K
+// products of the VGG-style heads 6x slower than the fp32 MFMA rate (ClusterNet6c k = 280: logits
+// [700 x 1400] over K = 4608 took 341 us).  AKC / BKC: the operand's unit stride runs along k (else along
+// m / n): decides how the 256 threads walk the tile so that a wave's lanes read consecutive addresses.
+// gridDim.z > 1: the K-tiles are split between gridDim.z blocks whose partial tiles go to
+// ws[z][M][Nn]; gemm_f32_fold_kernel adds them in z order (deterministic, no atomics) -- for launches with
+// too few tiles for the chip.  Products and sums are exact fp32 MFMA (32x32x2).
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(256) void gemm_f32_tiled_kernel(const float* __restrict__ A, long sam, long sak,
+                                                              const float* __restrict__ B, long sbk, long sbn,
+                                                              const float* __restrict__ bias,
+                                                              float* __restrict__ Cm, long scm, int M, int Nn,
+                                                              int K, int accumulate, float* __restrict__ ws) {
+  constexpr int TK = 32, LD = 65;
+  __shared__ float sA[2][TK * LD], sB[2][TK * LD];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int i = lane & 31, kk = lane >> 5;
+  const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+  const int ntiles = (K + TK - 1) / TK;
+  const int S = gridDim.z, z = blockIdx.z;
+  const int per = (ntiles + S - 1) / S;
+  const int t0 = z * per, t1 = min(ntiles, t0 + per);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float ra[8], rb[8];
+  auto gload = [&](int t) {
+    const int k0 = t * TK;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      int row, k;
+      if (AKC) { k = tid & 31; row = u * 8 + (tid >> 5); } else { row = tid & 63; k = u * 4 + (tid >> 6); }
+      ra[u] = (m0 + row < M && k0 + k < K) ? A[(long)(m0 + row) * sam + (long)(k0 + k) * sak] : 0.f;
+      if (BKC) { k = tid & 31; row = u * 8 + (tid >> 5); } else { row = tid & 63; k = u * 4 + (tid >> 6); }
+      rb[u] = (n0 + row < Nn && k0 + k < K) ? B[(long)(k0 + k) * sbk + (long)(n0 + row) * sbn] : 0.f;
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      int row, k;
+      if (AKC) { k = tid & 31; row = u * 8 + (tid >> 5); } else { row = tid & 63; k = u * 4 + (tid >> 6); }
+      sA[buf][k * LD + row] = ra[u];
+      if (BKC) { k = tid & 31; row = u * 8 + (tid >> 5); } else { row = tid & 63; k = u * 4 + (tid >> 6); }
+      sB[buf][k * LD + row] = rb[u];
+    }
+  };
+  if (t0 < t1) {
+    gload(t0);
+    lstore(0);
+    if (t0 + 1 < t1) gload(t0 + 1);
+  }
+  for (int t = t0; t < t1; ++t) {
+    const int cur = (t - t0) & 1;
+    __syncthreads();               // buffer `cur` complete; everyone is done reading the other one
+    if (t + 1 < t1) lstore(cur ^ 1);
+    if (t + 2 < t1) gload(t + 2);
+#pragma unroll
+    for (int k2 = 0; k2 < TK / 2; ++k2) {
+      const float a = sA[cur][(2 * k2 + kk) * LD + wm * 32 + i];
+      const float b = sB[cur][(2 * k2 + kk) * LD + wn * 32 + i];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+  }
+  const int col = n0 + wn * 32 + i;
+  if (S > 1) {
+    float* o = ws + (long)z * M * Nn;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm * 32 + mfma32_row(r, lane);
+      if (row < M && col < Nn) o[(long)row * Nn + col] = acc[r];
+    }
+    return;
+  }
+  const float bv = (bias && col < Nn) ? bias[col] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = m0 + wm * 32 + mfma32_row(r, lane);
+    if (row < M && col < Nn) {
+      float* o = Cm + (long)row * scm + col;
+      float v = acc[r] + bv;
+      if (accumulate) v += *o;
+      *o = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void gemm_f32_fold_kernel(const float* __restrict__ ws, int S,
+                                                             const float* __restrict__ bias,
+                                                             float* __restrict__ Cm, long scm, int M, int Nn,
+                                                             int accumulate) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long mn = (long)M * Nn;
+  if (idx >= mn) return;
+  const int row = (int)(idx / Nn), col = (int)(idx % Nn);
+  float v = ws[idx];
+  for (int q = 1; q < S; ++q) v += ws[(long)q * mn + idx];
+  if (bias) v += bias[col];
+  float* o = Cm + (long)row * scm + col;
+  if (accumulate) v += *o;
+  *o = v;
+}
+
+static bool gemm_tiled_ok(long sam, long sak, long sbk, long sbn, int M, int Nn, int K) {
+  return (sak == 1 || sam == 1) && (sbk == 1 || sbn == 1) && K >= 128 && (long)M * Nn >= 64 * 64 * 8;
+}
+// K-split factor the tiled kernel wants for this product (1 = none): about 1024 blocks, at least 4 K-tiles each
+static int gemm_tiled_split(int M, int Nn, int K) {
+  const long nt = (long)((M + 63) / 64) * ((Nn + 63) / 64);
+  const int ktiles = (K + 31) / 32;
+  int s = (int)((1024 + nt - 1) / nt);
+  if (s > ktiles / 4) s = ktiles / 4;
+  if (s > 16) s = 16;
+  return s < 1 ? 1 : s;
+}
+
 // one wave per row of k logits
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ logits,
                                                           float* __restrict__ probs, int rows,
@@ -287,10 +407,36 @@ int iic_avgpool_bwd(const float* dfeats, void* din_pt, int N, int H, int W, int 
   return iic_launch_status();
 }
 
-int iic_gemm_f32(const float* A, long sam, long sak, const float* B, long sbk, long sbn,
-                 const float* bias, float* C, long scm, int M, int Nn, int K, int accumulate,
-                 void* stream) {
+long iic_gemm_f32_ws_floats(long sam, long sak, long sbk, long sbn, int M, int Nn, int K) {
+  if (M <= 0 || Nn <= 0 || K <= 0 || !gemm_tiled_ok(sam, sak, sbk, sbn, M, Nn, K)) return 0;
+  const int S = gemm_tiled_split(M, Nn, K);
+  return S > 1 ? (long)S * M * Nn : 0;
+}
+
+int iic_gemm_f32_ws(const float* A, long sam, long sak, const float* B, long sbk, long sbn,
+                    const float* bias, float* C, long scm, int M, int Nn, int K, int accumulate,
+                    float* ws, long ws_floats, void* stream) {
   if (!A || !B || !C || M <= 0 || Nn <= 0 || K <= 0) return IIC_ERR_ARG;
+  // LDS-tiled kernel wherever an operand's unit stride allows coalesced tile loads and the product is big
+  // enough to matter (the small sub-head GEMMs of ClusterNet5g stay on the one-wave kernels); without a
+  // workspace no K split
+  if (gemm_tiled_ok(sam, sak, sbk, sbn, M, Nn, K)) {
+    int S = ws ? gemm_tiled_split(M, Nn, K) : 1;
+    if (S > 1 && (long)S * M * Nn > ws_floats) S = (int)(ws_floats / ((long)M * Nn));
+    if (S < 1) S = 1;
+    dim3 tg((M + 63) / 64, (Nn + 63) / 64, S);
+#define GT_LAUNCH(AK_, BK_)                                                                          \
+    hipLaunchKernelGGL((gemm_f32_tiled_kernel<AK_, BK_>), tg, dim3(256), 0, (hipStream_t)stream,     \
+                       A, sam, sak, B, sbk, sbn, bias, C, scm, M, Nn, K, accumulate, ws)
+    if (sak == 1) { if (sbk == 1) GT_LAUNCH(true, true); else GT_LAUNCH(true, false); }
+    else { if (sbk == 1) GT_LAUNCH(false, true); else GT_LAUNCH(false, false); }
+    if (S > 1) {
+      const long mn = (long)M * Nn;
+      hipLaunchKernelGGL(gemm_f32_fold_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0,
+                         (hipStream_t)stream, ws, S, bias, C, scm, M, Nn, accumulate);
+    }
+    return iic_launch_status();
+  }
   dim3 grid((M + 31) / 32, (Nn + 31) / 32);
   const long tiles = (long)grid.x * grid.y;
   // long K and too few tiles to fill 1024 SIMDs: split K over the waves of a block
@@ -304,6 +450,12 @@ int iic_gemm_f32(const float* A, long sam, long sak, const float* B, long sbk, l
     hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(64), 0, (hipStream_t)stream, A, sam, sak, B, sbk,
                        sbn, bias, C, scm, M, Nn, K, accumulate);
   return iic_launch_status();
+}
+
+int iic_gemm_f32(const float* A, long sam, long sak, const float* B, long sbk, long sbn,
+                 const float* bias, float* C, long scm, int M, int Nn, int K, int accumulate,
+                 void* stream) {
+  return iic_gemm_f32_ws(A, sam, sak, B, sbk, sbn, bias, C, scm, M, Nn, K, accumulate, nullptr, 0, stream);
 }
 
 /* split-K variant: C must be zero-initialised (or hold the value to accumulate onto); the K

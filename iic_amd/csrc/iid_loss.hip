@@ -175,6 +175,137 @@ __global__ __launch_bounds__(1024) void iid_loss_kernel(
 }
 
 // ---------------------------------------------------------------------------------
+// 2b. the same k x k stage for LARGE k (over-clustering heads: k = 280 at ClusterNet6c CIFAR-20,
+//     examples/commands.txt): one 1024-thread block per head is 5 blocks on a 256-CU chip and
+//     6 float64 logarithms per entry per pass -- 808 us per step at H = 5, k = 280.  Four
+//     launches of (G, H) blocks instead, the same arithmetic in the same float64, the per-row
+//     logarithms taken once per row; every sum in a fixed order (per-block partials folded by
+//     index), so the result does not depend on scheduling.
+//     extra workspace after the [H][k][k] doubles: psum[H][G], part4[H][G][4], row[H][4][k]
+//     (marginal, clamped-row-sum, log(clamped marginal), row term).
+// ---------------------------------------------------------------------------------
+#define IID_BIG_G 32
+__global__ __launch_bounds__(256) void iid_big_sym_kernel(const float* __restrict__ part, int nparts, int k,
+                                                          double* __restrict__ ws, double* __restrict__ psum) {
+  __shared__ double red[32];
+  const int g = blockIdx.x, G = gridDim.x, h = blockIdx.y, H = gridDim.y;
+  const long kk2 = (long)k * k;
+  const long per = (kk2 + G - 1) / G;
+  const long e0 = g * per, e1 = min(kk2, e0 + per);
+  double* Ps = ws + (long)h * kk2;
+  double s_loc = 0.0;
+  for (long idx = e0 + threadIdx.x; idx < e1; idx += 256) {
+    const int i = (int)(idx / k), j = (int)(idx % k);
+    double a = 0.0, b = 0.0;
+    for (int p = 0; p < nparts; ++p) {
+      const float* R = part + ((long)p * H + h) * kk2;
+      a += (double)R[(long)i * k + j];
+      b += (double)R[(long)j * k + i];
+    }
+    const double v = 0.5 * (a + b);
+    Ps[idx] = v;
+    s_loc += v;
+  }
+  const double t = block_sum_d(s_loc, red);
+  if (threadIdx.x == 0) psum[h * G + g] = t;
+}
+
+// one wave per row: marginals before clamping, row sums of the clamped joint, per-row logarithm and row term
+__global__ __launch_bounds__(256) void iid_big_rows_kernel(const double* __restrict__ ws, const double* __restrict__ psum,
+                                                           int G, int k, double eps, double* __restrict__ rows) {
+  const int h = blockIdx.y;
+  const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= k) return;
+  double S = 0.0;
+  for (int g = 0; g < G; ++g) S += psum[h * G + g];
+  const double invS = 1.0 / S;
+  const double* Ps = ws + (long)h * k * k;
+  double r = 0.0, rc = 0.0;
+  for (int j = lane; j < k; j += 64) {
+    const double P = Ps[(long)i * k + j] * invS;
+    r += P;
+    rc += (P < eps) ? eps : P;
+  }
+  r = wave_sum_d(r);
+  rc = wave_sum_d(rc);
+  if (lane == 0) {
+    double* o = rows + (long)h * 4 * k;
+    const bool mi = !(r < eps);
+    o[i] = r;
+    o[k + i] = rc;
+    o[2 * k + i] = log(mi ? r : eps);
+    o[3 * k + i] = mi ? rc / r : 0.0;
+  }
+}
+
+// PASS 0: loss terms and sum(dP o P) per block -> part4;  PASS 1: fold part4, write the losses and dR
+template <int PASS>
+__global__ __launch_bounds__(256) void iid_big_terms_kernel(const double* __restrict__ ws, const double* __restrict__ psum,
+                                                            const double* __restrict__ rows, double* __restrict__ part4,
+                                                            int k, double lamb, double eps, int detach_norm,
+                                                            float* __restrict__ loss_out, float* __restrict__ loss_nl_out,
+                                                            float* __restrict__ dR1, float* __restrict__ dR2) {
+  __shared__ double red[32];
+  const int g = blockIdx.x, G = gridDim.x, h = blockIdx.y;
+  const long kk2 = (long)k * k;
+  const long per = (kk2 + G - 1) / G;
+  const long e0 = g * per, e1 = min(kk2, e0 + per);
+  double S = 0.0;
+  for (int q = 0; q < G; ++q) S += psum[h * G + q];
+  const double invS = 1.0 / S;
+  const double* Ps = ws + (long)h * kk2;
+  const double* li_ = rows + (long)h * 4 * k + 2 * k;
+  const double* rt_ = rows + (long)h * 4 * k + 3 * k;
+  double l1 = 0.0, l2 = 0.0, g1 = 0.0, g2 = 0.0;
+  if (PASS == 1) {
+    for (int q = 0; q < G; ++q) {
+      const double* p4 = part4 + ((long)h * G + q) * 4;
+      l1 += p4[0];
+      l2 += p4[1];
+      g1 += p4[2];
+      g2 += p4[3];
+    }
+    if (detach_norm) g1 = g2 = 0.0;
+    if (g == 0 && threadIdx.x == 0) {
+      loss_out[h] = (float)l1;
+      loss_nl_out[h] = (float)l2;
+    }
+  }
+  for (long idx = e0 + threadIdx.x; idx < e1; idx += 256) {
+    const int i = (int)(idx / k), j = (int)(idx % k);
+    const double P = Ps[idx] * invS;
+    const bool mP = !(P < eps);
+    const double Pc = mP ? P : eps;
+    const double lP = log(Pc), li = li_[i], lj = li_[j];
+    const double rowi = rt_[i], colj = rt_[j];
+    const double d1 = (mP ? -(lP - lamb * lj - lamb * li) - 1.0 : 0.0) + lamb * (rowi + colj);
+    const double d2 = (mP ? -(lP - lj - li) - 1.0 : 0.0) + (rowi + colj);
+    if (PASS == 0) {
+      l1 -= Pc * (lP - lamb * lj - lamb * li);
+      l2 -= Pc * (lP - lj - li);
+      g1 += d1 * P;
+      g2 += d2 * P;
+    } else {
+      dR1[(long)h * kk2 + idx] = (float)((d1 - g1) * invS);
+      dR2[(long)h * kk2 + idx] = (float)((d2 - g2) * invS);
+    }
+  }
+  if (PASS == 0) {
+    l1 = block_sum_d(l1, red);
+    l2 = block_sum_d(l2, red);
+    g1 = block_sum_d(g1, red);
+    g2 = block_sum_d(g2, red);
+    if (threadIdx.x == 0) {
+      double* p4 = part4 + ((long)h * G + g) * 4;
+      p4[0] = l1;
+      p4[1] = l2;
+      p4[2] = g1;
+      p4[3] = g2;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // 3. input gradients.  grid = (ceil(bn/32), ceil(k/32), 2*H), block = 64.
 //    which = 0:  dz [n][a] = sum_b G[a][b] z'[n][b]
 //    which = 1:  dz'[n][a] = sum_b G[b][a] z [n][b]   (G symmetric, so same read)
@@ -230,7 +361,32 @@ int iic_iid_nsplit(int bn) {
   return s;
 }
 
-long iic_iid_workspace_bytes(int H, int k) { return (long)H * k * k * (long)sizeof(double); }
+#define IID_BIG_MIN_K 96
+long iic_iid_workspace_bytes(int H, int k) {
+  return ((long)H * k * k + (long)H * IID_BIG_G * 5 + (long)H * 4 * k) * (long)sizeof(double);
+}
+
+static int iid_loss_launch(const float* partials, int nparts, int H, int k, double lamb, double eps, void* workspace,
+                           float* loss, float* loss_no_lamb, float* dR1, float* dR2, int detach_norm,
+                           hipStream_t st) {
+  if (k < IID_BIG_MIN_K) {
+    hipLaunchKernelGGL(iid_loss_kernel, dim3(H), dim3(1024), 0, st, partials, nparts, k, lamb, eps,
+                       (double*)workspace, loss, loss_no_lamb, dR1, dR2, detach_norm);
+    return iic_launch_status();
+  }
+  double* ws = (double*)workspace;
+  double* psum = ws + (long)H * k * k;
+  double* part4 = psum + (long)H * IID_BIG_G;
+  double* rows = part4 + (long)H * IID_BIG_G * 4;
+  const dim3 grid(IID_BIG_G, H);
+  hipLaunchKernelGGL(iid_big_sym_kernel, grid, dim3(256), 0, st, partials, nparts, k, ws, psum);
+  hipLaunchKernelGGL(iid_big_rows_kernel, dim3((k + 3) / 4, H), dim3(256), 0, st, ws, psum, IID_BIG_G, k, eps, rows);
+  hipLaunchKernelGGL(iid_big_terms_kernel<0>, grid, dim3(256), 0, st, ws, psum, rows, part4, k, lamb, eps,
+                     detach_norm, loss, loss_no_lamb, dR1, dR2);
+  hipLaunchKernelGGL(iid_big_terms_kernel<1>, grid, dim3(256), 0, st, ws, psum, rows, part4, k, lamb, eps,
+                     detach_norm, loss, loss_no_lamb, dR1, dR2);
+  return iic_launch_status();
+}
 
 int iic_iid_joint_raw(const float* z, const float* zt, float* partials, int H, int bn, int k,
                       long head_stride, long ld, int nsplit, void* stream) {
@@ -248,10 +404,8 @@ int iic_iid_loss_from_joint(const float* partials, int nparts, int H, int k, dou
   if (!partials || !workspace || !loss || !loss_no_lamb || !dR_loss || !dR_loss_no_lamb)
     return IIC_ERR_ARG;
   if (H <= 0 || k <= 0 || k > IID_MAXK || nparts <= 0) return IIC_ERR_ARG;
-  hipLaunchKernelGGL(iid_loss_kernel, dim3(H), dim3(1024), 0, (hipStream_t)stream, partials,
-                     nparts, k, lamb, eps, (double*)workspace, loss, loss_no_lamb, dR_loss,
-                     dR_loss_no_lamb, 0);
-  return iic_launch_status();
+  return iid_loss_launch(partials, nparts, H, k, lamb, eps, workspace, loss, loss_no_lamb, dR_loss,
+                         dR_loss_no_lamb, 0, (hipStream_t)stream);
 }
 
 // Same k x k stage for the segmentation losses: H = number of shifts (uncollapsed, one joint
@@ -263,10 +417,8 @@ int iic_seg_loss_from_joint(const float* partials, int nparts, int H, int k, dou
   if (!partials || !workspace || !loss || !loss_no_lamb || !dR_loss || !dR_loss_no_lamb)
     return IIC_ERR_ARG;
   if (H <= 0 || k <= 0 || k > IID_MAXK || nparts <= 0) return IIC_ERR_ARG;
-  hipLaunchKernelGGL(iid_loss_kernel, dim3(H), dim3(1024), 0, (hipStream_t)stream, partials,
-                     nparts, k, lamb, eps, (double*)workspace, loss, loss_no_lamb, dR_loss,
-                     dR_loss_no_lamb, detach_norm);
-  return iic_launch_status();
+  return iid_loss_launch(partials, nparts, H, k, lamb, eps, workspace, loss, loss_no_lamb, dR_loss,
+                         dR_loss_no_lamb, detach_norm, (hipStream_t)stream);
 }
 
 int iic_iid_grad(const float* z, const float* zt, const float* dR_loss,

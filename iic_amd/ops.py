@@ -727,9 +727,19 @@ def avgpool_bwd(dfeats, out_pt, N, H, W, P, C, mask_act=None):
   return out_pt
 
 
+_GEMM_WS = {}      # (branch, device) -> fp32 workspace of the K-split GEMMs (grown on demand, reused)
+
+
 def gemm_f32(A, sam, sak, B, sbk, sbn, C, scm, M, N, K, bias=None, accumulate=False):
-  check(lib().iic_gemm_f32(ptr(A), sam, sak, ptr(B), sbk, sbn, ptr(bias), ptr(C), scm, M, N, K,
-                           1 if accumulate else 0, stream_ptr()), "iic_gemm_f32")
+  need = lib().iic_gemm_f32_ws_floats(sam, sak, sbk, sbn, M, N, K)
+  ws = None
+  if need:
+    key = (BRANCH[0], C.device.index)
+    ws = _GEMM_WS.get(key)
+    if ws is None or ws.numel() < need:
+      ws = _GEMM_WS[key] = torch.empty(need, dtype=F32, device=C.device)
+  check(lib().iic_gemm_f32_ws(ptr(A), sam, sak, ptr(B), sbk, sbn, ptr(bias), ptr(C), scm, M, N, K,
+                              1 if accumulate else 0, ptr(ws), need, stream_ptr()), "iic_gemm_f32_ws")
   return C
 
 

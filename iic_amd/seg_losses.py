@@ -124,7 +124,7 @@ class _SegLossFn(torch.autograd.Function):
       part, ns = R, 1
     H = 1 if collapsed else nq * nq
     nparts = ns * nq * nq if collapsed else ns
-    ws = torch.empty(H * k * k, dtype=torch.float64, device=x1.device)
+    ws = torch.empty(L.iic_iid_workspace_bytes(H, k) // 8, dtype=torch.float64, device=x1.device)
     loss = torch.empty(H, dtype=F32, device=x1.device)
     loss_nl = torch.empty(H, dtype=F32, device=x1.device)
     dR1 = torch.empty((H, k, k), dtype=F32, device=x1.device)

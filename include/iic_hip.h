@@ -287,6 +287,13 @@ int iic_avgpool_bwd(const float* dfeats, void* din_pt, int N, int H, int W, int 
 int iic_gemm_f32(const float* A, long sam, long sak, const float* B, long sbk, long sbn,
                  const float* bias, float* C, long scm, int M, int Nn, int K, int accumulate,
                  void* stream);
+/* Same product with a caller-provided fp32 workspace of iic_gemm_f32_ws_floats(...) elements (0 = none needed):
+ * launches with too few output tiles for the chip split K between blocks, partial tiles go to the workspace
+ * and are folded in a fixed order (deterministic).  iic_gemm_f32 == this with ws = NULL (no split).          */
+long iic_gemm_f32_ws_floats(long sam, long sak, long sbk, long sbn, int M, int Nn, int K);
+int iic_gemm_f32_ws(const float* A, long sam, long sak, const float* B, long sbk, long sbn,
+                    const float* bias, float* C, long scm, int M, int Nn, int K, int accumulate,
+                    float* ws, long ws_floats, void* stream);
 int iic_gemm_f32_splitk(const float* A, long sam, long sak, const float* B, long sbk, long sbn,
                         float* C, long scm, int M, int Nn, int K, int splitk, void* stream);
 /* SegmentationNet10a head (net10a.py:44-59): PT feature window <-> fp32 matrix for the 1x1

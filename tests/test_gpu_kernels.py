@@ -111,6 +111,48 @@ def test_iid_loss_packed_heads_full_size_and_no_lamb_grad():
         assert np.linalg.norm(mine - ref) / nrm <= max(1e-5, np.linalg.norm(r32 - ref) / nrm)
 
 
+@pytest.mark.parametrize("k,bn", [(96, 300), (140, 700), (280, 700)])
+def test_iid_loss_large_k_multi_block_path(k, bn):
+  """Over-clustering heads (k = 280 at CIFAR-20, examples/commands.txt): k >= 96 takes the four-launch
+  multi-block k x k stage (iid_loss.hip 2b) -- same float64 arithmetic as the one-block kernel, checked
+  against the float64 oracle; at bn = 700 most of the k*k joint entries sit below EPS, so the clamp
+  branches (IID_losses.py:17-19) are exercised too.  Two runs agree bit for bit."""
+  from iic_amd.losses import IID_loss_heads
+  from oracle import iid_oracle
+  H = 3
+  zs, zts = [], []
+  for h in range(H):
+    z, zt = iid_oracle.make_softmax_pair(bn, k, "trained" if h != 1 else "init", 300 + h)
+    zs.append(z)
+    zts.append(zt)
+  w1 = [1.0, -0.5, 2.0]
+  w2 = [0.25, 1.0, 0.0]
+
+  def run():
+    Z = torch.from_numpy(np.stack(zs, 1)).to(dev()).requires_grad_(True)
+    ZT = torch.from_numpy(np.stack(zts, 1)).to(dev()).requires_grad_(True)
+    loss, loss_nl = IID_loss_heads(Z, ZT, lamb=1.2)
+    ((loss * torch.tensor(w1, device=dev())).sum() + (loss_nl * torch.tensor(w2, device=dev())).sum()).backward()
+    return loss, loss_nl, Z.grad, ZT.grad
+  loss, loss_nl, gz, gzt = run()
+  loss_b, loss_nl_b, gz_b, gzt_b = run()
+  assert torch.equal(loss, loss_b) and torch.equal(loss_nl, loss_nl_b)
+  assert torch.equal(gz, gz_b) and torch.equal(gzt, gzt_b)
+  for h in range(H):
+    l, lnl, dz, dzt = iid_oracle.iid_loss_np(zs[h], zts[h], 1.2, w1[h], w2[h])
+    assert abs(loss[h].item() - l) <= _iid_tol(l), (h, loss[h].item(), l)
+    assert abs(loss_nl[h].item() - lnl) <= _iid_tol(lnl)
+    a32 = torch.from_numpy(zs[h]).requires_grad_(True)
+    b32 = torch.from_numpy(zts[h]).requires_grad_(True)
+    l32, lnl32 = iid_oracle.IID_loss(a32, b32, lamb=1.2)
+    (w1[h] * l32 + w2[h] * lnl32).backward()
+    for mine, ref, r32 in ((gz[:, h].cpu().numpy(), dz, a32.grad.numpy()),
+                           (gzt[:, h].cpu().numpy(), dzt, b32.grad.numpy())):
+      nrm = np.linalg.norm(ref)
+      assert nrm > 0
+      assert np.linalg.norm(mine - ref) / nrm <= max(1e-5, np.linalg.norm(r32 - ref) / nrm)
+
+
 def test_iid_loss_full_size_invariances():
   """Size-independent properties at the north-star size (660 x 70): the loss is symmetric in the two
   views (the joint is symmetrised, IID_losses.py:44), invariant to a permutation of the batch rows
