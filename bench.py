@@ -96,13 +96,16 @@ class ConvTimer(object):
 
 
 def pmc_traffic():
-  """HBM bytes per conv_igemm launch from the committed rocprofv3 PMC passes of this same
-  command (tools/pmc_traffic.py; PMC cannot be collected from inside the process), or None."""
-  p = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-  try:
-    return float(json.load(open(p))["conv_igemm_hbm_bytes_per_launch"])
-  except Exception:
-    return None
+  """(HBM bytes per conv_igemm launch, file it came from) -- from the newest committed rocprofv3 PMC passes
+  of this same command (tools/pmc_traffic.py; PMC cannot be collected from inside the process), or
+  (None, None)."""
+  import glob
+  for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")), reverse=True):
+    try:
+      return float(json.load(open(p))["conv_igemm_hbm_bytes_per_launch"]), os.path.relpath(p, ROOT)
+    except Exception:
+      continue
+  return None, None
 
 
 def cpu_baseline(n_pairs=96, steps=3, budget_s=90.0):
@@ -749,8 +752,9 @@ def main():
         out["roofline"] = {
           "bound": "mfma", "kernel": "conv_igemm_kernel + conv_igemm_bd_kernel (fwd + bwd-data implicit GEMM, bf16 MFMA)",
           "achieved": s["tflops"], "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-          "frac": s["tflops"] / BF16_PEAK_TFLOPS, "traffic": pmc_traffic(),
-          "traffic_unit": "HBM bytes per launch (PMC passes of this command, profiles/r02_pmc_traffic.json)",
+          "frac": s["tflops"] / BF16_PEAK_TFLOPS, "traffic": pmc_traffic()[0],
+          "traffic_source": pmc_traffic()[1],
+          "traffic_unit": "HBM bytes per launch (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/pmc_traffic.py)",
           "algorithmic_bytes_per_launch": s["alg_bytes"],
           "launches_timed": s["launches"], "avg_launch_us": s["avg_us"],
           "timed_in": "%d instrumented steps run after the timed region (same batch, same state)" % min(args.steps, 3),

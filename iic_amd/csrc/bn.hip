@@ -523,6 +523,9 @@ int iic_bn_finalize(float* stats, const float* gamma, const float* beta, float* 
                     void* stream) {
   if (!gamma || !beta || !coef || C <= 0) return IIC_ERR_ARG;
   if (training && (!stats || count <= 0)) return IIC_ERR_ARG;
+  // the statistic cells are read AND zeroed by 16-channel groups: a ragged last group would race with the
+  // clamped lanes of its neighbours (every network on the path has C % 64 == 0)
+  if (training && (C & 15)) return IIC_ERR_ARG;
   if (!training && (!running_mean || !running_var)) return IIC_ERR_ARG;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream,
                      stats, gamma, beta, running_mean, running_var, num_batches_tracked, coef, C,
@@ -617,7 +620,7 @@ int iic_bn_bwd_reduce(const void* dout, const void* act, const void* y, const vo
 
 int iic_bn_bwd_finalize(float* sums, const float* gamma, const float* coef, float* bcoef,
                         float* dgamma, float* dbeta, int C, long count, void* stream) {
-  if (!sums || !gamma || !coef || !bcoef || C <= 0 || count <= 0) return IIC_ERR_ARG;
+  if (!sums || !gamma || !coef || !bcoef || C <= 0 || count <= 0 || (C & 15)) return IIC_ERR_ARG;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0,
                      (hipStream_t)stream, sums, gamma, coef, bcoef, dgamma, dbeta, C, count);
   return iic_launch_status();

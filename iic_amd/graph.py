@@ -39,7 +39,7 @@ class CapturedStep(object):
     # capture on the SAME stream the warm-up ran on: autograd's AccumulateGrad nodes remember the
     # stream they were created on; with a different capture stream the engine forks every
     # gradient accumulation onto the old stream (a branchy graph -- and on ROCm 7.0 consecutive
-    # replays of such a graph were observed to overlap: tools/graph_debug.py)
+    # replays of such a graph were observed to overlap: tools/graph_probes.py graph_debug)
     with torch.cuda.graph(self.graph, stream=side):
       self.out = fn()
     self.replays = 0

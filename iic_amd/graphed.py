@@ -60,7 +60,7 @@ class _ViewGraph(object):
     # storage): the parameters' own AccumulateGrad nodes live on the stream the script's warm-up steps
     # ran on -- usually the legacy default stream --, and the captured backward touching them makes the
     # autograd engine synchronise the capture stream with that stream, which ends the capture with a
-    # crash in hipStreamEndCapture (tools/graphed_probe.py: fine when the warm-up ran on a side stream).
+    # crash in hipStreamEndCapture (tools/graph_probes.py graphed_probe: fine when the warm-up ran on a side stream).
     with torch.cuda.stream(self.cap):
       self.leaves = [p.detach().requires_grad_(True) for p in self.params]
     self.g_f = torch.cuda.CUDAGraph()

@@ -19,7 +19,7 @@ F32 = torch.float32
 # Branches: two independent forwards of a step (net(all_imgs), net(all_imgs_tf):
 # cluster_sobel.py:238-239) can run on two HIP streams -- as two parallel branches of the captured
 # step graph -- so that the tail of one view's kernel is filled by the other view's next kernel
-# (measured: 42.6 -> 38.2 ms for the two forward+backward passes, tools/dual_branch_probe.py).
+# (measured: 42.6 -> 38.2 ms for the two forward+backward passes, tools/graph_probes.py dual_branch_probe).
 # Everything the kernels share through HBM is therefore keyed by the branch index: PT buffers,
 # BatchNorm statistic accumulators, split-K / stem scratch, the bf16 weight operands.  A branch's
 # autograd Functions remember their branch (ctx.branch) and restore it in backward, where the

@@ -55,16 +55,49 @@ def _refactor(src, path):
   return str(_tool.refactor_string(src, path))
 
 
+def _int_kind(v):
+  """0: not an integer operand; 1: python / numpy integer scalar or integer ndarray; 2: integer torch tensor."""
+  if isinstance(v, bool):
+    return 1
+  if isinstance(v, numbers.Integral):
+    return 1
+  mod = type(v).__module__
+  if mod == "numpy" or mod.startswith("numpy."):
+    dt = getattr(v, "dtype", None)
+    return 1 if dt is not None and dt.kind in "iub" else 0
+  if mod == "torch" or mod.startswith("torch."):
+    isf = getattr(v, "is_floating_point", None)
+    if isf is None:
+      return 0
+    return 0 if (isf() or v.is_complex()) else 2
+  return 0
+
+
 def py2div(a, b):
-  """Python-2 ``a / b``: floor division for two ints, true division otherwise."""
-  if isinstance(a, numbers.Integral) and isinstance(b, numbers.Integral):
+  """Python-2 ``a / b`` without ``from __future__ import division`` (the reference's modules have none):
+  floor division for two ints -- python ints, numpy integer scalars and integer ndarrays (numpy's classic
+  division) --, C-style truncating division for integer torch tensors (torch 0.4.1's integer `/`), true
+  division otherwise."""
+  ka, kb = _int_kind(a), _int_kind(b)
+  if ka and kb:
+    if ka == 2 or kb == 2:
+      import torch
+      return torch.div(a, b, rounding_mode="trunc")
     return a // b
   return a / b
 
 
 def py2idiv(a, b):
   """Python-2 ``a /= b`` (in place where the type supports it, e.g. torch tensors)."""
-  if isinstance(a, numbers.Integral) and isinstance(b, numbers.Integral):
+  ka, kb = _int_kind(a), _int_kind(b)
+  if ka and kb:
+    if ka == 2:
+      return a.div_(b, rounding_mode="trunc")
+    if kb == 2:
+      import torch
+      return torch.div(a, b, rounding_mode="trunc")
+    if hasattr(a, "__ifloordiv__"):
+      return operator.ifloordiv(a, b)
     return a // b
   return operator.itruediv(a, b)
 

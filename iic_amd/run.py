@@ -17,9 +17,15 @@ the full batch; each architecture's TRAINING forward keeps this rank's contiguou
 stay together: both views are sliced identically), evaluation forwards run the whole batch on
 every rank; the losses all-reduce the raw joint; parameter gradients are SUM-all-reduced right
 before every optimiser step; every rank constructs identical initial weights (the scripts seed
-nothing: construction runs under a fixed forked RNG seed, $IIC_INIT_SEED) and only rank 0
-writes checkpoints.  The script's torch.nn.DataParallel degenerates to a plain call with one
-visible device.
+nothing: construction runs under a fixed forked RNG seed, $IIC_INIT_SEED).  The scripts write
+config.pickle / config.txt / figures / checkpoints into <out_root>/<model_ind> with plain open() /
+savefig / torch.save on every rank: ranks > 0 get `--out_root <out_root>/.rank<r>` (their own scratch
+copy; with --restart it is first filled from rank 0's directory), and torch.save is a no-op there, so the
+directory a user looks at is written by rank 0 alone.  python / numpy / torch RNGs are seeded identically
+on every rank ($IIC_RUN_SEED, default 0), so the (unseeded) loaders shuffle and augment identically and the
+row slices of all ranks together are exactly one global batch, and segmentation's per-step shift
+(_draw_sparse_shift) is the same on every rank before the joints are all-reduced.  The script's
+torch.nn.DataParallel degenerates to a plain call with one visible device.
 """
 import os
 import sys
@@ -85,6 +91,38 @@ def setup_distributed(backend="nccl", ref_modules=("code.archs", "code.archs.clu
   return handle
 
 
+def per_rank_out_root(argv, rank, default_root=None):
+  """argv with `--out_root` re-pointed at <out_root>/.rank<rank> for rank > 0 (returns (argv, rank-0 root,
+  this rank's root)); an absent --out_root is left alone when no default is known."""
+  argv = list(argv)
+  root = default_root
+  idx = None
+  for i, a in enumerate(argv):
+    if a == "--out_root" and i + 1 < len(argv):
+      idx, root = i + 1, argv[i + 1]
+    elif a.startswith("--out_root="):
+      idx, root = i, a.split("=", 1)[1]
+  if rank == 0 or root is None:
+    return argv, root, root
+  mine = os.path.join(root, ".rank%d" % rank)
+  if idx is None:
+    argv += ["--out_root", mine]
+  elif argv[idx].startswith("--out_root="):
+    argv[idx] = "--out_root=" + mine
+  else:
+    argv[idx] = mine
+  return argv, root, mine
+
+
+def _model_ind(argv):
+  for i, a in enumerate(argv):
+    if a == "--model_ind" and i + 1 < len(argv):
+      return argv[i + 1]
+    if a.startswith("--model_ind="):
+      return a.split("=", 1)[1]
+  return None
+
+
 def main(argv=None):
   argv = list(sys.argv[1:] if argv is None else argv)
   if not argv:
@@ -105,6 +143,22 @@ def main(argv=None):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group(os.environ.get("IIC_DIST_BACKEND", "nccl"))
     setup_distributed()
+    import random
+    import shutil
+    import numpy as np
+    seed = int(os.environ.get("IIC_RUN_SEED", "0"))
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    rank = dist.get_rank()
+    # (the scripts' default --out_root is the authors' cluster path: only an explicit one is re-pointed)
+    argv, root0, mine = per_rank_out_root(argv, rank)
+    if rank > 0 and root0 is not None:
+      os.makedirs(mine, exist_ok=True)
+      ind = _model_ind(argv)
+      if "--restart" in argv and ind is not None and os.path.isdir(os.path.join(root0, ind)):
+        shutil.copytree(os.path.join(root0, ind), os.path.join(mine, ind), dirs_exist_ok=True)
+    dist.barrier()
   target = argv[0]
   sys.argv = argv
   py2compat.run_script(target)

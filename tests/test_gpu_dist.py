@@ -49,4 +49,4 @@ def test_two_rank_bench_modes_agree():
   assert la == la and la == lb and lg == la, (lg, la, lb)
   # (no timing assertion: two gloo ranks time-slicing ONE GPU stall for seconds inside the host-side
   # collectives between graph segments -- an artefact of this rig; a single process with device-only
-  # stand-ins for the collectives enqueues the cut step in 0.5 ms: tools/graph_cut_probe.py)
+  # stand-ins for the collectives enqueues the cut step in 0.5 ms: tools/graph_probes.py graph_cut_probe)

@@ -71,6 +71,28 @@ def test_translate_division_semantics():
   assert g["x"] == 3.5
 
 
+def test_division_of_integer_arrays_and_tensors():
+  """Python 2 / numpy classic division and torch 0.4.1's integer `/` (the reference has no
+  `from __future__ import division`): integer ndarrays floor, integer tensors truncate, anything with a
+  float operand divides truly; the in-place form keeps the object."""
+  import numpy as np
+  import torch
+  from iic_amd.py2compat import py2div, py2idiv
+  a = np.array([7, -7, 9])
+  assert py2div(a, 2).tolist() == [3, -4, 4] and py2div(a, 2).dtype.kind == "i"
+  assert py2div(a, np.array([2, 2, 4])).tolist() == [3, -4, 2]
+  assert py2div(a, 2.0).dtype.kind == "f" and py2div(np.int64(7), 2) == 3 and py2div(np.float32(7), 2) == 3.5
+  t = torch.tensor([7, -7, 9])
+  assert py2div(t, 2).tolist() == [3, -3, 4] and not py2div(t, 2).is_floating_point()
+  assert py2div(t.float(), 2).tolist() == [3.5, -3.5, 4.5] and py2div(t, 2.0).is_floating_point()
+  b = np.array([8, 9])
+  assert py2idiv(b, 4) is b and b.tolist() == [2, 2]
+  u = torch.tensor([8, 9])
+  assert py2idiv(u, 4) is u and u.tolist() == [2, 2]
+  f = torch.tensor([1.0, 2.0])
+  assert py2idiv(f, 4) is f and f.tolist() == [0.25, 0.5]
+
+
 def test_implicit_relative_imports_and_stubs(tmp_path):
   root = tmp_path / "tree"
   (root / "code" / "pkg").mkdir(parents=True)

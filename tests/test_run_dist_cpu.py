@@ -132,3 +132,15 @@ def test_run_hook_chain_world2_matches_single_process():
     assert np.abs(flat - ref_flat).max() < 1e-10, np.abs(flat - ref_flat).max()
     assert save_patched == (rank != 0)      # one checkpoint writer
   assert np.array_equal(res[0][5], res[1][5])
+
+
+def test_per_rank_out_root_rewrites_only_ranks_above_zero():
+  """The unchanged scripts write config.pickle / config.txt / figures with plain open() on every rank
+  (cluster_sobel.py:117-124): under torchrun ranks > 0 are pointed at <out_root>/.rank<r>."""
+  from iic_amd.run import per_rank_out_root
+  argv = ["code.scripts.cluster.cluster_sobel", "--out_root", "/x/y", "--model_ind", "3"]
+  assert per_rank_out_root(argv, 0) == (argv, "/x/y", "/x/y")
+  got, root0, mine = per_rank_out_root(argv, 2)
+  assert got == argv[:2] + ["/x/y/.rank2"] + argv[3:] and root0 == "/x/y" and mine == "/x/y/.rank2"
+  assert per_rank_out_root(["m", "--out_root=/x/y"], 1)[0] == ["m", "--out_root=/x/y/.rank1"]
+  assert per_rank_out_root(["m", "--model_ind", "3"], 1) == (["m", "--model_ind", "3"], None, None)
