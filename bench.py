@@ -524,6 +524,9 @@ def main():
   ap.add_argument("--no-reference-api", action="store_true",
                   help="skip the second measurement through the reference's own call sequence "
                        "(net(x) -> list, IID_loss per sub-head, torch.optim.Adam; reported in config)")
+  ap.add_argument("--strong", action="store_true",
+                  help="N > 1: keep the GLOBAL batch at --pairs (default 660, the reference's batch_sz) and give "
+                       "every rank pairs/N of it, instead of --pairs per rank (weak scaling, the default)")
   ap.add_argument("--with-augment", action="store_true",
                   help="also build every step's batch inside the timed region with the GPU paired "
                        "augmentation (iic_amd.augment, SURVEY 8f rank 1) from a resident uint8 "
@@ -555,6 +558,9 @@ def main():
     from iic_amd import dist as idist
     idist.enable()
   assert args.gpus == world or world == 1, "launch with torchrun --nproc-per-node == --gpus"
+  if args.strong and world > 1:
+    assert args.pairs % world == 0, "--strong: --pairs must divide by the number of ranks"
+    args.pairs //= world
 
   from iic_amd import archs, dist as idist, ops
   from iic_amd.losses import IID_loss_heads
@@ -582,6 +588,8 @@ def main():
   # weak scaling: every rank owns `pairs` pairs (its shard of the global batch of pairs*world)
   imgs, imgs_tf = make_batch(args.pairs, INPUT_SZ, dev, seed=rank)
   params = list(net.parameters())
+  groups = net.grad_groups()       # gradient buckets of the data-parallel step, in backward order
+  assert sorted(id(p) for g in groups for p in g) == sorted(id(p) for p in params)
   # N > 1 with eager launches (IIC_DIST_GRAPH=0, or after a failed capture / self-check): by default
   # the two views run on two streams (measured at N = 1:
   # 42.0 -> 38.0 ms without graphs); the side view's gradients are folded into .grad after backward
@@ -633,7 +641,7 @@ def main():
       reducer.finish()
     elif world > 1:
       ops.fold_branch_grads(params)          # .grad += the side view's gradients (one foreach add)
-      idist.all_reduce_grads(params)
+      idist.all_reduce_grad_groups(groups)   # one flat bucket per layer group, as the staged graphs do
     opt.step()
     return loss
 
@@ -646,21 +654,37 @@ def main():
   def finish():
     if world > 1:
       ops.fold_branch_grads(params)          # .grad += the side view's gradients (one foreach add)
-      idist.all_reduce_grads(params)
+      idist.all_reduce_grad_groups(groups)
     opt.step()
 
   run = step
   launch_mode = None
+  replay_events = []          # staged N > 1 replay: host issue order of backward groups / bucket all-reduces
   if use_branch:
     from iic_amd.graph import CapturedPairStep
     try:
-      run = CapturedPairStep(lambda: net.forward_packed(sobel_process(imgs, False)),
-                             lambda: net.forward_packed(sobel_process(imgs_tf, False)),
-                             loss_fn, finish, lambda: net.zero_grad(set_to_none=True),
-                             warmup=max(1, args.warmup))       # warm-up steps are real steps
-      launch_mode = "hip-graph replay: %d linear graph segments, the two views on two streams%s" % (
-        4 + len(run.g_l.items) - run.g_l.cuts + len(run.g_opt.items) - run.g_opt.cuts,
-        ", %d collectives issued eagerly between them" % (run.g_l.cuts + run.g_opt.cuts) if world > 1 else "")
+      staged = world > 1 and os.environ.get("IIC_DIST_STAGED", "1") != "0"
+      if staged:
+        # backward captured per layer group: a group's gradient bucket is all-reduced (third stream, async)
+        # while the groups below it still run backward
+        run = CapturedPairStep(lambda: net.forward_packed_taps(sobel_process(imgs, False)),
+                               lambda: net.forward_packed_taps(sobel_process(imgs_tf, False)),
+                               loss_fn, finish, lambda: net.zero_grad(set_to_none=True),
+                               warmup=max(1, args.warmup), grad_groups=groups, opt_step=opt.step,
+                               events=replay_events)
+        nseg = 2 + 3 * len(groups) + len(run.g_l.items) - run.g_l.cuts + len(run.g_opt.items) - run.g_opt.cuts
+        ncoll = run.g_l.cuts + run.g_opt.cuts + len(groups)
+        launch_mode = ("hip-graph replay: %d linear graph segments, the two views on two streams, backward staged "
+                       "in %d layer groups whose gradient buckets are all-reduced under the remaining backward, "
+                       "%d collectives issued eagerly between the segments" % (nseg, len(groups), ncoll))
+      else:
+        run = CapturedPairStep(lambda: net.forward_packed(sobel_process(imgs, False)),
+                               lambda: net.forward_packed(sobel_process(imgs_tf, False)),
+                               loss_fn, finish, lambda: net.zero_grad(set_to_none=True),
+                               warmup=max(1, args.warmup))       # warm-up steps are real steps
+        launch_mode = "hip-graph replay: %d linear graph segments, the two views on two streams%s" % (
+          4 + len(run.g_l.items) - run.g_l.cuts + len(run.g_opt.items) - run.g_opt.cuts,
+          ", %d collectives issued eagerly between them" % (run.g_l.cuts + run.g_opt.cuts) if world > 1 else "")
     except Exception as e:      # (N > 1 only: every rank issues the same collectives in either mode)
       if world == 1:
         raise
@@ -734,7 +758,7 @@ def main():
       "metric": "paired-images/sec, STL10 96x96 ClusterNet5g+IID_loss",
       "value": value, "unit": "paired-images/sec", "n_gpus": world, "steps": args.steps,
       "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-      "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+      "scaling": "strong" if (args.strong and world > 1) else "weak", "vs_baseline": None, "dtype": "bf16",
       "data": "synthetic" if aug is None else "synthetic uint8 dataset, GPU paired augmentation in the timed region",
       "config": {"workload": "STL10 96x96 ClusterNet5g IID+ (cluster_sobel.py train step), "
                              "batch %d pairs/GPU, 5 sub-heads, k=70, bf16 MFMA convs / fp32 "
@@ -743,6 +767,8 @@ def main():
                  "parallelism": "dp%d" % world, "final_loss": loss_val,
                  "streams": 2 if (use_branch or two_stream) else 1,
                  "launch": (launch_mode if use_branch else "hip-graph replay") if use_graph else "eager (python/ctypes)",
+                 "replay_issue_order": ["%s%s" % (e[0], "" if len(e) == 1 else e[1])
+                                        for e in replay_events[:2 * len(groups) + 1]] if (use_branch and replay_events) else None,
                  "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps,
                  "host_cpu_ms_per_step": 1e3 * c_enq / args.steps},
     }

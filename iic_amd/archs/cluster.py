@@ -526,9 +526,10 @@ class _HeadsFn(torch.autograd.Function):
     probs = ops.softmax_fwd(logits, N * H, k)
     ctx.save_for_backward(feats, Wcat, probs)
     ctx.hk = (H, k)
+    ctx.branch, ctx.pt_dtype = ops.BRANCH[0], ops.PT_DTYPE[0]   # (the K-split GEMM workspace is per branch)
     return probs.view(N, H, k)
 
-  @staticmethod
+  @ops.branch_backward
   def backward(ctx, dprobs):
     feats, Wcat, probs = ctx.saved_tensors
     H, k = ctx.hk
@@ -628,10 +629,19 @@ class ClusterNet5gTrunk(nn.Module):
       b._chain = link
     try:
       stem = _StemF32Fn if ops.PT_DTYPE[0] is torch.float32 else _StemFn
+      # layer-group boundaries for a STAGED backward (iic_amd.graph.CapturedPairStep, data parallel: the
+      # gradient bucket of a group is all-reduced while the groups below it still run backward)
+      taps = getattr(self, "_tap_sink", None)
       x = stem.apply(x, ops.pv(self.conv1.weight), ops.pv(self.bn1.weight), ops.pv(self.bn1.bias), self)
       x = self.layer1(x)
+      if taps is not None:
+        taps.append(x)
       x = self.layer2(x)
+      if taps is not None:
+        taps.append(x)
       x = self.layer3(x)
+      if taps is not None:
+        taps.append(x)
       if penultimate_features:
         return ops.pt_to_nchw(x, 1).reshape(x.size(0), -1)
       x = self.layer4(x)
@@ -672,6 +682,25 @@ class ClusterNet5g(nn.Module):
   def forward_packed(self, x):
     """All sub-head outputs as one [N, H, k] tensor (feeds IID_loss_heads; 3 loss launches)."""
     return self.head.forward_packed(self.trunk(x))
+
+  def grad_groups(self):
+    """Parameters by layer group in the order backward finishes their gradients: [heads + layer4, layer3,
+    layer2, layer1 + stem] -- the gradient buckets of the data-parallel step."""
+    t = self.trunk
+    return [list(self.head.parameters()) + list(t.layer4.parameters()), list(t.layer3.parameters()),
+            list(t.layer2.parameters()),
+            list(t.layer1.parameters()) + list(t.conv1.parameters()) + list(t.bn1.parameters())]
+
+  def forward_packed_taps(self, x):
+    """forward_packed plus the activations at the group boundaries, [input of group 0, of group 1, ...]
+    (= outputs of layer3, layer2, layer1): what a staged backward differentiates through."""
+    sink = []
+    self.trunk._tap_sink = sink
+    try:
+      out = self.forward_packed(x)
+    finally:
+      self.trunk._tap_sink = None
+    return out, sink[::-1]
 
   @ops.auto_branch
   def forward(self, x, kmeans_use_features=False, trunk_features=False, penultimate_features=False):

@@ -132,6 +132,25 @@ def all_reduce_grads(params, bucket_bytes=64 << 20):
   flush()
 
 
+def all_reduce_grad_groups(groups):
+  """SUM all-reduce of .grad, ONE flat bucket per parameter group, in list order -- the eager counterpart
+  of the staged backward of iic_amd.graph.CapturedPairStep (same collectives, same sizes, same order, so
+  ranks that replay graphs and ranks that launch eagerly stay compatible)."""
+  if not enabled():
+    return
+  for grp in groups:
+    members = [p for p in grp if p.grad is not None]
+    if not members:
+      continue
+    flat = torch.cat([p.grad.reshape(-1) for p in members])
+    all_reduce_sum_(flat)
+    off = 0
+    for p in members:
+      n = p.grad.numel()
+      p.grad.copy_(flat[off:off + n].view_as(p.grad))
+      off += n
+
+
 class GradReducer(object):
   """Bucketed SUM all-reduce of parameter gradients OVERLAPPED with the backward pass.
 

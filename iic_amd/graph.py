@@ -134,11 +134,39 @@ class CapturedPairStep(object):
   finish).  Their captures are cut at those calls and the collectives are issued eagerly on
   stream 1 between the graph segments at replay: the host enqueues ~10 launches per step instead
   of ~1100, and every rank issues the same collectives in the same order as the eager step does
-  (so a rank that fell back to eager launches stays compatible with ranks that replay)."""
+  (so a rank that fell back to eager launches stays compatible with ranks that replay).
 
-  def __init__(self, view_a, view_b, loss_fn, finish, zero_grad, warmup=2):
-    from . import ops
+  STAGED backward (`grad_groups`, data parallel): with one all-reduce in `finish` the gradient exchange
+  starts when both backwards are over and nothing is left to hide it behind.  Given the parameters by layer
+  group in backward order (ClusterNet5g.grad_groups()) and views that also return the activations at the
+  group boundaries (forward_packed_taps), each view's backward is captured as one linear graph PER GROUP
+  (torch.autograd.grad from the group's output to its input activation and its parameters).  At replay, as
+  soon as group g of both views has run, a third stream folds the two views' gradients of that group into
+  one flat bucket and issues its SUM all-reduce (async: RCCL's own stream) while streams 1 and 2 replay
+  group g+1; the optimiser graph waits for the buckets.  .grad of every parameter is a view into its bucket.
+  `finish` must then issue the SAME collectives for the eager warm-up steps (fold, one all-reduce per group
+  in order, optimiser step: iic_amd.dist.all_reduce_grad_groups) and `opt_step` is the optimiser step alone.
+  `events` (optional list) receives ("bwd", g) / ("reduce", g) / ("opt",) in host issue order at replay."""
+
+  def __init__(self, view_a, view_b, loss_fn, finish, zero_grad, warmup=2, grad_groups=None, opt_step=None,
+               events=None, force_staged=False):
+    from . import dist as idist, ops
     assert torch.cuda.is_available(), "CapturedPairStep needs a device"
+    # (force_staged: the staged capture without a process group -- tests / probes on one GPU)
+    self.staged = grad_groups is not None and (idist.enabled() or force_staged)
+    assert not self.staged or opt_step is not None, "staged backward: pass opt_step (the optimiser step alone)"
+    self.events = events
+    if grad_groups is not None:      # views return (output, boundary activations)
+      va, vb = view_a, view_b
+      self._taps = {}
+
+      def view_a():
+        out, self._taps["a"] = va()
+        return out
+
+      def view_b():
+        out, self._taps["b"] = vb()
+        return out
     self.fns = (view_a, view_b, loss_fn, finish, zero_grad)
     cur = torch.cuda.current_stream()
     self.s1, self.s2 = torch.cuda.Stream(), torch.cuda.Stream()
@@ -170,16 +198,78 @@ class CapturedPairStep(object):
       loss.backward()
       ga, gb = xa_d.grad, xb_d.grad
       self.out = loss.detach()
-    with torch.cuda.graph(self.g_ba, pool=pool_a, stream=s1, capture_error_mode=mode):
-      xa.backward(ga)
-    with torch.cuda.graph(self.g_bb, pool=pool_b, stream=s2, capture_error_mode=mode):
-      xb.backward(gb)
-    self.g_opt = _Segmented(pool_a, s1, mode)
-    with self.g_opt:
-      finish()
+    if self.staged:
+      self._capture_staged(xa, xb, ga, gb, grad_groups, opt_step, pool_a, pool_b, mode)
+    else:
+      with torch.cuda.graph(self.g_ba, pool=pool_a, stream=s1, capture_error_mode=mode):
+        xa.backward(ga)
+      with torch.cuda.graph(self.g_bb, pool=pool_b, stream=s2, capture_error_mode=mode):
+        xb.backward(gb)
+      self.g_opt = _Segmented(pool_a, s1, mode)
+      with self.g_opt:
+        finish()
     self._keep = (xa, xb, xa_d, xb_d, ga, gb)     # buffers that cross graph boundaries
     cur.wait_stream(s1)
     self.replays = 0
+
+  def _capture_staged(self, xa, xb, ga, gb, groups, opt_step, pool_a, pool_b, mode):
+    from . import ops
+    s1, s2 = self.s1, self.s2
+    self.s3 = s3 = torch.cuda.Stream()
+    pool_c = torch.cuda.graph_pool_handle()
+    n = len(groups)
+    taps_a, taps_b = self._taps["a"], self._taps["b"]
+    assert len(taps_a) == n - 1 and len(taps_b) == n - 1, "one boundary activation between consecutive groups"
+    self.g_ba, self.g_bb, self.g_fold, self.buckets = [], [], [], []
+    cur = [xa, xb]
+    gcur = [ga, gb]
+    keep = []
+    for g, grp in enumerate(groups):
+      grp = [p for p in grp if p.requires_grad]
+      res = []
+      for v, (stream, pool, taps, graphs) in enumerate(((s1, pool_a, taps_a, self.g_ba), (s2, pool_b, taps_b, self.g_bb))):
+        leaves = grp if v == 0 else [ops.branch_leaf(p, 1) for p in grp]
+        ins = ([taps[g]] if g < n - 1 else []) + leaves
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, pool=pool, stream=stream, capture_error_mode=mode):
+          r = torch.autograd.grad([cur[v]], ins, [gcur[v]], allow_unused=True)
+        graphs.append(gr)
+        if g < n - 1:
+          assert r[0] is not None, "group %d: no gradient reaches its input activation" % g
+          cur[v], gcur[v] = taps[g], r[0]
+          r = r[1:]
+        res.append(r)
+      keep.append(res)
+      # fold: bucket = view A's gradients + view B's, flat, on the third stream
+      members = [(p, a, b) for p, a, b in zip(grp, res[0], res[1]) if a is not None or b is not None]
+      flat = torch.empty(sum(p.numel() for p, _, _ in members), dtype=torch.float32, device=xa.device)
+      views, off = [], 0
+      for p, _, _ in members:
+        views.append(flat[off:off + p.numel()].view_as(p))
+        off += p.numel()
+      s3.wait_stream(s1)
+      s3.wait_stream(s2)
+      gf = torch.cuda.CUDAGraph()
+      with torch.cuda.graph(gf, pool=pool_c, stream=s3, capture_error_mode=mode):
+        first = [a if a is not None else b for _, a, b in members]
+        torch._foreach_copy_(views, first)
+        both = [(v, b) for v, (_, a, b) in zip(views, members) if a is not None and b is not None]
+        if both:
+          torch._foreach_add_([v for v, _ in both], [b for _, b in both])
+      self.g_fold.append(gf)
+      self.buckets.append(flat)
+      for (p, _, _), v in zip(members, views):
+        p.grad = v                       # the optimiser graph reads the all-reduced bucket
+      absent = set(id(p) for p in grp) - set(id(p) for p, _, _ in members)
+      for p in grp:
+        if id(p) in absent:
+          p.grad = None
+    ops.clear_branch_grads()
+    s1.wait_stream(s3)
+    self.g_opt = _Segmented(pool_a, s1, mode)
+    with self.g_opt:
+      opt_step()
+    self._keep_staged = keep
 
   def _eager_step(self):
     from . import ops
@@ -206,6 +296,38 @@ class CapturedPairStep(object):
       finish()
     return loss.detach()
 
+  def _replay_staged(self):
+    import torch.distributed as tdist
+    from . import dist as idist
+    s1, s2, s3 = self.s1, self.s2, self.s3
+    ev = self.events
+    works = []
+    for g in range(len(self.g_fold)):
+      with torch.cuda.stream(s2):
+        self.g_bb[g].replay()
+      with torch.cuda.stream(s1):
+        self.g_ba[g].replay()
+      if ev is not None:
+        ev.append(("bwd", g))
+      s3.wait_stream(s1)
+      s3.wait_stream(s2)
+      with torch.cuda.stream(s3):
+        self.g_fold[g].replay()
+        # asynchronous: RCCL works on its own stream, ordered after the fold; streams 1 and 2 go on
+        # with the next group (gloo: a worker thread, the host does not wait here either)
+        if idist.enabled():
+          works.append(tdist.all_reduce(self.buckets[g], op=tdist.ReduceOp.SUM, group=idist._STATE["group"],
+                                        async_op=True))
+      if ev is not None:
+        ev.append(("reduce", g))
+    with torch.cuda.stream(s1):
+      s1.wait_stream(s3)
+      for w in works:
+        w.wait()                # (stream 1 waits for the collective's stream; gloo: the host does)
+      if ev is not None:
+        ev.append(("opt",))
+      self.g_opt.replay()
+
   def __call__(self):
     s1, s2 = self.s1, self.s2
     cur = torch.cuda.current_stream()
@@ -218,12 +340,15 @@ class CapturedPairStep(object):
       s1.wait_stream(s2)
       self.g_l.replay()
     s2.wait_stream(s1)
-    with torch.cuda.stream(s2):
-      self.g_bb.replay()
-    with torch.cuda.stream(s1):
-      self.g_ba.replay()
-      s1.wait_stream(s2)
-      self.g_opt.replay()
+    if self.staged:
+      self._replay_staged()
+    else:
+      with torch.cuda.stream(s2):
+        self.g_bb.replay()
+      with torch.cuda.stream(s1):
+        self.g_ba.replay()
+        s1.wait_stream(s2)
+        self.g_opt.replay()
     cur.wait_stream(s1)
     self.replays += 1
     bump_weights_epoch()

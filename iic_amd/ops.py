@@ -75,6 +75,15 @@ def pv(p):
   return q
 
 
+def branch_leaf(p, index):
+  """The autograd leaf branch `index` saw for parameter p (its alias, or p itself when the branch ran
+  without aliases / never touched p)."""
+  ent = _PROXIES.get(id(p))
+  if ent is None or ent[0] is not p or index in _NO_PROXY_BRANCHES:
+    return p
+  return ent[1].get(index, p)
+
+
 def branch_grads(p):
   """Gradients the side branches accumulated for parameter p (list, possibly empty)."""
   ent = _PROXIES.get(id(p))

@@ -24,13 +24,14 @@ def _free_port():
   return p
 
 
-def _run(overlap, graph):
+def _run(overlap, graph, staged=True, extra=()):
   env = dict(os.environ, IIC_DIST_BACKEND="gloo", IIC_DIST_OVERLAP="1" if overlap else "0",
+             IIC_DIST_STAGED="1" if staged else "0",
              IIC_DIST_GRAPH="force" if graph else "0", PYTHONPATH=ROOT)   # force: skip bench.py's speed self-check
   r = subprocess.run([sys.executable, "-W", "ignore", "-m", "torch.distributed.run", "--nnodes=1",
                       "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
                       os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--pairs", "66",
-                      "--no-roofline"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+                      "--no-roofline"] + list(extra), env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
   lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
   assert r.returncode == 0 and lines, r.stdout[-2000:] + r.stderr[-2000:]
   assert "graph capture failed" not in r.stderr, r.stderr[-2000:]
@@ -40,7 +41,7 @@ def _run(overlap, graph):
 def test_two_rank_bench_modes_agree():
   """graph segments with eager collectives between them (the N > 1 default), eager launches on two
   streams, eager launches on one stream with the overlapped reducer: same training, same loss bits."""
-  g, a, b = _run(False, True), _run(False, False), _run(True, False)
+  g, a, b = _run(False, True, staged=False), _run(False, False), _run(True, False)
   assert g["n_gpus"] == 2 and g["config"]["streams"] == 2 and "collectives issued eagerly" in g["config"]["launch"]
   assert a["n_gpus"] == 2 and a["config"]["streams"] == 2 and a["config"]["launch"].startswith("eager")
   assert b["config"]["streams"] == 1
@@ -50,3 +51,23 @@ def test_two_rank_bench_modes_agree():
   # (no timing assertion: two gloo ranks time-slicing ONE GPU stall for seconds inside the host-side
   # collectives between graph segments -- an artefact of this rig; a single process with device-only
   # stand-ins for the collectives enqueues the cut step in 0.5 ms: tools/graph_probes.py graph_cut_probe)
+
+
+def test_staged_backward_issues_bucket_all_reduces_under_the_remaining_backward():
+  """Graph-segment mode with the backward captured per layer group (the N > 1 default): the gradient
+  bucket of group g is handed to the collective BEFORE the host replays group g+1 of either view, the
+  optimiser comes last -- and the training is bit-identical to the unstaged graph mode and to eager
+  launches (same sums in the same order: view A + view B, then ranks)."""
+  s, u = _run(False, True, staged=True), _run(False, True, staged=False)
+  assert "backward staged in 4 layer groups" in s["config"]["launch"]
+  assert s["config"]["replay_issue_order"] == ["bwd0", "reduce0", "bwd1", "reduce1", "bwd2", "reduce2",
+                                               "bwd3", "reduce3", "opt"]
+  assert u["config"]["replay_issue_order"] is None
+  assert s["config"]["final_loss"] == u["config"]["final_loss"], (s["config"]["final_loss"], u["config"]["final_loss"])
+
+
+def test_strong_scaling_mode_splits_the_global_batch():
+  """--strong: the global batch stays at --pairs, every rank takes pairs / N of it."""
+  r = _run(False, True, extra=("--strong",))
+  assert r["scaling"] == "strong" and r["config"]["global_batch_pairs"] == 66 and r["n_gpus"] == 2
+  assert r["config"]["final_loss"] == r["config"]["final_loss"]      # (not NaN)

@@ -139,6 +139,52 @@ def test_captured_and_branched_steps_track_the_eager_step(mode):
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("mode", ["pair", "staged"])
+def test_two_stream_graph_modes_with_k_split_head_gemm_are_bit_identical_to_eager(mode):
+  """Batch large enough (96 x 512 features) for the heads' backward GEMM to take the LDS-tiled kernel with
+  its K split over a workspace: the workspace is per branch, so the two views' backward graphs -- replayed
+  concurrently on two streams -- must not share it (a shared one made view A's gradients differ from
+  replay to replay).  `staged`: the backward captured per layer group (the data-parallel replay order,
+  forced here without a process group).  Six steps enqueued back to back, no host synchronisation."""
+  from iic_amd.graph import CapturedPairStep
+  from iic_amd.losses import IID_loss_heads
+  from iic_amd.optim import Adam
+  from iic_amd.transforms import sobel_process
+  imgs, imgs_tf = _batch(n=96)
+  runs = {}
+  for name in ("eager", mode):
+    net = _net()
+    opt = Adam(net.parameters(), lr=2e-4, capturable=name != "eager")
+    loss_fn = lambda a, b: IID_loss_heads(a, b, lamb=1.0)[0].mean()     # noqa: E731
+    if name == "eager":
+      run = _make_step(net, opt, imgs, imgs_tf, False)
+      run(); run()
+    elif name == "pair":
+      run = CapturedPairStep(lambda: net.forward_packed(sobel_process(imgs, False)),
+                             lambda: net.forward_packed(sobel_process(imgs_tf, False)),
+                             loss_fn, opt.step, lambda: net.zero_grad(set_to_none=True), warmup=2)
+    else:
+      events = []
+      run = CapturedPairStep(lambda: net.forward_packed_taps(sobel_process(imgs, False)),
+                             lambda: net.forward_packed_taps(sobel_process(imgs_tf, False)),
+                             loss_fn, opt.step, lambda: net.zero_grad(set_to_none=True), warmup=2,
+                             grad_groups=net.grad_groups(), opt_step=opt.step, events=events, force_staged=True)
+      assert run.staged and len(run.g_ba) == 4 and len(run.buckets) == 4
+    losses = [run().clone() for _ in range(6)]       # (a replay returns the same static tensor every time)
+    torch.cuda.synchronize()
+    runs[name] = ([float(l) for l in losses], [p.detach().clone() for p in net.parameters()])
+    if name == "staged":
+      assert events[:9] == [("bwd", 0), ("reduce", 0), ("bwd", 1), ("reduce", 1), ("bwd", 2), ("reduce", 2),
+                            ("bwd", 3), ("reduce", 3), ("opt",)]
+      # .grad of every parameter is a view into its group's flat bucket
+      for grp, flat in zip(net.grad_groups(), run.buckets):
+        lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
+        assert all(lo <= p.grad.data_ptr() < hi for p in grp if p.grad is not None)
+  assert runs[mode][0] == runs["eager"][0], (runs[mode][0], runs["eager"][0])
+  for a, b in zip(runs[mode][1], runs["eager"][1]):
+    assert torch.equal(a, b)
+
+
 def test_replay_back_to_back_equals_replay_with_syncs():
   from iic_amd.graph import CapturedStep
   from iic_amd.optim import Adam
