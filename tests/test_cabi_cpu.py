@@ -26,7 +26,7 @@ def test_header_symbols_exported_and_bound():
   L = _lib.lib()
   assert L.iic_version() >= 1
   assert L.iic_iid_nsplit(660) >= 1
-  assert L.iic_iid_workspace_bytes(5, 70) == 5 * 70 * 70 * 8
+  assert L.iic_iid_workspace_bytes(5, 70) >= 5 * 70 * 70 * 8      # [H][k][k] float64 + the multi-block stage's scratch
 
 
 def test_geom_struct_matches_header_size():
