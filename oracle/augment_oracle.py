@@ -20,13 +20,18 @@ itself (present: the arithmetic that matters -- bilinear resampling, ImageEnhanc
 HSV round trip, the L conversion -- is PIL's own code), with the RANDOM PARAMETERS made explicit
 so that a device implementation can be compared on identical parameters:
 
-PINNING.  The oracle runs the third-party arithmetic itself (PIL's resize / rotate / ImageEnhance /
-HSV conversion are called, not restated), but on the Pillow installed here (12.2.0), not on the
-reference's pinned Pillow 5.2.0 + torchvision 0.2.1 (package_versions.txt:73,115; neither is
-available offline).  The torchvision layer adds no arithmetic (it forwards to the PIL calls used
-below; its uint8 hue wrap is restated in tv_adjust_hue).  Parity of csrc/augment.hip is therefore
-pinned to this container's PIL bit for bit; drift between Pillow 5.2.0 and 12.2.0 in those four
-operations is NOT checked -- with respect to the reference's own pinned versions this part is
+PINNING.  Pinned to the reference's OWN transform code: oracle/gen_golden_augment.py imports
+code/utils/cluster/transforms.py through the Python-2 hook and executes its sobel_make_transforms /
+greyscale_make_transforms / custom_greyscale_to_tensor / custom_cutout on oracle/tv021_shim.py (torchvision
+0.2.1's transforms restated over PIL, every random draw logged); tests/golden/augment.npz holds the
+tensors its Compose objects returned for 8 flag sets x 6 images with the draw logs, and
+tests/test_augment_golden_cpu.py replays those draws through pil_pipeline / np_pipeline below
+(`params_from_log`) and demands bit-equal pixels -- including the --cutout, --fluid_warp and --demean
+branches -- and compares the draw distributions field by field.  What is left unpinned is the Pillow
+version underneath: the shim and this oracle call the Pillow installed here (12.2.0) for resize / rotate /
+ImageEnhance / the HSV conversion, the reference's environment pins Pillow 5.2.0
+(package_versions.txt:73,115; not available offline).  Drift between those two Pillow versions in the
+four operations is NOT checked: with respect to the reference's pinned Pillow this part stays
 "parity unpinned".
 
   pil_pipeline(...)   the reference's op sequence on PIL images            (the oracle)
