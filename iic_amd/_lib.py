@@ -105,6 +105,8 @@ _SIGNATURES = {
                             c_float, c_float, c_float, c_float, c_int, _P]),
   "iic_adam_step_dev": (c_int, [c_int, POINTER(_P), POINTER(_P), POINTER(_P), POINTER(_P), POINTER(_P), POINTER(c_long),
                                 c_float, c_float, c_float, c_float, _P, _P]),
+  "iic_adam_step_devlr": (c_int, [c_int, POINTER(_P), POINTER(_P), POINTER(_P), POINTER(_P), POINTER(_P), POINTER(c_long),
+                                  _P, c_float, c_float, c_float, c_float, _P, _P]),
   "iic_f32_conv": (c_int, [POINTER(ConvGeom), _P, _P, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
   "iic_f32_wgrad": (c_int, [POINTER(ConvGeom), _P, _P, _P, c_int, c_int, _P]),
   "iic_f32_bn_apply": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),

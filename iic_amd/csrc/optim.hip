@@ -44,7 +44,9 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTable t, float beta
 // counter after the last chunk of the group.
 __global__ __launch_bounds__(256) void adam_dev_kernel(const AdamTable t, float lr, float beta1,
                                                        float beta2, float eps,
-                                                       const int* __restrict__ steps_done) {
+                                                       const int* __restrict__ steps_done,
+                                                       const float* __restrict__ lr_dev) {
+  if (lr_dev) lr = lr_dev[0];       // learning rate kept on the device: update_lr() between graph replays
   const double step = (double)(steps_done[0] + 1);
   const double bc1 = 1.0 - pow((double)beta1, step);
   const double bc2 = 1.0 - pow((double)beta2, step);
@@ -88,10 +90,10 @@ static void adam_fill_table(AdamTable& t, int base, int n, float* const* params,
   *gx_out = gx;
 }
 
-extern "C" int iic_adam_step_dev(int n, float* const* params, const float* const* grads,
-                                 const float* const* grads2, float* const* exp_avg, float* const* exp_avg_sq, const long* numel,
-                                 float lr, float beta1, float beta2, float eps, int* steps_done,
-                                 void* stream) {
+extern "C" int iic_adam_step_devlr(int n, float* const* params, const float* const* grads,
+                                   const float* const* grads2, float* const* exp_avg, float* const* exp_avg_sq,
+                                   const long* numel, const float* lr_dev, float lr, float beta1, float beta2,
+                                   float eps, int* steps_done, void* stream) {
   if (n <= 0 || !params || !grads || !exp_avg || !exp_avg_sq || !numel || !steps_done)
     return IIC_ERR_ARG;
   for (int base = 0; base < n; base += ADAM_CHUNK) {
@@ -100,10 +102,18 @@ extern "C" int iic_adam_step_dev(int n, float* const* params, const float* const
     long gx;
     adam_fill_table(t, base, n, params, grads, grads2, exp_avg, exp_avg_sq, numel, &cnt, &gx);
     hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)gx, cnt), dim3(256), 0, (hipStream_t)stream,
-                       t, lr, beta1, beta2, eps, (const int*)steps_done);
+                       t, lr, beta1, beta2, eps, (const int*)steps_done, lr_dev);
   }
   hipLaunchKernelGGL(adam_count_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, steps_done);
   return iic_launch_status();
+}
+
+extern "C" int iic_adam_step_dev(int n, float* const* params, const float* const* grads,
+                                 const float* const* grads2, float* const* exp_avg, float* const* exp_avg_sq, const long* numel,
+                                 float lr, float beta1, float beta2, float eps, int* steps_done,
+                                 void* stream) {
+  return iic_adam_step_devlr(n, params, grads, grads2, exp_avg, exp_avg_sq, numel, nullptr, lr, beta1, beta2, eps,
+                             steps_done, stream);
 }
 
 extern "C" int iic_adam_step(int n, float* const* params, const float* const* grads,

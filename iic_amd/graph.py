@@ -45,6 +45,8 @@ class CapturedStep(object):
     self.replays = 0
 
   def __call__(self):
+    from .optim import sync_captured_lr
+    sync_captured_lr()           # update_lr() between replays: the optimiser reads its rate from device memory
     self.graph.replay()
     self.replays += 1
     # parameters were updated by raw-pointer kernels inside the graph: eager code that runs
@@ -329,8 +331,10 @@ class CapturedPairStep(object):
       self.g_opt.replay()
 
   def __call__(self):
+    from .optim import sync_captured_lr
     s1, s2 = self.s1, self.s2
     cur = torch.cuda.current_stream()
+    sync_captured_lr()           # (on `cur`, which stream 1 waits for next)
     s1.wait_stream(cur)
     s2.wait_stream(s1)
     with torch.cuda.stream(s2):

@@ -12,12 +12,25 @@ so that the launch arguments never change and ``step()`` can be captured in a HI
 (iic_amd.graph.CapturedStep); ``state[p]['step']`` then reads that counter.
 """
 import ctypes
+import weakref
 
 import torch
 
 from . import ops
 from ._lib import check, lib, stream_ptr
 from .archs.cluster import bump_weights_epoch
+
+
+_CAPTURABLE = weakref.WeakSet()      # live capturable optimisers (their learning rates live on the device)
+
+
+def sync_captured_lr():
+  """Push param_groups[i]["lr"] of every capturable optimiser to its device copy where it changed since the
+  last push: called by iic_amd.graph.Captured*Step before every replay, so that update_lr()
+  (/root/reference/code/utils/cluster/general.py:12-23: an in-place edit of param_groups) takes effect on the
+  next replayed step although no host code of step() runs at replay."""
+  for opt in list(_CAPTURABLE):
+    opt.sync_lr()
 
 
 def _as_int(step):
@@ -35,6 +48,24 @@ class Adam(torch.optim.Optimizer):
     super(Adam, self).__init__(params, dict(lr=lr, betas=betas, eps=eps))
     self.capturable = bool(capturable)
     self._members = {}     # id(counter tensor) -> (counter, set of param ids sharing it)
+    if self.capturable:
+      _CAPTURABLE.add(self)
+
+  def _lr_dev(self, group, device):
+    """Device copy of the group's learning rate (capturable mode), created at the first step -- i.e. in the
+    eager warm-up steps, before any capture."""
+    t = group.get("_lr_dev")
+    if t is None or t.device != device:
+      t = group["_lr_dev"] = torch.full((1,), float(group["lr"]), dtype=torch.float32, device=device)
+      group["_lr_pushed"] = float(group["lr"])
+    return t
+
+  def sync_lr(self):
+    for group in self.param_groups:
+      t = group.get("_lr_dev")
+      if t is not None and group.get("_lr_pushed") != float(group["lr"]):
+        t.fill_(float(group["lr"]))
+        group["_lr_pushed"] = float(group["lr"])
 
   # ---- checkpoint compatibility with torch.optim.Adam (step stored as a tensor there) ----
   def load_state_dict(self, state_dict):
@@ -52,6 +83,7 @@ class Adam(torch.optim.Optimizer):
     # (the per-parameter dicts are the live ones: copy before dropping the private entry)
     sd["state"] = {k: {n: v for n, v in st.items() if n != "_counter"}
                    for k, st in sd["state"].items()}
+    sd["param_groups"] = [{n: v for n, v in g.items() if not n.startswith("_lr_")} for g in sd["param_groups"]]
     return sd
 
   def _sync_steps_to_host(self):
@@ -147,9 +179,12 @@ class Adam(torch.optim.Optimizer):
       hyper = (float(group["lr"]), float(group["betas"][0]), float(group["betas"][1]),
                float(group["eps"]))
       if self.capturable:
+        lr_dev = self._lr_dev(group, ps[0].device)
+        self.sync_lr()
         for counter, grp in self._counter_groups(ps):
           keep, tab = self._tables(grp, self.state)
-          check(lib().iic_adam_step_dev(*tab, *hyper, counter.data_ptr(), stream_ptr()), "iic_adam_step_dev")
+          check(lib().iic_adam_step_devlr(*tab, lr_dev.data_ptr(), *hyper, counter.data_ptr(), stream_ptr()),
+                "iic_adam_step_devlr")
           del keep
         continue
       # torch.optim.Adam keeps a step count PER PARAMETER: a two-head net only produces

@@ -348,6 +348,13 @@ int iic_adam_step_dev(int n, float* const* params, const float* const* grads,
                       const float* const* grads2, float* const* exp_avg, float* const* exp_avg_sq,
                       const long* numel, float lr, float beta1, float beta2, float eps,
                       int* steps_done, void* stream);
+/* ... and with the learning rate read from DEVICE memory too (lr_dev != NULL; `lr` is then ignored): the
+ * reference scales param_groups[i]["lr"] in place between epochs (update_lr, general.py:12-23), and a
+ * captured step must see the new rate without being re-captured.                                        */
+int iic_adam_step_devlr(int n, float* const* params, const float* const* grads,
+                        const float* const* grads2, float* const* exp_avg, float* const* exp_avg_sq,
+                        const long* numel, const float* lr_dev, float lr, float beta1, float beta2,
+                        float eps, int* steps_done, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * Exact-fp32 path (SURVEY.md 8c parity tier T2; csrc/f32_path.hip).  The same operators as above

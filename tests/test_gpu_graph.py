@@ -185,6 +185,41 @@ def test_two_stream_graph_modes_with_k_split_head_gemm_are_bit_identical_to_eage
     assert torch.equal(a, b)
 
 
+def test_update_lr_between_replays_changes_the_captured_optimiser_step():
+  """update_lr (/root/reference/code/utils/cluster/general.py:12-23) scales param_groups[i]["lr"] in place.
+  The captured optimiser step reads its rate from device memory, pushed before every replay: a replayed
+  run with a rate change in the middle must equal the eager run with the same change, bit for bit -- and
+  differ from a replayed run without it.  The checkpoint stays torch.optim.Adam-compatible."""
+  from iic_amd.graph import CapturedPairStep
+  from iic_amd.losses import IID_loss_heads
+  from iic_amd.optim import Adam
+  from iic_amd.transforms import sobel_process
+  imgs, imgs_tf = _batch()
+  out = {}
+  for name in ("eager", "pair", "pair-constant"):
+    net = _net()
+    opt = Adam(net.parameters(), lr=2e-4, capturable=name != "eager")
+    if name == "eager":
+      run = _make_step(net, opt, imgs, imgs_tf, False)
+      run(); run()
+    else:
+      run = CapturedPairStep(lambda: net.forward_packed(sobel_process(imgs, False)),
+                             lambda: net.forward_packed(sobel_process(imgs_tf, False)),
+                             lambda a, b: IID_loss_heads(a, b, lamb=1.0)[0].mean(), opt.step,
+                             lambda: net.zero_grad(set_to_none=True), warmup=2)
+    for i in range(6):
+      if i == 3 and name != "pair-constant":
+        for g in opt.param_groups:          # what update_lr does (general.py:20-23)
+          g["lr"] *= 0.1
+      run()
+    torch.cuda.synchronize()
+    out[name] = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).clone()
+    sd = opt.state_dict()
+    assert all(set(g) == {"lr", "betas", "eps", "params"} for g in sd["param_groups"]), sd["param_groups"][0].keys()
+  assert torch.equal(out["pair"], out["eager"])
+  assert not torch.equal(out["pair"], out["pair-constant"])
+
+
 def test_replay_back_to_back_equals_replay_with_syncs():
   from iic_amd.graph import CapturedStep
   from iic_amd.optim import Adam
