@@ -64,7 +64,10 @@ __device__ __forceinline__ void bd_bwait(u32x4& d) {
 // tile (half the patch and accumulators: 3 workgroups per CU -- more tiles in flight to hide the
 // per-tile prologue / epilogue where the K loop is short, i.e. few input channels).
 // RED: fused BatchNorm-backward reduction over the stored tile (conv_tile.h), 0 = off.
-template <bool GATHER, int ABL, bool DMA, int MS, int RED>
+// WN: 64-cout column groups of the workgroup tile.  2: 128 couts, waves 2 (rows) x 2 (cols), MS*64 rows;
+// 1: 64 couts (layers with Cout = 64: the backward-data of a 64 -> 128 convolution, SegmentationNet10a c2), the
+// four waves stacked along the rows, MS*128 rows -- the wave tile stays MS x 2 MFMA blocks either way.
+template <bool GATHER, int ABL, bool DMA, int MS, int RED, int WN = 2>
 __device__ __forceinline__ void bd_tile(
     const iic_conv_geom& g, const bf16_t* __restrict__ in, const unsigned char* __restrict__ wfrag,
     bf16_t* __restrict__ out, float* __restrict__ stats, const bf16_t* __restrict__ res_grad,
@@ -72,7 +75,8 @@ __device__ __forceinline__ void bd_tile(
     int dense_key, const bf16_t* __restrict__ red_y, const float* __restrict__ red_coef,
     const bf16_t* __restrict__ red_y2, float* __restrict__ red_stats, float* __restrict__ red_stats2,
     unsigned long long* __restrict__ prof, int stagger, int blk_in_class, int nwg_class, int m_base) {
-  constexpr int CLD = BD_BN + 8;
+  constexpr int BNT = WN * 64, NWM = 4 / WN;   // tile couts, wave row groups
+  constexpr int CLD = BNT + 8;
   constexpr bool PROF = (ABL & 128) != 0;
   constexpr bool NEWORD = (ABL & 256) == 0;     // ABL bit 256: the round-2 K-loop order (A/B runs)
   // PROF (ABL bit 128, results CORRECT): wave 0 stamps s_memtime at the phase boundaries of its tile
@@ -93,24 +97,24 @@ __device__ __forceinline__ void bd_tile(
       while (__builtin_readcyclecounter() < t_go) __builtin_amdgcn_s_sleep(16);
     }
   }
-  constexpr int BM = MS * 64, WR = MS * 32;     // workgroup tile rows, rows per wave
+  constexpr int BM = MS * 32 * NWM, WR = MS * 32;     // workgroup tile rows, rows per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned char* sA = smem_raw;                                   // [NP256][ROWB]
   int* s_pin = reinterpret_cast<int*>(smem_raw + lds_a_bytes);     // [256]
   int* s_pout = s_pin + BM;                                     // [256]
-  float* s_red = reinterpret_cast<float*>(s_pout + BM);         // [2 wm][2][128]
-  unsigned char* s_key = reinterpret_cast<unsigned char*>(s_red + 4 * BD_BN);   // DMA: [npix] swizzle keys
+  float* s_red = reinterpret_cast<float*>(s_pout + BM);         // [NWM wm][2][BNT]  (512 floats)
+  unsigned char* s_key = reinterpret_cast<unsigned char*>(s_red + NWM * 2 * BNT);   // DMA: [npix] swizzle keys (after 512 floats)
   bf16_t* sC = reinterpret_cast<bf16_t*>(smem_raw);                // epilogue reuse of sA
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
   const int l31 = lane & 31, g5 = lane >> 5;
 
-  const int nt = g.Cout / BD_BN;
+  const int nt = g.Cout / BNT;
   const int tix = xcd_tile_index(blk_in_class, nwg_class);
   const int mtile = tix / nt, ntile = tix - mtile * nt;
-  const int n0 = ntile * BD_BN;
+  const int n0 = ntile * BNT;
   const int m0 = m_base + mtile * BM;
   const int in_pixels = g.N * g.in_Hp * g.in_Wp;
 
@@ -125,7 +129,7 @@ __device__ __forceinline__ void bd_tile(
   }
   __syncthreads();
   const int p_lo = s_pin[0];
-  const int npix = GATHER ? BM : (MS >= 3 ? g.NP256 : g.NP);      // (192-row tiles: bound checked by the host)
+  const int npix = GATHER ? BM : (BM >= 192 ? g.NP256 : g.NP);    // (192-row tiles: bound checked by the host)
   // swizzle key of a pixel (see the header): D = p - J * (p / in_Wp); J must be even so that D keeps
   // the row parity (the 128-B half of the 256-B bank window is the physical row parity)
   const int jskip = (dense_key && !GATHER && g.sx == 1 && ((g.in_Wp - g.MX) & 1) == 0) ? g.in_Wp - g.MX : 0;
@@ -379,16 +383,22 @@ __device__ __forceinline__ void bd_tile(
       ss += __shfl_xor(ss, 32, 64);
       if (lane < 32) {
         const int col = wn * 64 + ns * 32 + lane;
-        s_red[(wm * 2 + 0) * BD_BN + col] = s;
-        s_red[(wm * 2 + 1) * BD_BN + col] = ss;
+        s_red[(wm * 2 + 0) * BNT + col] = s;
+        s_red[(wm * 2 + 1) * BNT + col] = ss;
       }
     }
   }
   __syncthreads();   // all waves finished reading sA; s_red complete
-  if (stats && tid < BD_BN && !(ABL & 64)) {
+  if (stats && tid < BNT && !(ABL & 64)) {
     const int stripe = blockIdx.x % IIC_STAT_STRIPES;
-    iic_stat_add(stats, stripe, g.Cout, n0 + tid, 0, s_red[0 * BD_BN + tid] + s_red[2 * BD_BN + tid]);
-    iic_stat_add(stats, stripe, g.Cout, n0 + tid, 1, s_red[1 * BD_BN + tid] + s_red[3 * BD_BN + tid]);
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < NWM; ++q) {
+      a0 += s_red[(q * 2 + 0) * BNT + tid];
+      a1 += s_red[(q * 2 + 1) * BNT + tid];
+    }
+    iic_stat_add(stats, stripe, g.Cout, n0 + tid, 0, a0);
+    iic_stat_add(stats, stripe, g.Cout, n0 + tid, 1, a1);
   }
 #pragma unroll
   for (int ms = 0; ms < MS; ++ms)
@@ -405,10 +415,10 @@ __device__ __forceinline__ void bd_tile(
   TileRed tr;
   if (RED) tile_red_zero(tr);
   if (!(ABL & 32))
-    igemm_store_tile<BD_BN, BM, BD_THREADS, 8, RED, (MS == 4 ? BD_STORE_UB : 4)>(sC, s_pout, out, res_grad, res_act, accumulate,
+    igemm_store_tile<BNT, BM, BD_THREADS, 8, RED, (BM == 256 ? BD_STORE_UB : 4)>(sC, s_pout, out, res_grad, res_act, accumulate,
                                                                  g.Cout, n0, tid, red_y, red_coef, red_y2, &tr);
   if (RED)
-    igemm_red_finish<BD_BN, BD_THREADS, RED>(tr, reinterpret_cast<float*>(smem_raw), red_stats, red_stats2,
+    igemm_red_finish<BNT, BD_THREADS, RED>(tr, reinterpret_cast<float*>(smem_raw), red_stats, red_stats2,
                                              g.Cout, n0, tid);
   if (PROF && prof && tid == 0) {
     unsigned long long* q = prof + (long)blockIdx.x * BD_PROF_SLOTS;
@@ -428,15 +438,19 @@ __device__ __forceinline__ void bd_tile(
 // MS2 * 64 rows high instead of 256, sized so that they still fit ONE round (host: the split below): the
 // first n_big workgroups take 256-row tiles of rows [0, m_split), the others MS2-tiles of the rest.
 // Results per output row are unchanged (same K order); only the grouping of the statistics partials differs.
-template <bool GATHER, int ABL, bool DMA, int MS, int RED, int MS2>
-__global__ __launch_bounds__(BD_THREADS, ((MS == 4 || MS2 != 0) ? 2 : 3)) void conv_igemm_bd_kernel(
+template <bool GATHER, int ABL, bool DMA, int MS, int RED, int MS2, int WN = 2>
+__global__ __launch_bounds__(BD_THREADS, ((MS == 4 || MS2 != 0 || WN == 1) ? 2 : 3)) void conv_igemm_bd_kernel(
     const iic_conv_geom g, const bf16_t* __restrict__ in, const unsigned char* __restrict__ wfrag,
     bf16_t* __restrict__ out, float* __restrict__ stats, const bf16_t* __restrict__ res_grad,
     const bf16_t* __restrict__ res_act, int accumulate, int num_mtiles, int lds_a_bytes,
     int dense_key, const bf16_t* __restrict__ red_y, const float* __restrict__ red_coef,
     const bf16_t* __restrict__ red_y2, float* __restrict__ red_stats, float* __restrict__ red_stats2,
     unsigned long long* __restrict__ prof, int stagger, int n_big, int m_split) {
-  if (MS2 == 0 || (int)blockIdx.x < n_big) {
+  if (WN == 1) {
+    bd_tile<GATHER, ABL, DMA, MS, RED, 1>(g, in, wfrag, out, stats, res_grad, res_act, accumulate, lds_a_bytes,
+                                          dense_key, red_y, red_coef, red_y2, red_stats, red_stats2, prof, stagger,
+                                          (int)blockIdx.x, num_mtiles * (g.Cout / 64), 0);
+  } else if (MS2 == 0 || (int)blockIdx.x < n_big) {
     bd_tile<GATHER, ABL, DMA, MS, RED>(g, in, wfrag, out, stats, res_grad, res_act, accumulate, lds_a_bytes,
                                        dense_key, red_y, red_coef, red_y2, red_stats, red_stats2, prof, stagger,
                                        (int)blockIdx.x, MS2 == 0 ? num_mtiles * (g.Cout / BD_BN) : n_big, 0);
@@ -500,11 +514,12 @@ static int g_bd_dma = 1;        // 1: LDS-DMA patch loads (128-B swizzled rows),
 extern "C" void iic_debug_bd_dma(int v) { g_bd_dma = v; }
 
 // ms: 4 = 256-row tiles, 2 = 128-row tiles (the kernel's MS)
-static long bd_lds_a(const iic_conv_geom* g, int ms) {
-  const long bm = ms * 64;
-  const long npix = g->ntaps == 1 ? bm : (ms == 4 ? g->NP256 : g->NP);
+// (wn: the kernel's WN -- 1 = 64-cout tiles of ms*128 rows)
+static long bd_lds_a(const iic_conv_geom* g, int ms, int wn = 2) {
+  const long bm = ms * 32 * (4 / wn);
+  const long npix = g->ntaps == 1 ? bm : (bm >= 192 ? g->NP256 : g->NP);
   long a = g_bd_dma ? ((npix * 128 + 1023) & ~1023L) : npix * ROWB;
-  long c = bm * (BD_BN + 8) * 2;
+  long c = bm * (wn * 64 + 8) * 2;
   long m = a > c ? a : c;
   return (m + 15) & ~15L;
 }
@@ -523,12 +538,19 @@ static int g_bd_mixed = 0;      // 1: last partial round in smaller tiles. Per l
 extern "C" void iic_debug_bd_mixed(int v) { g_bd_mixed = v; }
 static int g_bd_dense_key = 1;  // 0: swizzle key from the raw pixel index (A/B: conflicts at row ends)
 extern "C" void iic_debug_bd_dense_key(int v) { g_bd_dense_key = v; }
-static long bd_key_bytes(const iic_conv_geom* g, int ms) {    // swizzle-key table of the DMA patch (1 B / row)
+static long bd_key_bytes(const iic_conv_geom* g, int ms, int wn = 2) {    // swizzle-key table of the DMA patch (1 B / row)
   const int jskip = (g_bd_dense_key && g->ntaps > 1 && g->sx == 1 && ((g->in_Wp - g->MX) & 1) == 0) ? g->in_Wp - g->MX : 0;
-  return (g_bd_dma && jskip != 0) ? (((long)(ms == 4 ? g->NP256 : g->NP) + 15) & ~15L) : 0;
+  return (g_bd_dma && jskip != 0) ? (((long)(ms * 32 * (4 / wn) >= 192 ? g->NP256 : g->NP) + 15) & ~15L) : 0;
 }
-static long bd_lds_total(const iic_conv_geom* g, int ms) {
-  return bd_lds_a(g, ms) + 2L * ms * 64 * 4 + 4L * BD_BN * 4 + bd_key_bytes(g, ms);
+static long bd_lds_total(const iic_conv_geom* g, int ms, int wn = 2) {
+  return bd_lds_a(g, ms, wn) + 2L * ms * 32 * (4 / wn) * 4 + 4L * BD_BN * 4 + bd_key_bytes(g, ms, wn);
+}
+// 64-cout tiles (kernel WN = 1, 256 rows): layers whose Cout is an odd multiple of 64
+static int g_bd_w1 = 1;
+extern "C" void iic_debug_bd_w1(int v) { g_bd_w1 = v; }
+static bool bd_w1_ok(const iic_conv_geom* g) {
+  return g_bd_w1 && g_bd_dma && g->Cout % 64 == 0 && g->Cout % BD_BN != 0 && g->ntaps > 1 && g->NP256 > 0 &&
+         bd_lds_total(g, 2, 1) <= 160 * 1024;
 }
 // Tile height per geometry.  g_bd_ms: 0 = heuristic, 2 / 4 = forced (A/B runs, tests).
 static int g_bd_ms = 0;
@@ -545,7 +567,8 @@ static int bd_pick_ms(const iic_conv_geom* g) {
 int iic_conv_igemm_frag_supported(const iic_conv_geom* g) {
   if (!g) return 0;
   if (g_p64_enabled && iic_p64_supported(g)) return 1;
-  if (g->Cin % 64 != 0 || g->Cout % BD_BN != 0 || g->ntaps < 1 || g->ntaps > IIC_MAX_TAPS) return 0;
+  if (g->Cin % 64 != 0 || g->ntaps < 1 || g->ntaps > IIC_MAX_TAPS) return 0;
+  if (g->Cout % BD_BN != 0) return bd_w1_ok(g) ? 1 : 0;
   return bd_pick_ms(g) != 0;
 }
 
@@ -596,6 +619,31 @@ int iic_conv_igemm_frag_red(const iic_conv_geom* g, const void* in, const void* 
   const long M = igemm_rows_host(g);
   if (M <= 0) return IIC_ERR_ARG;
   if (M >= (1L << 31) || (long)g->N * g->in_Hp * g->in_Wp >= (1L << 31)) return IIC_ERR_UNSUPPORTED;
+  if (g->Cout % BD_BN != 0) {       // 64-cout tiles
+    const int mt1 = (int)((M + 255) / 256);
+    const int grid1 = mt1 * (g->Cout / 64);
+    const int la1 = (int)bd_lds_a(g, 2, 1);
+    const long lds1 = bd_lds_total(g, 2, 1);
+    hipStream_t s1 = (hipStream_t)stream;
+#define BD_LAUNCH_W1(RD_)                                                                              \
+  do {                                                                                                 \
+    static bool attr = false;                                                                          \
+    if (!attr) {                                                                                       \
+      (void)hipFuncSetAttribute(                                                                       \
+          reinterpret_cast<const void*>(&conv_igemm_bd_kernel<false, 0, true, 2, RD_, 0, 1>),          \
+          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                     \
+      attr = true;                                                                                     \
+    }                                                                                                  \
+    hipLaunchKernelGGL((conv_igemm_bd_kernel<false, 0, true, 2, RD_, 0, 1>), dim3(grid1),              \
+                       dim3(BD_THREADS), lds1, s1, *g, (const bf16_t*)in, (const unsigned char*)wfrag, \
+                       (bf16_t*)out, stats, (const bf16_t*)res_grad, (const bf16_t*)res_act,           \
+                       accumulate, mt1, la1, g_bd_dense_key, (const bf16_t*)red_y, red_coef,           \
+                       (const bf16_t*)red_y2, red_stats, red_stats2, (unsigned long long*)nullptr, 0,  \
+                       0, 0);                                                                          \
+  } while (0)
+    if (red == 0) BD_LAUNCH_W1(0); else if (red == 1) BD_LAUNCH_W1(1); else BD_LAUNCH_W1(2);
+    return iic_launch_status();
+  }
   const int ms = bd_pick_ms(g);
   const int bm = ms * 64;
   const int mt = (int)((M + bm - 1) / bm);

@@ -217,6 +217,8 @@ CONV_CASES = [  # cin, cout, K, stride, pad, N, H
   (64, 64, 3, 1, 1, 2, 49),     # wide rows (layer1 geometry)
   (512, 512, 3, 1, 1, 6, 7),    # 8 chunks, 256-row tail tile (layer4 geometry)
   (128, 128, 3, 1, 1, 20, 25),  # many tiles (layer2 geometry)
+  (64, 128, 3, 1, 1, 3, 30),    # SegmentationNet10a c2-like: the backward-data conv has 64 couts (64-cout tiles)
+  (128, 64, 3, 1, 1, 2, 21),    # ... and a forward with 64 couts, two channel chunks, tail tile
 ]
 
 
