@@ -59,6 +59,8 @@ _SIGNATURES = {
   "iic_conv_igemm_red_supported": (c_int, [POINTER(ConvGeom)]),
   "iic_conv_igemm_frag_red": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P]),
   "iic_weight_prep_frag": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+  "iic_weight_prep_multi_blocks": (c_long, [c_int, c_int, c_int]),
+  "iic_weight_prep_multi": (c_int, [_P, c_int, c_long, _P]),
   "iic_bn_finalize": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_long, c_long, c_float, c_float, c_int, _P]),
   "iic_stat_bytes": (c_long, [c_int]),
   "iic_bn_running_update": (c_int, [c_int, POINTER(_P), POINTER(_P), POINTER(_P), POINTER(_P), POINTER(c_int),

@@ -29,6 +29,7 @@ from .. import ops
 __all__ = ["ClusterNet5g", "ClusterNet5gTwoHead"]
 
 import os
+import weakref
 
 # Weight-gradient kernels run on a second HIP stream, concurrently with the dependent
 # backward-data / BatchNorm chain of the same block (they only share inputs): two kernels in
@@ -114,6 +115,30 @@ def bump_weights_epoch():
   _WEIGHTS_EPOCH[0] += 1
 
 
+_HOLDERS = {}     # branch -> WeakSet of _ConvHolder with an operand set in that branch
+
+
+def _refresh_branch(b):
+  stale = []
+  for h in list(_HOLDERS.get(b, ())):
+    ent = h._wbranch.get(b)
+    w = h.conv.weight
+    if ent is None or not w.is_cuda:
+      continue
+    key = (w.data_ptr(), w._version, _WEIGHTS_EPOCH[0])
+    if ent[0] != key and ent[0][0] == key[0]:
+      stale.append((h, ent, key))
+  if not stale:
+    return
+  by_dev = {}
+  for h, ent, key in stale:
+    by_dev.setdefault(ent[1].w.device, []).append((ent, key))
+  for dev, items in by_dev.items():
+    if ops.refresh_prepped([ent[1] for ent, _ in items], dev):
+      for ent, key in items:
+        ent[0] = key
+
+
 class _ConvHolder(object):
   """Per-conv caches: bf16 operand copies of the fp32 parameter, geometries, BN stat buffers."""
 
@@ -122,9 +147,7 @@ class _ConvHolder(object):
     self.pad_in, self.pad_out = pad_in, pad_out
     self.spec = G.ConvSpec(conv.in_channels, conv.out_channels, conv.kernel_size[0],
                            conv.stride[0], conv.padding[0], conv.dilation[0])
-    self._wkey = None
-    self._w = None
-    self._wbranch = {}
+    self._wbranch = {}      # branch -> [key, PreppedWeights]
     self._geoms = {}
     self._stats = {}
 
@@ -134,15 +157,20 @@ class _ConvHolder(object):
     w = self.conv.weight
     b = ops.BRANCH[0]
     key = (w.data_ptr(), w._version, _WEIGHTS_EPOCH[0])
-    if b == 0:
-      if key != self._wkey:
-        self._w = ops.PreppedWeights(w.detach())
-        self._wkey = key
-      return self._w
-    ent = self._wbranch.get(b)
-    if ent is None or ent[0] != key:
-      ent = (key, ops.PreppedWeights(w.detach()))
-      self._wbranch[b] = ent
+    ent = self._wbranch.get(b)                  # [key, PreppedWeights]
+    if ent is not None and ent[0] == key:
+      return ent[1]
+    if ent is None or ent[0][0] != key[0] or ent[1].w.device != w.device or not ops.MULTI_PREP[0]:
+      # first use (or the parameter moved): a fresh operand set, layouts made on demand
+      ent = self._wbranch[b] = [key, ops.PreppedWeights(w.detach())]
+      _HOLDERS.setdefault(b, weakref.WeakSet()).add(self)
+      return ent[1]
+    # the optimiser has stepped: re-write the layouts of EVERY convolution of this branch that is stale, in one
+    # launch, instead of one or two small launches in front of each convolution
+    _refresh_branch(b)
+    ent = self._wbranch[b]
+    if ent[0] != key:                           # (refresh not possible right now: per-layout launches)
+      ent = self._wbranch[b] = [key, ops.PreppedWeights(w.detach())]
     return ent[1]
 
   def geoms(self, N, H, W):

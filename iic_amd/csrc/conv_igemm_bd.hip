@@ -739,6 +739,60 @@ int iic_conv_igemm_frag_red(const iic_conv_geom* g, const void* in, const void* 
   return iic_launch_status();
 }
 
+// All weight operands of a network in ONE launch (jobs in device memory, see iic_weight_prep_job): a train step
+// re-lays ~70 convolution weights into 1-2 operand layouts each after the optimiser step -- 136 launches of
+// 5-7 us per ClusterNet5g step, 290 per ClusterNet6c two-head step, every one in front of its convolution on
+// the forward's critical path.  A block finds its job by binary search over the jobs' first-block indices.
+__global__ __launch_bounds__(256) void weight_prep_multi_kernel(const iic_weight_prep_job* __restrict__ jobs,
+                                                                int njobs) {
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((long long)blockIdx.x >= jobs[mid].first_block) lo = mid; else hi = mid - 1;
+  }
+  const iic_weight_prep_job j = jobs[lo];
+  const float* __restrict__ w = j.w;
+  bf16_t* __restrict__ o = reinterpret_cast<bf16_t*>(j.out);
+  const int Co = j.Cout, Ci = j.Cin, T = j.T, mode = j.mode;
+  const long total = (long)T * Co * Ci;
+  const long nblk = (total + 2047) >> 11;            // 8 elements per thread
+  const long b = (long)blockIdx.x - j.first_block;
+  if (b >= nblk) return;
+  for (long i = b * 256 + threadIdx.x; i < total; i += nblk * 256) {
+    if (mode <= 1) {         // MFMA B-fragment order (weight_prep_frag_kernel)
+      const int Nn = mode ? Ci : Co, Kk = mode ? Co : Ci;
+      const int n32 = Nn >> 5, nchunks = Kk >> 6;
+      const int e = (int)(i & 7), lane = (int)((i >> 3) & 63), ks = (int)((i >> 9) & 3);
+      long r = i >> 11;
+      const int jj = (int)(r % n32);
+      r /= n32;
+      const int kc = (int)(r % nchunks), t = (int)(r / nchunks);
+      const int n = jj * 32 + (lane & 31), k = kc * 64 + ks * 16 + (lane >> 5) * 8 + e;
+      const int co = mode ? k : n, ci = mode ? n : k;
+      o[i] = f32_to_bf16(w[((long)co * Ci + ci) * T + t]);
+    } else if (mode == 2) {  // [T][Co][Ci]
+      const int ci = (int)(i % Ci);
+      const long r = i / Ci;
+      const int co = (int)(r % Co), t = (int)(r / Co);
+      o[i] = f32_to_bf16(w[((long)co * Ci + ci) * T + t]);
+    } else {                 // [T][Ci][Co]
+      const int co = (int)(i % Co);
+      const long r = i / Co;
+      const int ci = (int)(r % Ci), t = (int)(r / Ci);
+      o[i] = f32_to_bf16(w[((long)co * Ci + ci) * T + t]);
+    }
+  }
+}
+
+long iic_weight_prep_multi_blocks(int Cout, int Cin, int T) { return ((long)T * Cout * Cin + 2047) >> 11; }
+
+int iic_weight_prep_multi(const iic_weight_prep_job* jobs_dev, int njobs, long total_blocks, void* stream) {
+  if (!jobs_dev || njobs <= 0 || total_blocks <= 0 || total_blocks >= (1L << 31)) return IIC_ERR_ARG;
+  hipLaunchKernelGGL(weight_prep_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                     jobs_dev, njobs);
+  return iic_launch_status();
+}
+
 int iic_weight_prep_frag(const float* w_oihw, void* w_frag, int Cout, int Cin, int T, int bwd,
                          void* stream) {
   if (!w_oihw || !w_frag || Cout <= 0 || Cin <= 0 || T <= 0) return IIC_ERR_ARG;

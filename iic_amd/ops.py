@@ -435,7 +435,11 @@ USE_FRAG = [os.environ.get("IIC_CONV_FRAG", "1") != "0"]
 
 class PreppedWeights(object):
   """bf16 operands of one conv parameter, laid out lazily per consumer kernel.  `pw[0]` is the
-  forward operand, `pw[1]` the backward-data operand (handles accepted by conv_igemm)."""
+  forward operand, `pw[1]` the backward-data operand (handles accepted by conv_igemm).
+
+  The layouts a consumer asked for once are kept (same buffers) and RE-WRITTEN IN PLACE when the parameter
+  has changed: `jobs()` lists them for the one-launch refresh of all convolutions of a network
+  (refresh_prepped; archs.cluster._ConvHolder.weights)."""
 
   def __init__(self, w):
     self.w = w
@@ -447,6 +451,19 @@ class PreppedWeights(object):
       self._rows = weight_prep(self.w, want_bwd=True)
     return self._rows[1 if bwd else 0]
 
+  def jobs(self):
+    """(src ptr, dst ptr, Cout, Cin, T, mode) of every materialised layout (modes: include/iic_hip.h)."""
+    co, ci, kh, kw = self.w.shape
+    out = []
+    for k in (0, 1):
+      if self._frag[k] is not None:
+        out.append((self.w.data_ptr(), self._frag[k].data_ptr(), co, ci, kh * kw, k))
+    if self._rows is not None:
+      for k in (0, 1):
+        if self._rows[k] is not None:
+          out.append((self.w.data_ptr(), self._rows[k].data_ptr(), co, ci, kh * kw, 2 + k))
+    return out
+
   def frag(self, bwd):
     k = 1 if bwd else 0
     if self._frag[k] is None:
@@ -455,6 +472,43 @@ class PreppedWeights(object):
 
   def __getitem__(self, i):
     return WOperand(self, bool(i))
+
+
+class _PrepJob(ctypes.Structure):
+  _fields_ = [("w", ctypes.c_void_p), ("out", ctypes.c_void_p), ("first_block", ctypes.c_longlong),
+              ("Cout", ctypes.c_int32), ("Cin", ctypes.c_int32), ("T", ctypes.c_int32), ("mode", ctypes.c_int32)]
+
+
+_PREP_TABLES = {}      # (device index, tuple of jobs) -> (device table, njobs, total blocks)
+MULTI_PREP = [os.environ.get("IIC_MULTI_PREP", "1") != "0"]
+
+
+def refresh_prepped(pws, device):
+  """Re-write every materialised layout of the given PreppedWeights from their (updated) fp32 parameters in
+  ONE launch (iic_weight_prep_multi).  The job table lives in device memory and is cached by content: a
+  network's jobs are the same every step, so the upload happens once, in the eager warm-up steps.  Returns
+  False when nothing was launched because a NEW table would have to be uploaded while a stream is being
+  captured (the caller then falls back to per-layout launches)."""
+  jobs = tuple(j for pw in pws for j in pw.jobs())
+  if not jobs:
+    return True
+  key = (device.index, jobs)
+  ent = _PREP_TABLES.get(key)
+  if ent is None:
+    if torch.cuda.is_current_stream_capturing():
+      return False
+    arr = (_PrepJob * len(jobs))()
+    blk = 0
+    for a, (src, dst, co, ci, t, mode) in zip(arr, jobs):
+      a.w, a.out, a.first_block, a.Cout, a.Cin, a.T, a.mode = src, dst, blk, co, ci, t, mode
+      blk += lib().iic_weight_prep_multi_blocks(co, ci, t)
+    host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+    ent = _PREP_TABLES[key] = (host.to(device), len(jobs), blk)
+    if len(_PREP_TABLES) > 64:          # (tables of networks that no longer exist)
+      for k in list(_PREP_TABLES)[:-32]:
+        del _PREP_TABLES[k]
+  check(lib().iic_weight_prep_multi(ptr(ent[0]), ent[1], ent[2], stream_ptr()), "iic_weight_prep_multi")
+  return True
 
 
 class WOperand(object):

@@ -185,6 +185,19 @@ int iic_conv_igemm_frag_red(const iic_conv_geom* g, const void* in, const void* 
                             float* red_stats, float* red_stats2, void* stream);
 int iic_weight_prep_frag(const float* w_oihw, void* w_frag, int Cout, int Cin, int T, int bwd,
                          void* stream);
+/* Every weight operand of a network in ONE launch (what the per-parameter calls above do once per conv and
+ * layout after each optimiser step): `jobs_dev` = njobs records in DEVICE memory, sorted by first_block
+ * (job i owns blocks [first_block, first_block + iic_weight_prep_multi_blocks(Cout, Cin, T))),
+ * total_blocks = the sum.  mode: 0 / 1 = B-fragment order forward / backward-data operand
+ * (iic_weight_prep_frag), 2 = [T][Co][Ci], 3 = [T][Ci][Co] (iic_weight_prep's two outputs).               */
+typedef struct iic_weight_prep_job {
+  const float* w;        /* fp32 OIHW parameter */
+  void* out;             /* bf16 operand */
+  long long first_block;
+  int32_t Cout, Cin, T, mode;
+} iic_weight_prep_job;
+long iic_weight_prep_multi_blocks(int Cout, int Cin, int T);
+int iic_weight_prep_multi(const iic_weight_prep_job* jobs_dev, int njobs, long total_blocks, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * BatchNorm2d (train / eval), ReLU, residual add -- replaces nn.BatchNorm2d / nn.ReLU /
