@@ -83,17 +83,34 @@ __device__ __forceinline__ bf16x8 wd_pack(const s16x4 h0, const s16x4 h1) {
   return u.v;
 }
 
+// Row walkers.  Dense numbering (g.MP == 0 or == MY*MX): (n, y, x) advanced by one K-tile at a time, no
+// divisions.  Padded numbering (g.MP rows per image, a multiple of 256 > MY*MX: large images, so that no tile
+// straddles two images -- iic_amd/geom.py): the walker keeps (n, r = row within the image) in (n, y) and
+// divides once per table entry; rows r >= MY*MX are invalid (conv_tile.h igemm_row_pixels: they read the
+// image's last pixel and get pout = -1, i.e. a zero dY row).
 struct WdWalk {
   int n, y, x;
 };
+__device__ __forceinline__ bool wd_padded(const iic_conv_geom& g) { return g.MP > 0 && g.MP != g.MY * g.MX; }
 __device__ __forceinline__ void wd_walk_init(WdWalk& w, const iic_conv_geom& g, int m) {
+  if (wd_padded(g)) {
+    w.n = m / g.MP;
+    w.y = m - w.n * g.MP;      // r
+    w.x = 0;
+    return;
+  }
   const int plane = g.MY * g.MX;
   w.n = m / plane;
   const int r = m - w.n * plane;
   w.y = r / g.MX;
   w.x = r - w.y * g.MX;
 }
-__device__ __forceinline__ void wd_walk_advance(WdWalk& w, const iic_conv_geom& g, int d_y, int d_x) {
+__device__ __forceinline__ void wd_walk_advance(WdWalk& w, const iic_conv_geom& g, int d_y, int d_x, int d_rows) {
+  if (wd_padded(g)) {
+    w.y += d_rows;
+    while (w.y >= g.MP) { w.y -= g.MP; ++w.n; }
+    return;
+  }
   w.x += d_x;
   w.y += d_y;
   if (w.x >= g.MX) { w.x -= g.MX; ++w.y; }
@@ -101,8 +118,21 @@ __device__ __forceinline__ void wd_walk_advance(WdWalk& w, const iic_conv_geom& 
 }
 __device__ __forceinline__ void wd_walk_pixels(const WdWalk& w, const iic_conv_geom& g, int& pin,
                                                int& pout) {
-  const bool valid = w.n < g.N;
-  const int n = valid ? w.n : g.N - 1, y = valid ? w.y : g.MY - 1, x = valid ? w.x : g.MX - 1;
+  int n, y, x;
+  bool valid;
+  if (wd_padded(g)) {
+    const int plane = g.MY * g.MX;
+    valid = w.n < g.N && w.y < plane;
+    n = w.n < g.N ? w.n : g.N - 1;
+    const int r = valid ? w.y : plane - 1;
+    y = r / g.MX;
+    x = r - y * g.MX;
+  } else {
+    valid = w.n < g.N;
+    n = valid ? w.n : g.N - 1;
+    y = valid ? w.y : g.MY - 1;
+    x = valid ? w.x : g.MX - 1;
+  }
   pin = (n * g.in_Hp + y * g.sy + g.oy) * g.in_Wp + x * g.sx + g.ox;
   pout = valid ? (n * g.out_Hp + y * g.ty + g.py) * g.out_Wp + x * g.tx + g.px : -1;
 }
@@ -196,9 +226,9 @@ __global__ __launch_bounds__(PF ? 256 : WD_THREADS) void conv_wgrad_dma_kernel(
         s_pout[(kt & (WD_NTAB - 1)) * WD_BM + tid] = pout;
         s_prow[(kt & (WD_NTAB - 1)) * WD_BM + tid] = (unsigned short)(pin - p0);
       }
-      wd_walk_advance(wr, g, d_y, d_x);
-      wd_walk_advance(w0, g, d_y, d_x);
-      wd_walk_advance(w1, g, d_y, d_x);
+      wd_walk_advance(wr, g, d_y, d_x, WD_BM);
+      wd_walk_advance(w0, g, d_y, d_x, WD_BM);
+      wd_walk_advance(w1, g, d_y, d_x, WD_BM);
       if (tid == 0) {
         s_plo[(kt & (WD_NTAB - 1)) * 2] = p0;
         s_plo[(kt & (WD_NTAB - 1)) * 2 + 1] = ((p1 + max_tap_off - p0 + 1) * 128 + 1023) >> 10;
@@ -405,13 +435,17 @@ extern "C" void iic_debug_enable_wgrad_dma(int v) { g_wd_enabled = v; }
 // patch does not fit twice in LDS (wide images).  g_wd_enabled = 3 forces it (tests).
 static int wd_config(const iic_conv_geom* g, int* bmk, int* nbuf) {
   if (g->ntaps != 9 || g->Cin % 64 != 0 || g->Cout % 64 != 0 || g->NP <= 0 || g->NP > 65535) return 0;
-  if (g->MP > 0 && g->MP != g->MY * g->MX) return 0;   // the row walkers assume the dense row numbering
+  if (g->MP > 0 && g->MP % 128 != 0) return 0;         // padded numbering: K-tiles must not straddle images
   const int cot = (g->Cout % 128 == 0) ? 128 : 64;
   if (g_wd_enabled != 3 && wd_lds(g->NP, cot, 128, 2) <= 160 * 1024) {
     *bmk = 128;
     *nbuf = 2;
     return 1;
   }
+  // padded row numbering = large images (SegmentationNet10a at 200 x 200): measured with the 64-pixel ring
+  // (the only one that fits there) 675 / 615 / 1180 us for c2 / c3 / c4 against 644 / 593 / 1127 us on the
+  // register-staged kernel -- the walkers support the numbering (tests), the dispatcher keeps the faster kernel
+  if (g->MP > 0 && g->MP != g->MY * g->MX && g_wd_enabled != 3) return 0;
   if (g->NP64 > 0) {
     // (2 buffers: the stride-2 layers, whose 64-row patch spans 330-440 input pixels)
     for (int nb = 4; nb >= 2; --nb)
@@ -434,7 +468,7 @@ int iic_wgrad_dma_launch(const iic_conv_geom* g, const void* x, const void* dy, 
                          int nsplit, void* stream) {
   int bmk = 0, nbuf = 0;
   if (!wd_config(g, &bmk, &nbuf)) return IIC_ERR_UNSUPPORTED;
-  const long M = (long)g->N * g->MY * g->MX;
+  const long M = (long)g->N * (g->MP > 0 ? g->MP : g->MY * g->MX);
   const int kt = (int)((M + bmk - 1) / bmk);
   const int cot = (g->Cout % 128 == 0) ? 128 : 64;
   const int np = bmk == 64 ? g->NP64 : g->NP;

@@ -464,6 +464,36 @@ def test_conv_backward_weight_long_k_ranges(case, nsplit, dma):
     _wgrad_dma(1)
 
 
+@pytest.mark.parametrize("dma", [3, 0])
+@pytest.mark.parametrize("cin,cout,H,dil", [(64, 128, 200, 1), (128, 128, 100, 2)])
+def test_conv_backward_weight_padded_row_numbering(cin, cout, H, dil, dma):
+  """Large images (SegmentationNet10a at 200 x 200, PT border 3): iic_amd.geom pads the per-image GEMM row
+  count to a multiple of 256 (g.MP) so that no tile straddles two images; rows past the image are invalid
+  (zero dY).  The DMA weight-gradient kernel walks that numbering too (dma = 3 forces its 64-pixel ring: by
+  default the dispatcher keeps these layers on the register-staged kernel, which is 4-5 % faster there);
+  both against F.conv2d's weight gradient."""
+  from iic_amd import geom, ops
+  N, K, P = 2, 3, 3
+  x, w = _conv_inputs(cin, cout, K, N, H, 11)
+  wt = w.clone().requires_grad_(True)
+  y = F.conv2d(x, wt, stride=1, padding=1, dilation=dil)
+  dy = bf16_round(torch.from_numpy(np.random.default_rng(6).standard_normal(tuple(y.shape)).astype(np.float32)))
+  y.backward(dy)
+  ref = wt.grad
+  spec = geom.ConvSpec(cin, cout, K, 1, 1, dil)
+  g = geom.fwd_geom(spec, N, H, H, P, P)
+  assert g.MP > g.MY * g.MX and g.MP % 256 == 0, "this case is meant to exercise the padded numbering"
+  _wgrad_dma(dma)
+  try:
+    dW = ops.conv_wgrad(g, ops.pt_from_nchw(x.to(dev()), P), ops.pt_from_nchw(dy.to(dev()), P), K * K, use_tr=True)
+    torch.cuda.synchronize()
+  finally:
+    _wgrad_dma(1)
+  got = dW.view(cout, cin, K, K).cpu()
+  scale = ref.abs().max().item()
+  assert (got - ref).abs().max().item() <= 2e-3 * scale, (got - ref).abs().max().item() / scale
+
+
 def _conv_backward_weight(case, use_tr, nsplit=None):
   from iic_amd import geom, ops
   cin, cout, K, s, p, N, H = case
