@@ -22,19 +22,17 @@
 
 #include "stem_common.h"
 
-// conv outputs for 32 pixels (row y, cols x0..x0+31) x 64 couts of one image.
+// The KS input values this lane contributes to the 32-pixel tile (row y, cols x0..x0+31) of one image, loaded
+// UNCONDITIONALLY (out-of-image taps read element 0 and are zeroed by a select): with the load under the bounds
+// check the compiler emitted branch -> load -> s_waitcnt vmcnt(0) -> 2 MFMAs per k-step, i.e. nine exposed memory
+// latencies per tile (SQ: 44 % of the waves' cycles parked on s_waitcnt, matrix pipe 35 % busy).  Separate from
+// the MFMAs so that callers can have the NEXT tile's values in flight while this tile multiplies.
 template <int CIN>
-__device__ __forceinline__ void stem_conv_tile(const float* __restrict__ xin, int H, int W, int y,
-                                               int x0, int lane,
-                                               const float (&wr)[2][StemK<CIN>::KS],
-                                               f32x16 (&acc)[2]) {
+__device__ __forceinline__ void stem_load_patch(const float* __restrict__ xin, int H, int W, int y, int x0,
+                                                int lane, float (&av)[StemK<CIN>::KS]) {
   constexpr int K = StemK<CIN>::K;
   const int px = x0 + (lane & 31);
   const bool hi = (lane >> 5) != 0;
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[h][r] = 0.f;
 #pragma unroll
   for (int s = 0; s < StemK<CIN>::KS; ++s) {
     const int k0 = 2 * s, k1 = 2 * s + 1;
@@ -43,11 +41,33 @@ __device__ __forceinline__ void stem_conv_tile(const float* __restrict__ xin, in
     const int dx = (hi ? (k1 % 3) : (k0 % 3)) - 1;
     const bool kval = hi ? (k1 < K) : true;
     const int yy = y + dy, xx = px + dx;
-    float a = 0.f;
-    if (kval && yy >= 0 && yy < H && xx >= 0 && xx < W) a = xin[((long)c * H + yy) * W + xx];
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wr[0][s], acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wr[1][s], acc[1], 0, 0, 0);
+    const bool ok = kval && yy >= 0 && yy < H && xx >= 0 && xx < W;
+    const float v = xin[ok ? ((long)c * H + yy) * W + xx : 0];
+    av[s] = ok ? v : 0.f;
   }
+}
+template <int CIN>
+__device__ __forceinline__ void stem_mma(const float (&av)[StemK<CIN>::KS], const float (&wr)[2][StemK<CIN>::KS],
+                                         f32x16 (&acc)[2]) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[h][r] = 0.f;
+#pragma unroll
+  for (int s = 0; s < StemK<CIN>::KS; ++s) {
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], wr[0][s], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], wr[1][s], acc[1], 0, 0, 0);
+  }
+}
+// conv outputs for 32 pixels (row y, cols x0..x0+31) x 64 couts of one image.
+template <int CIN>
+__device__ __forceinline__ void stem_conv_tile(const float* __restrict__ xin, int H, int W, int y,
+                                               int x0, int lane,
+                                               const float (&wr)[2][StemK<CIN>::KS],
+                                               f32x16 (&acc)[2]) {
+  float av[StemK<CIN>::KS];
+  stem_load_patch<CIN>(xin, H, W, y, x0, lane, av);
+  stem_mma<CIN>(av, wr, acc);
 }
 
 // ------------------------------------------------------------------------------------
@@ -70,6 +90,7 @@ __global__ __launch_bounds__(256) void stem_stats_kernel(const float* __restrict
     const long row = t / nseg;
     const int y = (int)(row % H), n = (int)(row / H);
     f32x16 acc[2];
+    // (loading the NEXT tile's values before this tile's MFMAs was measured slower: 223 vs 208 us)
     stem_conv_tile<CIN>(x + (long)n * CIN * H * W, H, W, y, seg * 32, lane, wr, acc);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
