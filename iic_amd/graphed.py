@@ -26,6 +26,7 @@ their forward graph (one operand set per branch, ops / archs.cluster._ConvHolder
 
 Switch: ops.GRAPH_FORWARD[0] (env IIC_GRAPH_FORWARD; `python -m iic_amd.run` turns it on).
 """
+import os
 import sys
 
 import torch
@@ -192,6 +193,8 @@ def forward(fwd, mod, x, args, kwargs):
       st["graphs"][key] = _FAILED
       return eager()
     st["graphs"][key] = vg
+    if os.environ.get("IIC_GRAPH_LOG"):
+      sys.stderr.write("[iic_amd.graphed] captured forward + backward graphs for %r\n" % (key,))
     # the capture bumped the weights epoch (so that the re-layout kernels are part of the graph); this
     # forward still belongs to the step that was running
     st["epoch"] = _epoch(mod)
