@@ -489,12 +489,11 @@ int iic_p64_launch(const iic_conv_geom* g, const void* in, const void* wfrag, vo
                    const void* res_grad, const void* res_act, int accumulate, const void* red_y,
                    const float* red_coef, const void* red_y2, float* red_stats, float* red_stats2,
                    void* stream);
-// conv_igemm_bd2.hip: third generation (half-chunk double-buffered patch, interleaved K loop)
-int iic_bd2_supported(const iic_conv_geom* g, int ms);
-int iic_bd2_launch(const iic_conv_geom* g, const void* in, const void* wfrag, void* out, float* stats,
-                   const void* res_grad, const void* res_act, int accumulate, const void* red_y,
-                   const float* red_coef, const void* red_y2, float* red_stats, float* red_stats2,
-                   int dense_key, unsigned long long* prof, void* stream);
+// conv_igemm_pw.hip: persistent kernel for the stride-1 multi-tap launches (round 4)
+int iic_pw_supported(const iic_conv_geom* g);
+int iic_pw_launch(const iic_conv_geom* g, const void* in, const void* wfrag, void* out, float* stats,
+                  const void* res_grad, const void* res_act, int accumulate, const void* red_y,
+                  const float* red_coef, const void* red_y2, float* red_stats, float* red_stats2, void* stream);
 static int g_bd_one_wg = 1;      // also take LDS footprints that leave room for only one workgroup per CU
                                  // (large-image segmentation layers: still 15-20 % faster than conv_igemm_kernel)
 extern "C" void iic_debug_bd_one_wg(int v) { g_bd_one_wg = v; }
@@ -610,12 +609,9 @@ int iic_conv_igemm_frag_red(const iic_conv_geom* g, const void* in, const void* 
     return iic_p64_launch(g, in, wfrag, out, stats, res_grad, res_act, accumulate, red_y, red_coef, red_y2,
                           red_stats, red_stats2, stream);
   }
-  {
-    const int abl = iic_debug_get_ablate();
-    if (g->ntaps > 1 && g_bd_dma && g_bd_ms != 2 && (abl == 0 || abl == 128) && iic_bd2_supported(g, 4))
-      return iic_bd2_launch(g, in, wfrag, out, stats, res_grad, res_act, accumulate, red_y, red_coef, red_y2,
-                            red_stats, red_stats2, g_bd_dense_key, abl == 128 ? g_bd_prof : nullptr, stream);
-  }
+  if (iic_debug_get_ablate() == 0 && g_bd_dma && g_bd_ms == 0 && iic_pw_supported(g))
+    return iic_pw_launch(g, in, wfrag, out, stats, res_grad, res_act, accumulate, red_y, red_coef, red_y2, red_stats,
+                         red_stats2, stream);
   const long M = igemm_rows_host(g);
   if (M <= 0) return IIC_ERR_ARG;
   if (M >= (1L << 31) || (long)g->N * g->in_Hp * g->in_Wp >= (1L << 31)) return IIC_ERR_UNSUPPORTED;

@@ -29,9 +29,9 @@
 // pixels 2 apart straddle an image-row end (2-way).  The swizzle is applied on the DMA's SOURCE address.
 #include <type_traits>
 
-#include "common.h"
-#include "conv_tile.h"
-#include "../../include/iic_hip.h"
+#include "../common.h"
+#include "../conv_tile.h"
+#include "../../../include/iic_hip.h"
 
 #define B2_BN 128
 #define B2_THREADS 256

@@ -11,7 +11,7 @@
 //   stage 4  + tile epilogue: accumulators -> bf16 -> LDS -> 16-byte global stores (256 x 128 tile)
 // Every workgroup also stamps s_memtime / s_memrealtime so that the tool can report the shader
 // clock the chip actually held (cycles per 100 MHz tick).
-#include "common.h"
+#include "../common.h"
 #include <type_traits>
 
 #define MF_THREADS 256

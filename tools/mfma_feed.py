@@ -35,7 +35,7 @@ def main():
                   "1 B loads L1-hot, 2 setprio around the MFMAs, 4 interleaved issue order, 6 = 2+4, 8 B ring 16 deep")
   a = ap.parse_args()
   dev = torch.device("cuda:0")
-  L = ctypes.CDLL(_lib.LIB_PATH)
+  L = ctypes.CDLL(os.path.join(os.path.dirname(_lib.LIB_PATH), "libiic_probe.so"))   # make -C iic_amd/csrc probes
   fn = L.iic_debug_mfma_feed
   fn.restype = ctypes.c_int
   fn.argtypes = [ctypes.c_int] * 6 + [ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_void_p,
