@@ -92,6 +92,16 @@ class _ViewGraph(object):
     cur.wait_stream(self.cap)
     self.static_outs = [o.detach() for o in self.outs]
     self.first = True
+    self.sig = _storage_sig(mod)
+
+
+def _storage_sig(mod):
+  """Device addresses of every parameter and buffer of the module.  A captured graph has them baked in; the
+  reference's scripts move the whole network to the host and back around every checkpoint
+  (/root/reference/code/scripts/cluster/cluster_sobel.py:314-339: net.module.cpu() ... net.module.cuda()), which
+  re-allocates all of them -- replaying the old graphs would then train on freed memory (found by running the real
+  scripts on the GPU, round 4: epoch 2 of a graph-replay run diverged from the eager run)."""
+  return tuple(p.data_ptr() for p in mod.parameters()) + tuple(b.data_ptr() for b in mod.buffers())
 
 
 class _GraphedFn(torch.autograd.Function):
@@ -178,6 +188,13 @@ def forward(fwd, mod, x, args, kwargs):
     finally:
       ops.BRANCH[0] = prev
   vg = st["graphs"].get(key)
+  if vg is not None and vg is not _FAILED and vg.sig != _storage_sig(mod):
+    # the module's storage moved (.cpu() / .cuda() / .to()): every graph of this module is stale
+    if os.environ.get("IIC_GRAPH_LOG"):
+      sys.stderr.write("[iic_amd.graphed] parameters moved: dropped %d captured graphs\n" % len(st["graphs"]))
+    st["graphs"].clear()
+    st["warm"].clear()
+    vg = None
   if vg is _FAILED:
     return eager()
   if vg is None:
@@ -185,12 +202,19 @@ def forward(fwd, mod, x, args, kwargs):
     if n < WARMUP:
       st["warm"][key] = n + 1
       return eager()
+    n_def = len(ops._DEFERRED_RUNNING)
     try:
       vg = _ViewGraph(fwd, mod, x, args, kwargs, res)
     except Exception as e:                   # noqa: BLE001 -- never take a run down over an optimisation
       sys.stderr.write("[iic_amd.graphed] capture failed for %r (%s: %s): eager launches for this shape\n"
                        % (key, type(e).__name__, e))
       st["graphs"][key] = _FAILED
+      # Undo what the aborted capture left on the host: running-statistic updates it queued (their kernels never
+      # ran), operand sets whose re-layout was only recorded (a fresh weights epoch makes every holder re-lay
+      # them eagerly), and the step position (the capture bumped the epoch once already).
+      del ops._DEFERRED_RUNNING[n_def:]
+      _cl.bump_weights_epoch()
+      st["epoch"] = _epoch(mod)
       return eager()
     st["graphs"][key] = vg
     if os.environ.get("IIC_GRAPH_LOG"):

@@ -480,6 +480,7 @@ class _PrepJob(ctypes.Structure):
 
 
 _PREP_TABLES = {}      # (device index, tuple of jobs) -> (device table, njobs, total blocks)
+_PREP_PINNED = set()   # keys whose launch was recorded into a HIP graph: the table's address is baked in
 MULTI_PREP = [os.environ.get("IIC_MULTI_PREP", "1") != "0"]
 
 
@@ -504,9 +505,11 @@ def refresh_prepped(pws, device):
       blk += lib().iic_weight_prep_multi_blocks(co, ci, t)
     host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
     ent = _PREP_TABLES[key] = (host.to(device), len(jobs), blk)
-    if len(_PREP_TABLES) > 64:          # (tables of networks that no longer exist)
-      for k in list(_PREP_TABLES)[:-32]:
+    if len(_PREP_TABLES) > 256:         # (tables of networks that no longer exist; never one a graph may replay)
+      for k in [k for k in list(_PREP_TABLES)[:-128] if k not in _PREP_PINNED]:
         del _PREP_TABLES[k]
+  if torch.cuda.is_current_stream_capturing():
+    _PREP_PINNED.add(key)
   check(lib().iic_weight_prep_multi(ptr(ent[0]), ent[1], ent[2], stream_ptr()), "iic_weight_prep_multi")
   return True
 
@@ -791,6 +794,7 @@ def avgpool_bwd(dfeats, out_pt, N, H, W, P, C, mask_act=None):
 
 
 _GEMM_WS = {}      # (branch, device) -> fp32 workspace of the K-split GEMMs (grown on demand, reused)
+_GEMM_WS_RETIRED = []   # superseded workspaces: a captured graph may have their address baked in -- never freed
 
 
 def gemm_f32(A, sam, sak, B, sbk, sbn, C, scm, M, N, K, bias=None, accumulate=False):
@@ -800,7 +804,10 @@ def gemm_f32(A, sam, sak, B, sbk, sbn, C, scm, M, N, K, bias=None, accumulate=Fa
     key = (BRANCH[0], C.device.index)
     ws = _GEMM_WS.get(key)
     if ws is None or ws.numel() < need:
-      ws = _GEMM_WS[key] = torch.empty(need, dtype=F32, device=C.device)
+      if ws is not None:
+        _GEMM_WS_RETIRED.append(ws)        # (head B's graphs kept replaying into a buffer that head A's
+                                           #  larger request had freed)
+      ws = _GEMM_WS[key] = torch.empty(max(need, 1 << 20), dtype=F32, device=C.device)
   check(lib().iic_gemm_f32_ws(ptr(A), sam, sak, ptr(B), sbk, sbn, ptr(bias), ptr(C), scm, M, N, K,
                               1 if accumulate else 0, ptr(ws), need, stream_ptr()), "iic_gemm_f32_ws")
   return C

@@ -69,7 +69,14 @@ class Adam(torch.optim.Optimizer):
 
   # ---- checkpoint compatibility with torch.optim.Adam (step stored as a tensor there) ----
   def load_state_dict(self, state_dict):
+    # captured graphs read the learning rate through the EXISTING device tensors: keep them across the
+    # replacement of param_groups and refill them with the loaded rates
+    lr_devs = [g.get("_lr_dev") for g in self.param_groups]
     super(Adam, self).load_state_dict(state_dict)
+    for g, t in zip(self.param_groups, lr_devs):
+      if t is not None:
+        t.fill_(float(g["lr"]))
+        g["_lr_dev"], g["_lr_pushed"] = t, float(g["lr"])
     self._members = {}
     for st in self.state.values():
       if "step" in st:
@@ -180,7 +187,8 @@ class Adam(torch.optim.Optimizer):
                float(group["eps"]))
       if self.capturable:
         lr_dev = self._lr_dev(group, ps[0].device)
-        self.sync_lr()
+        if not torch.cuda.is_current_stream_capturing():
+          self.sync_lr()         # (recorded into a graph, the fill would reset the rate at every replay: ADVICE r3)
         for counter, grp in self._counter_groups(ps):
           keep, tab = self._tables(grp, self.state)
           check(lib().iic_adam_step_devlr(*tab, lr_dev.data_ptr(), *hyper, counter.data_ptr(), stream_ptr()),

@@ -123,6 +123,29 @@ def _model_ind(argv):
   return None
 
 
+def _restart_epoch(argv):
+  """Epoch a `--restart` run continues from (config.pickle of <out_root>/<model_ind>, written by the script every
+  epoch), 0 otherwise: the per-run RNG seed is offset by it so that a restarted multi-rank run does not replay the
+  shuffle / augmentation sequence of epoch 0 (every rank derives the same value)."""
+  if "--restart" not in argv:
+    return 0
+  import pickle
+  root = None
+  for i, a in enumerate(argv):
+    if a == "--out_root" and i + 1 < len(argv):
+      root = argv[i + 1]
+    elif a.startswith("--out_root="):
+      root = a.split("=", 1)[1]
+  ind = _model_ind(argv)
+  if root is None or ind is None:
+    return 0
+  try:
+    with open(os.path.join(root, ind, "config.pickle"), "rb") as f:
+      return int(getattr(pickle.load(f), "last_epoch", 0)) + 1
+  except Exception:      # noqa: BLE001  (no checkpoint yet: the script itself will complain)
+    return 0
+
+
 def main(argv=None):
   argv = list(sys.argv[1:] if argv is None else argv)
   if not argv:
@@ -146,7 +169,7 @@ def main(argv=None):
     import random
     import shutil
     import numpy as np
-    seed = int(os.environ.get("IIC_RUN_SEED", "0"))
+    seed = int(os.environ.get("IIC_RUN_SEED", "0")) + 1000003 * _restart_epoch(argv)
     random.seed(seed)
     np.random.seed(seed)
     torch.manual_seed(seed)
