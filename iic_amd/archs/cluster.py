@@ -313,6 +313,14 @@ class _StemF32Fn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------
 # BasicBlock  (residual.py:10-43)
 # ------------------------------------------------------------------------------------
+# Timing ablation (results WRONG; bench.py --lr 0): skip the forward BatchNorm+ReLU apply between conv1 and conv2 of
+# the blocks of layers 2-4 -- the upper bound of what fusing that pass into conv2's loaders could give
+# (profiles/r04_bn_ablation.txt).  The first two steps still apply, so that the recycled activation
+# buffers hold realistic values afterwards: skipped from the start, conv2 multiplied the pool's zero-filled
+# buffers and the whole step ran 4.3 ms faster -- zero operands draw less power, the chip clocks higher.
+ABLATE_BN1_APPLY = [os.environ.get("IIC_ABLATE_BN1_APPLY", "0") != "0", 0]
+
+
 class _BlockFn(torch.autograd.Function):
   @staticmethod
   def forward(ctx, x, w1, g1, b1, w2, g2, b2, wd, gd, bd, blk, chain=None):
@@ -340,7 +348,9 @@ class _BlockFn(torch.autograd.Function):
     ops.conv_igemm(gf1, x, h1.weights()[0], y1, stats=st1)
     coef1 = bn_coef(blk.bn1, h1, g1, b1, st1)
     a1 = ops.pt_alloc(N, Ho, Wo, planes, 1, dev)
-    ops.bn_apply(y1, coef1, a1, N, Ho, Wo, 1, planes, relu=True)
+    ABLATE_BN1_APPLY[1] += 1
+    if not (ABLATE_BN1_APPLY[0] and planes >= 128 and ABLATE_BN1_APPLY[1] > 2 * 2 * 16):
+      ops.bn_apply(y1, coef1, a1, N, Ho, Wo, 1, planes, relu=True)
     st2 = h2.stats(dev) if _bn_training(blk.bn2) else None
     y2 = ops.pt_alloc(N, Ho, Wo, planes, 1, dev)
     ops.conv_igemm(gf2, a1, h2.weights()[0], y2, stats=st2)

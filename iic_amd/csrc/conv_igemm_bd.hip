@@ -559,6 +559,13 @@ static int bd_pick_ms(const iic_conv_geom* g) {
   const bool ok2 = (g->ntaps == 1 || g->NP > 0) && bd_lds_total(g, 2) <= 160 * 1024;
   if (g_bd_ms == 4) return ok4 ? 4 : (ok2 ? 2 : 0);
   if (g_bd_ms == 2) return ok2 ? 2 : (ok4 ? 4 : 0);
+  // small launches (a rank's share of the batch under strong scaling: tools/pairs_sweep.sh): when the 256-row tiles
+  // fill less than half of the chip's 512 workgroup slots, 128-row tiles (3 workgroups per CU) halve the time a
+  // launch is held up by its single round (660 / 4 images: conv family 7.58 -> 7.08 ms per step)
+  if (ok4 && ok2 && g->ntaps > 1) {
+    const long M = igemm_rows_host(g);
+    if (((M + 255) / 256) * (g->Cout / BD_BN) * 2 <= 512) return 2;
+  }
   return ok4 ? 4 : (ok2 ? 2 : 0);
 }
 

@@ -57,3 +57,35 @@ def test_small_gemm_families(shape):
   M, N, K = shape
   _run(M, N, K, True, True, bias=True, accumulate=False)
   _run(M, N, K, False, False, bias=False, accumulate=True)
+
+
+@pytest.mark.gpu
+def test_k_split_workspace_is_never_freed_when_it_grows():
+  """the K-split GEMM workspace of a branch used to be re-allocated when a later call needed
+  more (head A's 660 x 350 logits after head B's 660 x 50): the old tensor went back to the caching allocator with
+  its address still baked into head B's captured graphs.  Superseded workspaces are now kept alive."""
+  import torch
+  from iic_amd import ops
+  dev = torch.device("cuda:0")
+  ops._GEMM_WS.clear()
+  del ops._GEMM_WS_RETIRED[:]
+
+  def logits(n, k_out, kdim=512):
+    x = torch.randn(n, kdim, device=dev)
+    w = torch.randn(k_out, kdim, device=dev)
+    c = torch.empty(n, k_out, device=dev)
+    ops.gemm_f32(x, kdim, 1, w, 1, kdim, c, k_out, n, k_out, kdim)
+    torch.cuda.synchronize()
+    assert torch.allclose(c, x @ w.t(), rtol=2e-4, atol=2e-3)
+  logits(660, 50)
+  key = (ops.BRANCH[0], dev.index)
+  first = ops._GEMM_WS.get(key)
+  if first is None:
+    pytest.skip("this shape takes no K split on this build")
+  p0, n0 = first.data_ptr(), first.numel()
+  logits(4096, 700)                       # a larger request on the same branch
+  second = ops._GEMM_WS[key]
+  if second.data_ptr() != p0:
+    assert second.numel() > n0
+    assert any(t.data_ptr() == p0 for t in ops._GEMM_WS_RETIRED), "the superseded workspace was freed"
+  logits(660, 50)                         # and the small shape still computes right
