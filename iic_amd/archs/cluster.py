@@ -604,7 +604,7 @@ class ClusterNet5gHead(nn.Module):
     if kmeans_use_features:
       return [x for _ in range(self.num_sub_heads)]   # duplicates, as the reference
     probs = self.forward_packed(x)
-    return [probs[:, i, :] for i in range(self.num_sub_heads)]
+    return ops.tag_pack([probs[:, i, :] for i in range(self.num_sub_heads)])
 
 
 # ------------------------------------------------------------------------------------

@@ -262,7 +262,7 @@ class ClusterNet6cHead(nn.Module):
     if kmeans_use_features:
       return [x for _ in range(self.num_sub_heads)]
     probs = self.forward_packed(x)
-    return [probs[:, i, :] for i in range(self.num_sub_heads)]
+    return ops.tag_pack([probs[:, i, :] for i in range(self.num_sub_heads)])
 
 
 def _initialize_weights_vgg(net, mode="fan_in"):

@@ -6,6 +6,8 @@ the hot path is a kernel of libiic_hip.so.  All wrappers enqueue on torch's curr
 import ctypes
 import os
 
+import weakref
+
 import torch
 
 from . import _lib
@@ -189,6 +191,33 @@ _FEATURE_FLAGS = ("trunk_features", "penultimate_features", "kmeans_use_features
 # optimiser and the losses join.  A caller that does neither would grow the list without bound and
 # evaluate on stale running statistics -- past this many entries the next forward joins by itself.
 _DEFERRED_LIMIT = 1024
+
+
+class HeadPack(object):
+  """What the sub-head outputs of ONE forward share: the reference hands the loss a python list of per-sub-head
+  [bn, k] tensors (net5g.py:76-80) and calls IID_loss once per sub-head (cluster_sobel.py:241-253).  The list's
+  tensors are tagged with their pack and index so that iic_amd.losses.IID_loss can evaluate all sub-head pairs of
+  two packs in ONE set of launches at the first call and hand the other calls their share."""
+  __slots__ = ("tensors", "cache", "__weakref__")
+
+  def __init__(self, tensors):
+    # weak references: a tensor -> pack -> tensor cycle would keep a step's autograd graph (and with it ~18 GB of
+    # saved activations at the north-star batch) alive until the cyclic garbage collector happens to run
+    self.tensors = [weakref.ref(t) for t in tensors]
+    self.cache = {}
+
+  def alive(self):
+    ts = [r() for r in self.tensors]
+    return ts if all(t is not None for t in ts) else None
+
+
+def tag_pack(tensors):
+  """Tag a list of per-sub-head output tensors (returns the list)."""
+  if len(tensors) > 1 and all(torch.is_tensor(t) and t.dim() == 2 for t in tensors):
+    pack = HeadPack(tensors)
+    for i, t in enumerate(tensors):
+      t._iic_pack = (pack, i)
+  return tensors
 
 
 # Graph replay of the training forwards / backwards for unchanged scripts (iic_amd/graphed.py);

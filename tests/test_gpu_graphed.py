@@ -101,3 +101,46 @@ def test_other_batch_shape_falls_back_to_eager_launches():
   assert na == 2 and la == le
   for k in sa:
     assert torch.equal(sa[k], se[k]), k
+
+
+def test_per_sub_head_loss_calls_are_batched_and_bit_identical():
+  """The script calls IID_loss once per sub-head on the list net(x) returned (cluster_sobel.py:241-253): the tagged
+  lists let the first call evaluate every sub-head pair in one set of launches (iic_amd.losses._packed_pair).  Losses,
+  no-lamb losses and the parameter gradients must equal the one-call-per-sub-head path bit for bit; mismatched pairs
+  and untagged tensors fall back to it."""
+  from iic_amd import archs, losses, ops
+  from iic_amd.transforms import sobel_process
+  dev = torch.device("cuda:0")
+  cfg = types.SimpleNamespace(in_channels=2, input_sz=32, batchnorm_track=True, num_sub_heads=5, output_k=10)
+  g = torch.Generator().manual_seed(2)
+  imgs = torch.rand(24, 1, 32, 32, generator=g).to(dev)
+  imgs_tf = (torch.flip(imgs, dims=[3]) * 0.9 + 0.03).clamp(0, 1)
+  out = {}
+  for batched in (True, False):
+    torch.manual_seed(0)
+    net = archs.ClusterNet5g(cfg).to(dev).train()
+    losses.BATCH_SUB_HEADS[0] = batched
+    try:
+      xo, xt = net(sobel_process(imgs, False)), net(sobel_process(imgs_tf, False))
+      assert hasattr(xo[0], "_iic_pack") and xo[3]._iic_pack[1] == 3
+      vals, tot = [], None
+      for i in range(5):
+        l, nl = losses.IID_loss(xo[i], xt[i], lamb=1.5)
+        vals += [l.item(), nl.item()]
+        tot = l if tot is None else tot + l
+      if batched:
+        assert len(xo[0]._iic_pack[0].cache) == 1             # one evaluation served the five calls
+        m, _ = losses.IID_loss(xo[1], xt[2], lamb=1.5)        # a mismatched pair is not served from it
+        ref, _ = losses._IIDLossFn.apply(xo[1].unsqueeze(0), xt[2].unsqueeze(0), 1.5, 2.220446049250313e-16)
+        assert m.item() == ref[0].item()
+        u, _ = losses.IID_loss(xo[0].clone(), xt[0].clone(), lamb=1.5)       # untagged copies
+        assert u.item() == vals[0]
+      (tot / 5).backward()
+      torch.cuda.synchronize()
+      out[batched] = (vals, [p.grad.clone() for p in net.parameters()])
+    finally:
+      losses.BATCH_SUB_HEADS[0] = True
+      ops.join()
+  assert out[True][0] == out[False][0], (out[True][0], out[False][0])
+  for a, b in zip(out[True][1], out[False][1]):
+    assert torch.equal(a, b)
