@@ -94,6 +94,8 @@ class _ViewGraph(object):
     self.static_outs = [o.detach() for o in self.outs]
     self.first = True
     self.sig = _storage_sig(mod)
+    self.bwd_event = None        # recorded after every backward replay (consumers of the static gradients wait on it)
+    self.family = {}             # the module's {key: _ViewGraph} (set by forward())
 
 
 def _storage_sig(mod):
@@ -130,6 +132,8 @@ class _GraphedFn(torch.autograd.Function):
       else:
         s.copy_(g)
     vg.g_b.replay()
+    vg.bwd_event = torch.cuda.Event()
+    vg.bwd_event.record()
     # The first view to arrive hands autograd fresh aliases of its static gradient buffers: AccumulateGrad takes
     # them as .grad without a copy (it owns the only reference to the alias).  A later view (every .grad already
     # set, by AccumulateGrad nodes that ran on this same engine thread) would cost one `add_` launch per
@@ -144,6 +148,12 @@ class _GraphedFn(torch.autograd.Function):
       else:
         ret.append(None if g is None else g.detach())
     if tgt:
+      # the .grad buffers being added to were written by ANOTHER view's backward graph, possibly on another stream
+      # (auto_branch): autograd's AccumulateGrad would have synchronised with it, so must this
+      cur = torch.cuda.current_stream()
+      for other in vg.family.values():
+        if other is not vg and other is not _FAILED and other.bwd_event is not None:
+          cur.wait_event(other.bwd_event)
       torch._foreach_add_(tgt, src)
     return (None, None) + tuple(ret)
 
@@ -231,6 +241,7 @@ def forward(fwd, mod, x, args, kwargs):
       st["epoch"] = _epoch(mod)
       return eager()
     st["graphs"][key] = vg
+    vg.family = st["graphs"]
     if os.environ.get("IIC_GRAPH_LOG"):
       sys.stderr.write("[iic_amd.graphed] captured forward + backward graphs for %r\n" % (key,))
     # the capture bumped the weights epoch (so that the re-layout kernels are part of the graph); this

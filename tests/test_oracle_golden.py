@@ -119,6 +119,17 @@ def test_net5g_oracle_matches_reference(g_nets):
   for n, gr in gs.items():
     ref = g_nets["net5g_grad/" + n]
     assert abs(float(gr.double().norm()) - ref[0]) <= 1e-3 * max(ref[0], 1e-6), n
+  # the gradients themselves (oracle/gen_golden_grads.py: whole tensors up to 40960 elements, 8192 evenly spaced
+  # elements of the larger ones)
+  gg = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "net5g_grads.npz"))
+  assert float(gg["loss"][0]) == float(g_nets["net5g_loss"][0])
+  for n, gr in gs.items():
+    ref = gg["grad/" + n].astype(np.float64)
+    got = gr.detach().double().numpy().reshape(-1)
+    if got.size > 40960:
+      got = got[(np.arange(8192, dtype=np.int64) * got.size) // 8192]
+    err = np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30)
+    assert err <= 1e-3 or np.linalg.norm(got - ref) <= 1e-9, (n, err)
   assert np.allclose(params["trunk.bn1.running_mean"].numpy(), g_nets["net5g_rm_bn1"], atol=1e-6)
   assert np.allclose(params["trunk.bn1.running_var"].numpy(), g_nets["net5g_rv_bn1"], atol=1e-6)
   assert np.allclose(params["trunk.layer4.2.bn2.running_var"].numpy(), g_nets["net5g_rv_l4"],
