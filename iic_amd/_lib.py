@@ -57,6 +57,10 @@ _SIGNATURES = {
   "iic_conv_igemm_frag_supported": (c_int, [POINTER(ConvGeom)]),
   "iic_conv_igemm_frag": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P, _P, _P, c_int, _P]),
   "iic_conv_igemm_red_supported": (c_int, [POINTER(ConvGeom)]),
+  "iic_conv_igemm_apply_supported": (c_int, [POINTER(ConvGeom)]),
+  "iic_conv_igemm_frag_apply": (c_int, [POINTER(ConvGeom), _P, _P, c_int, _P, _P, _P, _P]),
+  "iic_conv_wgrad_apply_supported": (c_int, [POINTER(ConvGeom)]),
+  "iic_conv_wgrad_apply": (c_int, [POINTER(ConvGeom), _P, _P, c_int, _P, _P, c_int, _P]),
   "iic_conv_igemm_frag_red": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P]),
   "iic_weight_prep_frag": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
   "iic_weight_prep_multi_blocks": (c_long, [c_int, c_int, c_int]),

@@ -347,13 +347,23 @@ class _BlockFn(torch.autograd.Function):
     y1 = ops.pt_alloc(N, Ho, Wo, planes, 1, dev)
     ops.conv_igemm(gf1, x, h1.weights()[0], y1, stats=st1)
     coef1 = bn_coef(blk.bn1, h1, g1, b1, st1)
-    a1 = ops.pt_alloc(N, Ho, Wo, planes, 1, dev)
-    ABLATE_BN1_APPLY[1] += 1
-    if not (ABLATE_BN1_APPLY[0] and planes >= 128 and ABLATE_BN1_APPLY[1] > 2 * 2 * 16):
-      ops.bn_apply(y1, coef1, a1, N, Ho, Wo, 1, planes, relu=True)
+    # conv2 reads relu(bn1(y1)): either a tensor a1 made by a separate pass, or -- fused -- y1 itself with bn1's
+    # coefficients applied to the staged patch (ops.conv_igemm_apply; the weight gradient does the same in backward,
+    # the data gradient's ReLU mask comes from (y1, coef1) anyway: BN_MASK_FROM_Y).  Needs the mask-from-y backward
+    # and an un-tapped activation (nobody else reads a1).
+    fuse_a1 = (need_grad or not torch.is_grad_enabled()) and BN_MASK_FROM_Y[0] and FUSE_RED[0] and \
+        ops.apply_supported(gf2, h2.weights()[0]) and not (ABLATE_BN1_APPLY[0])
     st2 = h2.stats(dev) if _bn_training(blk.bn2) else None
     y2 = ops.pt_alloc(N, Ho, Wo, planes, 1, dev)
-    ops.conv_igemm(gf2, a1, h2.weights()[0], y2, stats=st2)
+    if fuse_a1:
+      a1 = None
+      ops.conv_igemm_apply(gf2, y1, coef1, 1, h2.weights()[0], y2, stats=st2)
+    else:
+      a1 = ops.pt_alloc(N, Ho, Wo, planes, 1, dev)
+      ABLATE_BN1_APPLY[1] += 1
+      if not (ABLATE_BN1_APPLY[0] and planes >= 128 and ABLATE_BN1_APPLY[1] > 2 * 2 * 16):
+        ops.bn_apply(y1, coef1, a1, N, Ho, Wo, 1, planes, relu=True)
+      ops.conv_igemm(gf2, a1, h2.weights()[0], y2, stats=st2)
     coef2 = bn_coef(blk.bn2, h2, g2, b2, st2)
     out = ops.pt_alloc(N, Ho, Wo, planes, 1, dev)
     yd = coefd = None
@@ -388,12 +398,14 @@ class _BlockFn(torch.autograd.Function):
           chain.ctx, chain.y2, chain.yd, chain.blk = ctx, y2, yd, blk
         else:
           chain.ctx = None
+      ctx.fuse_a1 = fuse_a1
       ctx.save_for_backward(x, y1, a1, y2, out, yd, coef1, coef2, coefd, g1, g2, gd)
     else:
       if chain is not None:
         chain.ctx = None
       for t in (y1, a1, y2, yd):
-        ops.POOL.release(t)
+        if t is not None:
+          ops.POOL.release(t)
     return out
 
   @ops.branch_backward
@@ -442,7 +454,10 @@ class _BlockFn(torch.autograd.Function):
       return r
 
     # ---- conv2 backward: weight grad (side stream) || data grad + bn1 backward (main)
-    dW2 = on_side(lambda: ops.conv_wgrad(gf2, a1, dy2, 9, use_tr)).view(planes, planes, 3, 3)
+    if ctx.fuse_a1:      # X operand = relu(bn1(y1)) applied to the staged patch
+      dW2 = on_side(lambda: ops.conv_wgrad(gf2, y1, dy2, 9, use_tr, x_coef=coef1, x_pad=1)).view(planes, planes, 3, 3)
+    else:
+      dW2 = on_side(lambda: ops.conv_wgrad(gf2, a1, dy2, 9, use_tr)).view(planes, planes, 3, 3)
     dWd = None
     if hd is not None:
       gfd, _ = hd.geoms(N, H, W)

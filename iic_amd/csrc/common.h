@@ -99,6 +99,24 @@ __device__ __forceinline__ void iic_stat_collect(float* stats, int nstripes, int
   v1 = p1 ? __builtin_nan("") : a1;
 }
 
+// floor(n / d) for 0 <= n < 2^31 as a multiply-shift (64-bit product); the pair is made on the host
+struct iic_mdiv {
+  unsigned mul;
+  int sh;
+};
+static inline iic_mdiv iic_make_mdiv(int d) {
+  iic_mdiv r;
+  int l = 0;
+  while ((1L << l) < d) ++l;
+  r.sh = 31 + l;
+  r.mul = (unsigned)(((1ULL << r.sh) + (unsigned long long)d - 1) / (unsigned long long)d);
+  if (d == 1) { r.mul = 1u << 31; r.sh = 31; }
+  return r;
+}
+__device__ __forceinline__ int iic_mdivide(int n, const iic_mdiv& d) {
+  return (int)(((unsigned long long)(unsigned)n * d.mul) >> d.sh);
+}
+
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) {
   return __uint_as_float(((uint32_t)v) << 16);
 }

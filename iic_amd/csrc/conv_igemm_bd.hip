@@ -569,6 +569,27 @@ static int bd_pick_ms(const iic_conv_geom* g) {
   return ok4 ? 4 : (ok2 ? 2 : 0);
 }
 
+int iic_pw_apply_supported(const iic_conv_geom* g);
+int iic_pw_launch_apply(const iic_conv_geom* g, const void* in, const float* in_coef, int in_pad, int apply_relu,
+                        const void* wfrag, void* out, float* stats, const void* res_grad, const void* res_act,
+                        int accumulate, const void* red_y, const float* red_coef, const void* red_y2,
+                        float* red_stats, float* red_stats2, void* stream);
+
+/* 1 if iic_conv_igemm_frag_apply can run this geometry. */
+int iic_conv_igemm_apply_supported(const iic_conv_geom* g) {
+  return g && g_bd_dma && iic_debug_get_ablate() == 0 && iic_pw_apply_supported(g);
+}
+
+/* Forward convolution whose input is relu(scale[c] * in + shift[c]) on the interior of `in` (0 on its border of width
+ * in_pad): conv(bn-relu(in)) without the activation tensor. */
+int iic_conv_igemm_frag_apply(const iic_conv_geom* g, const void* in, const float* in_coef, int in_pad,
+                              const void* wfrag, void* out, float* stats, void* stream) {
+  if (!g || !in || !in_coef || !wfrag || !out || in_pad < 0) return IIC_ERR_ARG;
+  if (!iic_conv_igemm_apply_supported(g)) return IIC_ERR_UNSUPPORTED;
+  return iic_pw_launch_apply(g, in, in_coef, in_pad, 1, wfrag, out, stats, nullptr, nullptr, 0, nullptr, nullptr,
+                             nullptr, nullptr, nullptr, stream);
+}
+
 /* 1 if iic_conv_igemm_frag can run this geometry (else use iic_conv_igemm). */
 int iic_conv_igemm_frag_supported(const iic_conv_geom* g) {
   if (!g) return 0;

@@ -336,6 +336,9 @@ __global__ void probe_tr16_kernel(uint16_t* out) {
 int iic_wgrad_dma_supported(const iic_conv_geom* g);
 int iic_wgrad_dma_launch(const iic_conv_geom* g, const void* x, const void* dy, float* partials,
                          int nsplit, void* stream);
+int iic_wgrad_dma_apply_supported(const iic_conv_geom* g);
+int iic_wgrad_dma_launch_apply(const iic_conv_geom* g, const void* x, const float* x_coef, int x_pad, int relu,
+                               const void* dy, float* partials, int nsplit, void* stream);
 
 extern "C" {
 
@@ -387,6 +390,20 @@ int iic_conv_wgrad(const iic_conv_geom* g, const void* x, const void* dy, float*
   if (use_tr) { if (ga) WGRAD_LAUNCH2(true, true); else WGRAD_LAUNCH2(true, false); }
   else        { if (ga) WGRAD_LAUNCH2(false, true); else WGRAD_LAUNCH2(false, false); }
   return iic_launch_status();
+}
+
+int iic_conv_wgrad_apply_supported(const iic_conv_geom* g) {
+  if (!g || g->Cin % 64 != 0 || g->Cout % 64 != 0) return 0;
+  const long M = igemm_rows_host(g);
+  if (M >= (1L << 31) || (long)g->N * g->in_Hp * g->in_Wp >= (1L << 31)) return 0;
+  return iic_wgrad_dma_apply_supported(g);
+}
+
+int iic_conv_wgrad_apply(const iic_conv_geom* g, const void* x, const float* x_coef, int x_pad, const void* dy,
+                         float* partials, int nsplit, void* stream) {
+  if (!g || !x || !x_coef || !dy || !partials || nsplit < 1 || x_pad < 0) return IIC_ERR_ARG;
+  if (!iic_conv_wgrad_apply_supported(g)) return IIC_ERR_UNSUPPORTED;
+  return iic_wgrad_dma_launch_apply(g, x, x_coef, x_pad, 1, dy, partials, nsplit, stream);
 }
 
 int iic_conv_wgrad_reduce(const float* partials, int nsplit, int T, int Cout, int Cin, float* dW,

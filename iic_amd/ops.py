@@ -611,9 +611,37 @@ def conv_igemm(g, x_pt, w_t, out_pt, stats=None, res_grad=None, res_act=None, ac
 _WG_PART = {}
 
 
-def conv_wgrad(g, x_pt, dy_pt, wtaps, use_tr=True, out=None, accumulate=False, nsplit=None):
+# conv(relu(bn(y))) without the activation tensor (include/iic_hip.h iic_conv_igemm_frag_apply / iic_conv_wgrad_apply):
+# built and bit-identical, but OFF by default (IIC_FUSE_APPLY=1 switches it on): measured on the north-star step
+# (profiles/r04_bn_ablation.txt) the in-LDS transform costs conv2's forward +25...30 us and its weight gradient +33 us
+# per launch (1.6 ms per step) to save 26 bn_apply launches of ~26 us each (0.7 ms) -- the layer 2-4 applies are cheap,
+# the expensive BatchNorm passes are layer 1's (64 channels at 49 x 49), whose convolutions this kernel does not serve.
+FUSE_APPLY = [os.environ.get("IIC_FUSE_APPLY", "0") == "1"]
+
+
+def apply_supported(gf, w_t):
+  """Can this forward conv AND its weight gradient take their input as (raw tensor, BatchNorm coefficients)?"""
+  if not (FUSE_APPLY[0] and PT_DTYPE[0] is BF16 and isinstance(w_t, WOperand) and USE_FRAG[0]):
+    return False
+  ok = getattr(gf, "_apply_ok", None)
+  if ok is None:
+    ok = bool(lib().iic_conv_igemm_apply_supported(ctypes.byref(gf))) and \
+        bool(lib().iic_conv_wgrad_apply_supported(ctypes.byref(gf)))
+    gf._apply_ok = ok
+  return ok
+
+
+def conv_igemm_apply(g, y_pt, coef, pad, w_t, out_pt, stats=None):
+  """out = conv(relu(coef[0] * y + coef[1])) on the interior of y (border of width `pad` stays zero)."""
+  check(lib().iic_conv_igemm_frag_apply(ctypes.byref(g), ptr(y_pt), ptr(coef), pad, ptr(w_t.pw.frag(w_t.bwd)),
+                                        ptr(out_pt), ptr(stats), stream_ptr()), "iic_conv_igemm_frag_apply")
+  return out_pt
+
+
+def conv_wgrad(g, x_pt, dy_pt, wtaps, use_tr=True, out=None, accumulate=False, nsplit=None, x_coef=None, x_pad=1):
   """Returns dW fp32 [Co][Ci][kh][kw] flattened as [Co, Ci, wtaps].  nsplit: override of the
-  split-K factor (tests: few splits = many K-tiles per workgroup)."""
+  split-K factor (tests: few splits = many K-tiles per workgroup).  x_coef: the X operand is
+  relu(x_coef[0] * x + x_coef[1]) of the raw tensor x (iic_conv_wgrad_apply)."""
   if x_pt.dtype == F32:
     if out is None:
       out = torch.empty((g.Cout, g.Cin, wtaps), dtype=F32, device=x_pt.device)
@@ -627,8 +655,12 @@ def conv_wgrad(g, x_pt, dy_pt, wtaps, use_tr=True, out=None, accumulate=False, n
   if part is None or part.numel() < need:
     part = torch.empty(max(need, 1 << 22), dtype=F32, device=x_pt.device)
     _WG_PART[key] = part
-  check(lib().iic_conv_wgrad(ctypes.byref(g), ptr(x_pt), ptr(dy_pt), ptr(part), ns,
-                             1 if use_tr else 0, stream_ptr()), "iic_conv_wgrad")
+  if x_coef is not None:
+    check(lib().iic_conv_wgrad_apply(ctypes.byref(g), ptr(x_pt), ptr(x_coef), x_pad, ptr(dy_pt), ptr(part), ns,
+                                     stream_ptr()), "iic_conv_wgrad_apply")
+  else:
+    check(lib().iic_conv_wgrad(ctypes.byref(g), ptr(x_pt), ptr(dy_pt), ptr(part), ns,
+                               1 if use_tr else 0, stream_ptr()), "iic_conv_wgrad")
   if out is None:
     out = torch.empty((g.Cout, g.Cin, wtaps), dtype=F32, device=x_pt.device)
   assert g.ntaps == wtaps, "wgrad geometry must list every weight tap once"

@@ -185,6 +185,21 @@ int iic_conv_igemm_frag_red(const iic_conv_geom* g, const void* in, const void* 
                             float* red_stats, float* red_stats2, void* stream);
 int iic_weight_prep_frag(const float* w_oihw, void* w_frag, int Cout, int Cin, int T, int bwd,
                          void* stream);
+/* conv( relu(BatchNorm(in)) ) without the activation tensor (round 4): residual.py:19-23 runs conv1 -> bn1 -> relu ->
+ * conv2; bn1's normalisation + ReLU used to be a separate HBM pass (iic_bn_apply: read the raw conv1 output, write the
+ * activation) whose only consumers are conv2's forward and conv2's weight gradient.  These two entry points take the
+ * RAW tensor and bn1's forward coefficients instead (coef: [0] = scale, [1] = shift, each [Cin] -- the first two rows
+ * of iic_bn_finalize's output) and apply relu(scale * x + shift) to the staged patch in LDS, with the tensor's zero
+ * border of width in_pad kept zero: the same arithmetic as iic_bn_apply, so outputs are bit-identical to the
+ * two-step path.  Forward geometries of the persistent kernel only (csrc/conv_igemm_pw.hip); stats as
+ * iic_conv_igemm.                                                                                              */
+int iic_conv_igemm_apply_supported(const iic_conv_geom* g);
+int iic_conv_igemm_frag_apply(const iic_conv_geom* g, const void* in, const float* in_coef, int in_pad,
+                              const void* w_frag, void* out, float* stats, void* stream);
+/* bwd-weight of such a convolution: partial[s][t][co][ci] as iic_conv_wgrad, with x = relu(scale * x_raw + shift). */
+int iic_conv_wgrad_apply_supported(const iic_conv_geom* g);
+int iic_conv_wgrad_apply(const iic_conv_geom* g, const void* x_raw, const float* x_coef, int x_pad, const void* dy,
+                         float* partials, int nsplit, void* stream);
 /* Every weight operand of a network in ONE launch (what the per-parameter calls above do once per conv and
  * layout after each optimiser step): `jobs_dev` = njobs records in DEVICE memory, sorted by first_block
  * (job i owns blocks [first_block, first_block + iic_weight_prep_multi_blocks(Cout, Cin, T))),

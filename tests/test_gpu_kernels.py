@@ -1050,3 +1050,55 @@ def test_fused_bn_backward_reduction_in_conv_epilogue(cin, cout, H, N, has2, mas
     scale = float(ref.abs().max())
     assert float((f - ref).abs().max()) <= 2e-5 * scale + 1e-6, float((f - ref).abs().max()) / scale
     assert float((f - s_).abs().max()) <= 2e-5 * scale + 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,H,N", [(128, 128, 25, 40), (256, 256, 13, 96), (512, 512, 7, 300), (128, 256, 12, 33)])
+def test_conv_with_fused_batchnorm_relu_input_is_bit_identical(cin, cout, H, N):
+  """include/iic_hip.h iic_conv_igemm_frag_apply / iic_conv_wgrad_apply (residual.py:19-23: conv1 -> bn1 -> relu -> conv2
+  without the activation tensor): forward output, BatchNorm statistics and weight gradient must equal, bit for bit, what
+  the two-step path gives (iic_bn_apply writes relu(scale * y + shift), then the plain convolution / weight gradient) --
+  including the zero border of the activation (relu(shift) there would be wrong) and a ragged last tile."""
+  from iic_amd import geom, ops
+  dev = torch.device("cuda:0")
+  torch.manual_seed(cin + H)
+  spec = geom.ConvSpec(cin, cout, 3, 1, 1)
+  gf = geom.fwd_geom(spec, N, H, H, 1, 1)
+  pw = ops.PreppedWeights(torch.randn(cout, cin, 3, 3, device=dev) * 0.05)
+  prev = ops.FUSE_APPLY[0]
+  ops.FUSE_APPLY[0] = True          # (off by default: see iic_amd/ops.py)
+  try:
+    ok = ops.apply_supported(gf, pw[0])
+  finally:
+    ops.FUSE_APPLY[0] = prev
+  if not ok:
+    pytest.skip("geometry not taken by the fused-input kernels")
+  y = torch.zeros(N, H + 2, H + 2, cin, device=dev, dtype=torch.bfloat16)
+  y[:, 1:-1, 1:-1] = torch.randn(N, H, H, cin, device=dev).to(torch.bfloat16)
+  coef = torch.zeros(5, cin, device=dev)
+  coef[0] = torch.rand(cin, device=dev) * 1.5 + 0.25
+  coef[1] = torch.randn(cin, device=dev) * 0.7            # positive shifts: relu(shift) != 0 on the border
+  dy = torch.zeros(N, H + 2, H + 2, cout, device=dev, dtype=torch.bfloat16)
+  dy[:, 1:-1, 1:-1] = torch.randn(N, H, H, cout, device=dev).to(torch.bfloat16)
+  # two-step reference
+  a = torch.zeros_like(y)
+  ops.bn_apply(y, coef, a, N, H, H, 1, cin, relu=True)
+  assert float(a[:, 0].abs().max()) == 0.0 and float(a[:, :, 0].abs().max()) == 0.0
+  o_ref = torch.zeros(N, H + 2, H + 2, cout, device=dev, dtype=torch.bfloat16)
+  st_ref = ops.new_stats(cout, dev)
+  ops.conv_igemm(gf, a, pw[0], o_ref, stats=st_ref)
+  dw_ref = ops.conv_wgrad(gf, a, dy, 9, True)
+  # fused
+  o = torch.zeros_like(o_ref)
+  st = ops.new_stats(cout, dev)
+  ops.conv_igemm_apply(gf, y, coef, 1, pw[0], o, stats=st)
+  dw = ops.conv_wgrad(gf, y, dy, 9, True, x_coef=coef, x_pad=1)
+  torch.cuda.synchronize()
+  assert torch.equal(o, o_ref)
+  assert torch.equal(dw, dw_ref)
+  c_ref = ops.bn_finalize(st_ref, torch.ones(cout, device=dev), torch.zeros(cout, device=dev), None, None, None, cout,
+                          N * H * H, True)
+  c = ops.bn_finalize(st, torch.ones(cout, device=dev), torch.zeros(cout, device=dev), None, None, None, cout,
+                      N * H * H, True)
+  torch.cuda.synchronize()
+  assert torch.allclose(c, c_ref, rtol=1e-5, atol=1e-6)
