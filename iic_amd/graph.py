@@ -16,12 +16,31 @@ persistent device tensors that the caller overwrites in place between replays
 keeps its step count on the device (``iic_amd.optim.Adam(capturable=True)``); no host reads
 (``.item()``) inside.  Nothing here is specific to one architecture.
 """
+import gc
+
 import torch
 
 from .archs.cluster import bump_weights_epoch
 
 
+def _no_gc(fn):
+  """Run a capturing constructor with the cyclic garbage collector off: an object it collects while a stream is
+  capturing (a dropped CUDAGraph, a pooled tensor) is freed by a HIP call that is illegal under capture and aborts
+  the process (seen in round 4: `Fatal Python error: Aborted ... Garbage-collecting` inside a capture)."""
+  def wrapped(*a, **k):
+    was = gc.isenabled()
+    gc.disable()
+    try:
+      return fn(*a, **k)
+    finally:
+      if was:
+        gc.enable()
+  wrapped.__doc__ = fn.__doc__
+  return wrapped
+
+
 class CapturedStep(object):
+  @_no_gc
   def __init__(self, fn, warmup=2):
     assert torch.cuda.is_available(), "CapturedStep needs a device"
     self.fn = fn
@@ -150,6 +169,7 @@ class CapturedPairStep(object):
   in order, optimiser step: iic_amd.dist.all_reduce_grad_groups) and `opt_step` is the optimiser step alone.
   `events` (optional list) receives ("bwd", g) / ("reduce", g) / ("opt",) in host issue order at replay."""
 
+  @_no_gc
   def __init__(self, view_a, view_b, loss_fn, finish, zero_grad, warmup=2, grad_groups=None, opt_step=None,
                events=None, force_staged=False):
     from . import dist as idist, ops

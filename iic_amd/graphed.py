@@ -26,8 +26,10 @@ their forward graph (one operand set per branch, ops / archs.cluster._ConvHolder
 
 Switch: ops.GRAPH_FORWARD[0] (env IIC_GRAPH_FORWARD; `python -m iic_amd.run` turns it on).
 """
+import gc
 import os
 import sys
+import weakref
 
 import torch
 
@@ -74,6 +76,10 @@ class _ViewGraph(object):
     # branch (one-stream runs) therefore get a namespace of their own.
     prev_branch = ops.BRANCH[0]
     ops.BRANCH[0] = res_branch
+    # no cyclic garbage collection while a stream is capturing: a collected tensor / graph would be freed by a HIP call
+    # that is illegal under capture (torch.cuda.graph collects once on entry, but a capture allocates plenty itself)
+    gc_was = gc.isenabled()
+    gc.disable()
     try:
       with torch.cuda.graph(self.g_f, pool=pool, stream=self.cap, capture_error_mode=mode):
         with torch.enable_grad():
@@ -81,21 +87,30 @@ class _ViewGraph(object):
     finally:
       ops._CAPTURE_PROXIES[0] = None
       ops.BRANCH[0] = prev_branch
+      if gc_was:
+        gc.enable()
     self.outs, self.out_type = _flat(out)
     # running-statistic updates this forward postponed to the join (branch mode): the same (static) tensors
     # at every replay
     self.deferred = list(ops._DEFERRED_RUNNING[n_def:])
     self.gouts = [torch.zeros_like(o) for o in self.outs]
     self.g_b = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(self.g_b, pool=pool, stream=self.cap, capture_error_mode=mode):
-      grads = torch.autograd.grad(self.outs, self.leaves, self.gouts, allow_unused=True)
+    gc.disable()
+    try:
+      with torch.cuda.graph(self.g_b, pool=pool, stream=self.cap, capture_error_mode=mode):
+        grads = torch.autograd.grad(self.outs, self.leaves, self.gouts, allow_unused=True)
+    finally:
+      if gc_was:
+        gc.enable()
     self.grads = list(grads)
     cur.wait_stream(self.cap)
     self.static_outs = [o.detach() for o in self.outs]
     self.first = True
     self.sig = _storage_sig(mod)
     self.bwd_event = None        # recorded after every backward replay (consumers of the static gradients wait on it)
-    self.family = {}             # the module's {key: _ViewGraph} (set by forward())
+    # (a weak reference: vg -> module state -> vg would be a cycle, and a captured graph that only the cyclic garbage
+    #  collector frees can be destroyed in the middle of ANOTHER capture -- hipGraphDestroy under capture aborts)
+    self.mod_ref = weakref.ref(mod)
 
 
 def _storage_sig(mod):
@@ -151,7 +166,8 @@ class _GraphedFn(torch.autograd.Function):
       # the .grad buffers being added to were written by ANOTHER view's backward graph, possibly on another stream
       # (auto_branch): autograd's AccumulateGrad would have synchronised with it, so must this
       cur = torch.cuda.current_stream()
-      for other in vg.family.values():
+      mod = vg.mod_ref()
+      for other in (_state(mod)["graphs"].values() if mod is not None else ()):
         if other is not vg and other is not _FAILED and other.bwd_event is not None:
           cur.wait_event(other.bwd_event)
       torch._foreach_add_(tgt, src)
@@ -241,7 +257,6 @@ def forward(fwd, mod, x, args, kwargs):
       st["epoch"] = _epoch(mod)
       return eager()
     st["graphs"][key] = vg
-    vg.family = st["graphs"]
     if os.environ.get("IIC_GRAPH_LOG"):
       sys.stderr.write("[iic_amd.graphed] captured forward + backward graphs for %r\n" % (key,))
     # the capture bumped the weights epoch (so that the re-layout kernels are part of the graph); this
