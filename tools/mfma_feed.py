@@ -33,6 +33,8 @@ def main():
   ap.add_argument("--npix", type=int, default=330)
   ap.add_argument("--vars", type=str, default="0", help="comma list of probe variants (VAR bits of probe_mfma_feed.hip): "
                   "1 B loads L1-hot, 2 setprio around the MFMAs, 4 interleaved issue order, 6 = 2+4, 8 B ring 16 deep")
+  ap.add_argument("--hold", type=str, default="", help="stage,variant,shape index,seconds: run that one launch back to back "
+                  "for the given time (tools/power_probe_feed.sh samples rocm-smi meanwhile)")
   a = ap.parse_args()
   dev = torch.device("cuda:0")
   L = ctypes.CDLL(os.path.join(os.path.dirname(_lib.LIB_PATH), "libiic_probe.so"))   # make -C iic_amd/csrc probes
@@ -46,6 +48,28 @@ def main():
   patch = torch.randn((gmax * 256 + 1024) * 256, device=dev).to(torch.bfloat16)
   out = torch.empty(gmax * 256 * 128, device=dev, dtype=torch.bfloat16)
   clk = torch.zeros(gmax * 4, device=dev, dtype=torch.int64)
+  if a.hold:
+    import time
+    stage, var, si, secs = a.hold.split(",")
+    stage, var, si, secs = int(stage), int(var), int(si), float(secs)
+    name, nit, cits, grid = SHAPES[si]
+    t_end = time.time() + secs
+    n = 0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    while time.time() < t_end:
+      for _ in range(50):
+        rc = fn(stage | (var << 4), grid, nit, cits, a.npix, 80 * 1024, wfrag.data_ptr(), wbytes, patch.data_ptr(), out.data_ptr(),
+                None, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, rc
+      n += 50
+      torch.cuda.synchronize()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / n
+    flops = grid * 4.0 * nit * 4 * 8 * FLOP_PER_MFMA
+    print("hold: stage %d variant %d %s: %.1f us per launch, %.0f TF/s over %.1f s" % (stage, var, name, us, flops / us / 1e6, secs))
+    return
   print("stages: 0 MFMA only | 1 +A LDS reads | 2 +B global ring | 3 +chunk reloads | 4 +epilogue   (random operands)")
   variants = [int(v) for v in a.vars.split(",")]
   for var, (occ_name, lds) in [(v, o) for v in variants for o in (("2 workgroups/CU (2 waves/SIMD)", 80 * 1024),
