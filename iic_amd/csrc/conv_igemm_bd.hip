@@ -745,6 +745,9 @@ int iic_conv_igemm_frag_red(const iic_conv_geom* g, const void* in, const void* 
   } while (0)
   if (g->ntaps == 1) BD_LAUNCH(true, 0);
   else switch (iic_debug_get_ablate()) {
+#ifdef IIC_BD_ABLATIONS
+    // timing-ablation and phase-stamp instantiations (tools/conv_perf.py --frag-ablate, tools/bd_timeline.py): NOT in the
+    // product library -- `make -C iic_amd/csrc ABL=1` builds them in (13 more instantiations of the kernel)
     case 1: BD_LAUNCH(false, 1); break;
     case 2: BD_LAUNCH(false, 2); break;
     case 3: BD_LAUNCH(false, 3); break;
@@ -758,6 +761,7 @@ int iic_conv_igemm_frag_red(const iic_conv_geom* g, const void* in, const void* 
     case 96: BD_LAUNCH(false, 96); break;
     case 128: BD_LAUNCH(false, 128); break;
     case 256: BD_LAUNCH(false, 256); break;
+#endif
     default: BD_LAUNCH(false, 0); break;
   }
   return iic_launch_status();

@@ -420,12 +420,15 @@ int iic_p64_launch(const iic_conv_geom* g, const void* in, const void* wfrag, vo
   if (red == 1) { P64_LAUNCH2(0, 1); return iic_launch_status(); }
   if (red == 2) { P64_LAUNCH2(0, 2); return iic_launch_status(); }
   switch (iic_debug_get_ablate()) {
+#ifdef IIC_BD_ABLATIONS
+    // timing-ablation / phase-profile instantiations (tools/p64_phases.py): `make -C iic_amd/csrc ABL=1` only
     case 1: P64_LAUNCH(1); break;
     case 2: P64_LAUNCH(2); break;
     case 3: P64_LAUNCH(3); break;
     case 4: P64_LAUNCH(4); break;
     case 7: P64_LAUNCH(7); break;
     case 8: P64_LAUNCH(8); break;
+#endif
     default: P64_LAUNCH(0); break;
   }
   return iic_launch_status();

@@ -1,4 +1,5 @@
-"""Per-tile phase timeline of conv_igemm_bd_kernel (the instruction-level substitute for a rocprofv3 ATT
+"""(needs the ablation build of the library: make -C iic_amd/csrc clean && make -C iic_amd/csrc ABL=1)
+Per-tile phase timeline of conv_igemm_bd_kernel (the instruction-level substitute for a rocprofv3 ATT
 thread trace: the ATT decoder library is not part of this image).  The kernel's PROF build
 (iic_debug_set_ablate(128), results unchanged) lets wave 0 of every workgroup stamp s_memtime at its
 phase boundaries; this tool launches one layer, decodes the stamps and prints where a tile's cycles go,

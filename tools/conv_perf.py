@@ -1,4 +1,5 @@
-"""Per-layer timing of the conv kernels at the north-star shapes (660 images per pass).
+"""(needs the ablation build of the library: make -C iic_amd/csrc clean && make -C iic_amd/csrc ABL=1)
+Per-layer timing of the conv kernels at the north-star shapes (660 images per pass).
 python tools/conv_perf.py [--n 660] [--iters 20] -> table of us and TFLOP/s per geometry."""
 import argparse
 import sys, os

@@ -1,4 +1,5 @@
-"""Where a tile's cycles go in the persistent 64 -> 64 convolution (conv_igemm_p64_kernel, ResNet layer1 of
+"""(needs the ablation build of the library: make -C iic_amd/csrc clean && make -C iic_amd/csrc ABL=1)
+Where a tile's cycles go in the persistent 64 -> 64 convolution (conv_igemm_p64_kernel, ResNet layer1 of
 ClusterNet5g): the kernel's PROF build (iic_debug_set_ablate(8), results unchanged) sums, per workgroup, the
 s_memtime cycles of each phase of its tile loop.
 
