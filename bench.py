@@ -742,7 +742,9 @@ def main():
   if use_branch:
     from iic_amd.graph import CapturedPairStep
     try:
-      staged = world > 1 and os.environ.get("IIC_DIST_STAGED", "1") != "0"
+      side_wgrad = os.environ.get("IIC_WGRAD_SIDE", "0") == "1"
+      force_staged = side_wgrad or os.environ.get("IIC_FORCE_STAGED", "0") == "1"
+      staged = (world > 1 and os.environ.get("IIC_DIST_STAGED", "1") != "0") or force_staged
       if staged:
         # backward captured per layer group: a group's gradient bucket is all-reduced (third stream, async)
         # while the groups below it still run backward
@@ -750,7 +752,7 @@ def main():
                                lambda: net.forward_packed_taps(sobel_process(imgs_tf, False)),
                                loss_fn, finish, lambda: net.zero_grad(set_to_none=True),
                                warmup=max(1, args.warmup), grad_groups=groups, opt_step=opt.step,
-                               events=replay_events)
+                               events=replay_events, force_staged=force_staged, side_wgrad=side_wgrad)
         nseg = 2 + 3 * len(groups) + len(run.g_l.items) - run.g_l.cuts + len(run.g_opt.items) - run.g_opt.cuts
         ncoll = run.g_l.cuts + run.g_opt.cuts + len(groups)
         launch_mode = ("hip-graph replay: %d linear graph segments, the two views on two streams, backward staged "

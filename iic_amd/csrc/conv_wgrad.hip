@@ -344,12 +344,20 @@ extern "C" {
 
 static int wgrad_cot(const iic_conv_geom* g) { return (g->Cout % 128 == 0) ? 128 : 64; }
 
+// Workgroups a weight-gradient launch aims for (tiles x K-splits); a 12-wave workgroup fills a CU.  256 (one per CU, rounds
+// 1-3) means every CU has to take one, and in the two-stream step a CU whose LDS the other view's kernel holds delays the
+// launch's last workgroup; 224 also writes 1/8 less split-K partial traffic.  Measured on three boxes, default step,
+// interleaved (tools/ab_env.sh, profiles/r04_wgrad_target_wgs.txt): 224 / 192 / 128 are 0.2-0.35 ms per step faster than 256,
+// 160 and 96 slower (K-tile quantisation), 64 much slower.
+static int g_wgrad_target_wgs = 224;
+void iic_debug_wgrad_target_wgs(int v) { g_wgrad_target_wgs = v > 0 ? v : 224; }
+
 int iic_conv_wgrad_nsplit(const iic_conv_geom* g) {
   const long M = igemm_rows_host(g);
   const int kt = (int)((M + BM - 1) / BM);
   const int batches = g->ntaps == 1 ? 1 : (g->ntaps + NTG * TPG - 1) / (NTG * TPG);
   const int tiles = (g->Cout / wgrad_cot(g)) * (g->Cin / 64) * batches;
-  int ns = 256 / (tiles > 0 ? tiles : 1);   // one workgroup (12 waves) per CU
+  int ns = g_wgrad_target_wgs / (tiles > 0 ? tiles : 1);   // default: one workgroup (12 waves) per CU
   if (ns < 1) ns = 1;
   if (ns > kt) ns = kt;
   return ns;

@@ -339,6 +339,8 @@ class PTPool(object):
     self.live = {}            # data_ptr -> serial of the alloc() that handed it out
     self.serial = 0
     self.allocated_bytes = 0
+    self.pinned = set()       # data_ptr of buffers a deferred launch still reads (deferring_wgrads)
+    self.held = []            # pinned buffers whose release was requested meanwhile
 
   def alloc(self, shape, device, P=1):
     dt = PT_DTYPE[0]
@@ -362,10 +364,25 @@ class PTPool(object):
     ent = self.owned.get(t.data_ptr())
     if ent is None or ent[0].shape != t.shape:
       return                  # not one of ours (a user tensor, a view): never recycle it
+    if t.data_ptr() in self.pinned:
+      if t.data_ptr() in self.live and not any(h is ent[0] for h in self.held):
+        self.held.append(ent[0])
+      return                  # a recorded launch on another stream still reads it: unpin_all() releases it
     if self.live.pop(t.data_ptr(), None) is None:
       return                  # already back in the pool
     key = (tuple(t.shape), ent[1], str(t.device), ent[2], t.dtype)
     self.free.setdefault(key, []).append(ent[0])
+
+  def pin(self, t):
+    if t is not None and t.data_ptr() in self.owned:
+      self.pinned.add(t.data_ptr())
+
+  def unpin_all(self):
+    """The streams that ran the recorded launches have been joined: hand back what was released meanwhile."""
+    self.pinned.clear()
+    held, self.held = self.held, []
+    for t in held:
+      self.release(t)
 
   def mark(self):
     return self.serial
@@ -380,6 +397,8 @@ class PTPool(object):
     self.free.clear()
     self.owned.clear()
     self.live.clear()
+    self.pinned.clear()
+    del self.held[:]
 
 
 POOL = PTPool()
@@ -572,8 +591,42 @@ def red_supported(g, w_t):
   return ok
 
 
+# Round-4 experiment (IIC_MFMA_TOKEN=<timeout us>, needs `make probes`): a device-side lock around every matrix-bound
+# launch, so that the two views' streams never run two of them at once (csrc/probes/stream_util.hip).  Measured result:
+# DESIGN.md section 7.
+MFMA_TOKEN = [int(os.environ.get("IIC_MFMA_TOKEN", "0") or 0)]
+_TOKEN_LIB = [None]
+
+
+def _token_lib():
+  if _TOKEN_LIB[0] is None:
+    L = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libiic_probe.so"))
+    L.iic_debug_token_acquire.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.iic_debug_token_release.argtypes = [ctypes.c_void_p]
+    assert L.iic_debug_token_init() == 1
+    _TOKEN_LIB[0] = L
+  return _TOKEN_LIB[0]
+
+
+class _mfma_token(object):
+  def __enter__(self):
+    if MFMA_TOKEN[0] > 0:
+      check(_token_lib().iic_debug_token_acquire(stream_ptr(), MFMA_TOKEN[0]), "token acquire")
+
+  def __exit__(self, *exc):
+    if MFMA_TOKEN[0] > 0:
+      check(_token_lib().iic_debug_token_release(stream_ptr()), "token release")
+    return False
+
+
 def conv_igemm(g, x_pt, w_t, out_pt, stats=None, res_grad=None, res_act=None, accumulate=False,
                premask=False, red=None):
+  with _mfma_token():
+    return _conv_igemm(g, x_pt, w_t, out_pt, stats, res_grad, res_act, accumulate, premask, red)
+
+
+def _conv_igemm(g, x_pt, w_t, out_pt, stats=None, res_grad=None, res_act=None, accumulate=False,
+                premask=False, red=None):
   """w_t: a row-major bf16 operand tensor (first-generation kernel) or a WOperand handle
   (second-generation weights-direct kernel wherever the geometry supports it).
   premask: out = (value [+ previous] [+ res_grad]) where res_act > 0 else 0 (IIC_ACC_PREMASK).
@@ -638,6 +691,54 @@ def conv_igemm_apply(g, y_pt, coef, pad, w_t, out_pt, stats=None):
   return out_pt
 
 
+# Deferred weight gradients (iic_amd.graph.CapturedPairStep, side_wgrad): a weight gradient depends on its layer's
+# (input, output gradient) pair and on nothing downstream, while the data-gradient / BatchNorm chain of the backward
+# pass is strictly serial and alternates matrix-bound and HBM-bound kernels.  While `deferring_wgrads()` is active,
+# conv_wgrad only RECORDS its launch (and hands back the still unwritten gradient tensor); the caller runs the recorded
+# launches later on another stream (run_deferred_wgrads) so that they fill the chain's HBM-bound phases.  The PT buffers
+# a recorded launch reads are pinned: PTPool.release() keeps them out of circulation until unpin_all().
+_WGRAD_DEFER = [None]
+
+
+class deferring_wgrads(object):
+  def __init__(self):
+    self.items = []
+
+  def __enter__(self):
+    assert _WGRAD_DEFER[0] is None, "deferring_wgrads does not nest"
+    _WGRAD_DEFER[0] = self.items
+    return self
+
+  def __exit__(self, *exc):
+    _WGRAD_DEFER[0] = None
+    return False
+
+
+def run_deferred_wgrads(items, branch):
+  """Enqueue the recorded weight-gradient launches (and their split-K reduces) on the current stream, with the
+  split-K scratch of (branch, "side") -- the recording stream may be running its own weight gradients meanwhile."""
+  for (g, x_pt, dy_pt, wtaps, use_tr, out, accumulate, ns, x_coef, x_pad) in items:
+    _conv_wgrad_launch(g, x_pt, dy_pt, wtaps, use_tr, out, accumulate, ns, x_coef, x_pad, (str(x_pt.device), branch, "side"))
+  del items[:]
+
+
+def _conv_wgrad_launch(g, x_pt, dy_pt, wtaps, use_tr, out, accumulate, ns, x_coef, x_pad, key):
+  need = ns * g.ntaps * g.Cout * g.Cin
+  part = _WG_PART.get(key)
+  if part is None or part.numel() < need:
+    part = torch.empty(max(need, 1 << 22), dtype=F32, device=x_pt.device)
+    _WG_PART[key] = part
+  with _mfma_token():
+    if x_coef is not None:
+      check(lib().iic_conv_wgrad_apply(ctypes.byref(g), ptr(x_pt), ptr(x_coef), x_pad, ptr(dy_pt), ptr(part), ns,
+                                       stream_ptr()), "iic_conv_wgrad_apply")
+    else:
+      check(lib().iic_conv_wgrad(ctypes.byref(g), ptr(x_pt), ptr(dy_pt), ptr(part), ns,
+                                 1 if use_tr else 0, stream_ptr()), "iic_conv_wgrad")
+  check(lib().iic_conv_wgrad_reduce(ptr(part), ns, wtaps, g.Cout, g.Cin, ptr(out),
+                                    1 if accumulate else 0, stream_ptr()), "iic_conv_wgrad_reduce")
+
+
 def conv_wgrad(g, x_pt, dy_pt, wtaps, use_tr=True, out=None, accumulate=False, nsplit=None, x_coef=None, x_pad=1):
   """Returns dW fp32 [Co][Ci][kh][kw] flattened as [Co, Ci, wtaps].  nsplit: override of the
   split-K factor (tests: few splits = many K-tiles per workgroup).  x_coef: the X operand is
@@ -649,23 +750,16 @@ def conv_wgrad(g, x_pt, dy_pt, wtaps, use_tr=True, out=None, accumulate=False, n
                               stream_ptr()), "iic_f32_wgrad")
     return out
   ns = int(nsplit) if nsplit else lib().iic_conv_wgrad_nsplit(ctypes.byref(g))
-  need = ns * g.ntaps * g.Cout * g.Cin
-  key = (str(x_pt.device), BRANCH[0])
-  part = _WG_PART.get(key)
-  if part is None or part.numel() < need:
-    part = torch.empty(max(need, 1 << 22), dtype=F32, device=x_pt.device)
-    _WG_PART[key] = part
-  if x_coef is not None:
-    check(lib().iic_conv_wgrad_apply(ctypes.byref(g), ptr(x_pt), ptr(x_coef), x_pad, ptr(dy_pt), ptr(part), ns,
-                                     stream_ptr()), "iic_conv_wgrad_apply")
-  else:
-    check(lib().iic_conv_wgrad(ctypes.byref(g), ptr(x_pt), ptr(dy_pt), ptr(part), ns,
-                               1 if use_tr else 0, stream_ptr()), "iic_conv_wgrad")
   if out is None:
     out = torch.empty((g.Cout, g.Cin, wtaps), dtype=F32, device=x_pt.device)
   assert g.ntaps == wtaps, "wgrad geometry must list every weight tap once"
-  check(lib().iic_conv_wgrad_reduce(ptr(part), ns, wtaps, g.Cout, g.Cin, ptr(out),
-                                    1 if accumulate else 0, stream_ptr()), "iic_conv_wgrad_reduce")
+  pending = _WGRAD_DEFER[0]
+  if pending is not None:
+    POOL.pin(x_pt)
+    POOL.pin(dy_pt)
+    pending.append((g, x_pt, dy_pt, wtaps, use_tr, out, accumulate, ns, x_coef, x_pad))
+    return out
+  _conv_wgrad_launch(g, x_pt, dy_pt, wtaps, use_tr, out, accumulate, ns, x_coef, x_pad, (str(x_pt.device), BRANCH[0]))
   return out
 
 

@@ -139,13 +139,16 @@ def test_captured_and_branched_steps_track_the_eager_step(mode):
     assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("mode", ["pair", "staged"])
+@pytest.mark.parametrize("mode", ["pair", "staged", "staged-side"])
 def test_two_stream_graph_modes_with_k_split_head_gemm_are_bit_identical_to_eager(mode):
   """Batch large enough (96 x 512 features) for the heads' backward GEMM to take the LDS-tiled kernel with
   its K split over a workspace: the workspace is per branch, so the two views' backward graphs -- replayed
   concurrently on two streams -- must not share it (a shared one made view A's gradients differ from
   replay to replay).  `staged`: the backward captured per layer group (the data-parallel replay order,
-  forced here without a process group).  Six steps enqueued back to back, no host synchronisation."""
+  forced here without a process group); `staged-side`: in addition every group's weight gradients are captured as
+  graphs of their own and replayed on per-view side streams beside the next group's data-gradient / BatchNorm chain
+  (CapturedPairStep side_wgrad: recorded launches, pinned PT buffers).  Six steps enqueued back to back, no host
+  synchronisation."""
   from iic_amd.graph import CapturedPairStep
   from iic_amd.losses import IID_loss_heads
   from iic_amd.optim import Adam
@@ -168,12 +171,17 @@ def test_two_stream_graph_modes_with_k_split_head_gemm_are_bit_identical_to_eage
       run = CapturedPairStep(lambda: net.forward_packed_taps(sobel_process(imgs, False)),
                              lambda: net.forward_packed_taps(sobel_process(imgs_tf, False)),
                              loss_fn, opt.step, lambda: net.zero_grad(set_to_none=True), warmup=2,
-                             grad_groups=net.grad_groups(), opt_step=opt.step, events=events, force_staged=True)
+                             grad_groups=net.grad_groups(), opt_step=opt.step, events=events, force_staged=True,
+                             side_wgrad=mode == "staged-side")
       assert run.staged and len(run.g_ba) == 4 and len(run.buckets) == 4
+      if mode == "staged-side":
+        assert len(run.g_w[0]) == 4 and len(run.g_w[1]) == 4
+        from iic_amd import ops
+        assert not ops.POOL.pinned and not ops.POOL.held
     losses = [run().clone() for _ in range(6)]       # (a replay returns the same static tensor every time)
     torch.cuda.synchronize()
     runs[name] = ([float(l) for l in losses], [p.detach().clone() for p in net.parameters()])
-    if name == "staged":
+    if name.startswith("staged"):
       assert events[:9] == [("bwd", 0), ("reduce", 0), ("bwd", 1), ("reduce", 1), ("bwd", 2), ("reduce", 2),
                             ("bwd", 3), ("reduce", 3), ("opt",)]
       # .grad of every parameter is a view into its group's flat bucket
