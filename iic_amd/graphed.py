@@ -122,6 +122,26 @@ def _storage_sig(mod):
   return tuple(p.data_ptr() for p in mod.parameters()) + tuple(b.data_ptr() for b in mod.buffers())
 
 
+_SIG_FULL_EVERY = 256
+
+
+def _sig_changed(mod, st, vg):
+  """vg.sig != _storage_sig(mod), without walking the module tree at every forward (0.65 ms of host time per call for
+  ClusterNet5g -- time by which the second view's forward graph starts after the first's): the Parameter / buffer
+  OBJECTS are listed once per module state and only their addresses are compared; every _SIG_FULL_EVERY-th call the
+  tree is walked again, which also catches a Parameter object that was replaced rather than moved."""
+  ts = st.get("sig_tensors")
+  n = st["sig_calls"] = st.get("sig_calls", 0) + 1
+  if ts is None or n % _SIG_FULL_EVERY == 0:
+    ts = st["sig_tensors"] = list(mod.parameters()) + list(mod.buffers())
+  if len(ts) != len(vg.sig):
+    return True
+  for t, a in zip(ts, vg.sig):
+    if t.data_ptr() != a:
+      return True
+  return False
+
+
 class _GraphedFn(torch.autograd.Function):
   @staticmethod
   def forward(ctx, vg, x, *params):
@@ -131,6 +151,8 @@ class _GraphedFn(torch.autograd.Function):
       ops._DEFERRED_RUNNING.extend(vg.deferred)
     vg.first = False
     ctx.vg = vg
+    # the stream the script itself is on (inside ops.branch: the stream that forked): its optimiser will read the gradients
+    ctx.caller_stream = ops._BRANCH_MAIN[0] or torch.cuda.current_stream()
     return tuple(o.detach() for o in vg.static_outs)       # fresh tensor objects over the static storage
 
   @staticmethod
@@ -154,23 +176,40 @@ class _GraphedFn(torch.autograd.Function):
     # set, by AccumulateGrad nodes that ran on this same engine thread) would cost one `add_` launch per
     # parameter there -- 118 for ClusterNet5g, 0.6 ms per step: one multi-tensor add instead, and nothing is
     # returned for those parameters.
+    # The FIRST view to arrive (.grad still None) used to hand autograd aliases of its static gradient buffers; the 118
+    # AccumulateGrad nodes then run one by one on the engine thread -- each with an event record + stream wait, because
+    # the parameters' accumulators live on the stream the script's warm-up ran on and this view's graph on another --
+    # BEFORE the engine reaches the other view's node: ~1.5 ms by which the second backward graph started late
+    # (tools/graphed_perf.py --profile).  The aliases are now installed as .grad right here (parameters with hooks keep
+    # the autograd route).
     tgt, src, ret = [], [], []
     for p, g in zip(vg.params, vg.grads):
       if g is not None and p.grad is not None and FUSED_ACCUMULATE[0] and p.grad.dtype == g.dtype:
         tgt.append(p.grad)
         src.append(g)
         ret.append(None)
+      elif (g is not None and p.grad is None and FUSED_ACCUMULATE[0] and not p._backward_hooks
+            and not getattr(p, "_post_accumulate_grad_hooks", None)):
+        p.grad = g.detach()
+        ret.append(None)
       else:
         ret.append(None if g is None else g.detach())
+    cur = torch.cuda.current_stream()
     if tgt:
       # the .grad buffers being added to were written by ANOTHER view's backward graph, possibly on another stream
       # (auto_branch): autograd's AccumulateGrad would have synchronised with it, so must this
-      cur = torch.cuda.current_stream()
       mod = vg.mod_ref()
       for other in (_state(mod)["graphs"].values() if mod is not None else ()):
         if other is not vg and other is not _FAILED and other.bwd_event is not None:
           cur.wait_event(other.bwd_event)
       torch._foreach_add_(tgt, src)
+    # Whoever reads .grad next -- the script's optimiser, on the stream the script is on -- must come after this view's
+    # graph and fold.  The engine only orders the caller's stream after LEAF streams (AccumulateGrad nodes), and none of
+    # the gradients above went through one: without this wait the optimiser raced the side-stream view's backward as soon
+    # as the host got ahead of the GPU (found in round 4 by test_graphed_two_streams_are_ordered_before_the_optimiser...:
+    # wrong losses from the seventh step on).
+    if ctx.caller_stream != cur:
+      ctx.caller_stream.wait_event(cur.record_event())
     return (None, None) + tuple(ret)
 
 
@@ -196,29 +235,68 @@ def _epoch(mod):
   return (_cl._WEIGHTS_EPOCH[0], None if p is None else p._version)
 
 
-def forward(fwd, mod, x, args, kwargs):
-  """Called by ops.auto_branch's wrapper for an eligible training forward (inside the branch context when
-  there is one).  Returns the forward's result, from a replayed graph when this key has been captured."""
+class _Plan(object):
+  __slots__ = ("st", "key", "res", "vg", "mode")
+
+
+def plan(mod, x, kwargs, branch):
+  """What an eligible training forward that is about to run as branch `branch` will do: "replay" a captured graph,
+  "capture" one, or run "eager" (a warm-up occurrence, a shape whose capture failed).  Called by ops.auto_branch BEFORE
+  it enters the branch, because the two cases want different parameter handling there: a replayed / captured view
+  accumulates its gradients itself (_GraphedFn.backward), an eager side-stream view must see the parameters through
+  leaf aliases (see ops.auto_branch).  Advances the step position."""
   st = _state(mod)
   ep = _epoch(mod)
   if st["epoch"] != ep:                      # the optimiser stepped: a new step begins
     st["epoch"], st["pos"] = ep, 0
   pos = st["pos"]
   st["pos"] += 1
-  key = (tuple(x.shape), x.dtype, x.device.index, kwargs.get("head"), pos, ops.BRANCH[0])
+  key = (tuple(x.shape), x.dtype, x.device.index, kwargs.get("head"), pos, branch)
   # resource namespace of this position (see _ViewGraph): its real branch, unless an earlier position of the
   # step lives there already (one-stream runs) -- the eager warm-up occurrences use the same namespace, so
   # that its PT buffers exist (zero-filled ONCE) before the capture; a buffer first allocated inside a
   # capture would be zero-filled by every replay (measured: 1.2 ms per step for one view's activations)
   res = st["res"].get(key)
   if res is None:
-    b = ops.BRANCH[0]
-    clash = any(k[:4] == key[:4] and k[4] < pos and r == b for k, r in st["res"].items())
-    res = st["res"][key] = (100 + pos) if clash else b
+    clash = any(k[:4] == key[:4] and k[4] < pos and r == branch for k, r in st["res"].items())
+    res = st["res"][key] = (100 + pos) if clash else branch
     if clash:
       ops._NO_PROXY_BRANCHES.add(res)        # a namespace, not a stream branch: parameters stay themselves
+  vg = st["graphs"].get(key)
+  if vg is not None and vg is not _FAILED and _sig_changed(mod, st, vg):
+    # the module's storage moved (.cpu() / .cuda() / .to()): every graph of this module is stale
+    if os.environ.get("IIC_GRAPH_LOG"):
+      sys.stderr.write("[iic_amd.graphed] parameters moved: dropped %d captured graphs\n" % len(st["graphs"]))
+    st["graphs"].clear()
+    st["warm"].clear()
+    st.pop("sig_tensors", None)
+    vg = None
+  pl = _Plan()
+  pl.st, pl.key, pl.res, pl.vg = st, key, res, vg
+  if vg is _FAILED:
+    pl.mode = "eager"
+  elif vg is None:
+    n = st["warm"].get(key, 0)
+    if n < WARMUP:
+      st["warm"][key] = n + 1
+      pl.mode = "eager"
+    else:
+      pl.mode = "capture"
+  else:
+    pl.mode = "replay"
+  return pl
+
+
+def forward(fwd, mod, x, args, kwargs, pl=None):
+  """Called by ops.auto_branch's wrapper for an eligible training forward (inside the branch context when
+  there is one).  Returns the forward's result, from a replayed graph when this key has been captured."""
+  if pl is None:
+    pl = plan(mod, x, kwargs, ops.BRANCH[0])
+  st, key, res, vg = pl.st, pl.key, pl.res, pl.vg
 
   def eager():
+    if ops.BRANCH[0] in ops._NO_PROXY_BRANCHES:     # (a failed capture inside a branch that was entered without aliases)
+      ops.use_aliases_in_current_branch()
     if res == ops.BRANCH[0]:
       return fwd(mod, x, *args, **kwargs)
     prev = ops.BRANCH[0]
@@ -227,21 +305,9 @@ def forward(fwd, mod, x, args, kwargs):
       return fwd(mod, x, *args, **kwargs)
     finally:
       ops.BRANCH[0] = prev
-  vg = st["graphs"].get(key)
-  if vg is not None and vg is not _FAILED and vg.sig != _storage_sig(mod):
-    # the module's storage moved (.cpu() / .cuda() / .to()): every graph of this module is stale
-    if os.environ.get("IIC_GRAPH_LOG"):
-      sys.stderr.write("[iic_amd.graphed] parameters moved: dropped %d captured graphs\n" % len(st["graphs"]))
-    st["graphs"].clear()
-    st["warm"].clear()
-    vg = None
-  if vg is _FAILED:
+  if pl.mode == "eager":
     return eager()
-  if vg is None:
-    n = st["warm"].get(key, 0)
-    if n < WARMUP:
-      st["warm"][key] = n + 1
-      return eager()
+  if pl.mode == "capture":
     n_def = len(ops._DEFERRED_RUNNING)
     try:
       vg = _ViewGraph(fwd, mod, x, args, kwargs, res)

@@ -42,6 +42,7 @@ _BRANCH_STREAM = {}
 _PROXIES = {}             # id(param) -> (param, {branch: leaf alias sharing its storage})
 _DEFERRED_RUNNING = []    # (coef, running_mean, running_var, num_batches_tracked, C) of a branch
 _PENDING_JOIN = []        # (main stream, side stream) of branches not joined yet
+_BRANCH_MAIN = [None]     # inside `with branch():` the stream the caller was on (iic_amd.graphed orders it after a view's backward)
 
 
 # IIC_BRANCH_PROXIES=0: side branches use the parameters themselves.  Autograd then accumulates
@@ -51,6 +52,46 @@ USE_PROXIES = [os.environ.get("IIC_BRANCH_PROXIES", "1") != "0"]
 
 
 _NO_PROXY_BRANCHES = set()
+# Branches whose alias gradients are folded into the parameters' .grad by an end-of-backward callback (auto_branch: an
+# UNCHANGED script, any optimiser).  Until round 4 auto_branch ran its side view WITHOUT aliases and let autograd
+# accumulate both views into p.grad across the two streams; with torch 2.10's AccumulateGrad stream handling that is a
+# race as soon as the GPU, not the host, is the bottleneck (300 images of 96 x 96: garbage losses from the third step
+# on, correct under AMD_SERIALIZE_KERNEL=3; found by tools/race_check.py -- the 24-image tests are host-bound and never
+# showed it).  With aliases each view accumulates on its own stream into its own leaves, and ONE multi-tensor add on the
+# caller's stream, after it has waited for the side stream, produces p.grad.
+_AUTO_FOLD = set()
+_FOLD_STATE = {"queued": False, "main": None}
+
+
+def use_aliases_in_current_branch():
+  """(iic_amd.graphed: an eager forward inside a branch that was entered without aliases -- a failed capture)"""
+  b = BRANCH[0]
+  if 0 < b < 100:
+    _NO_PROXY_BRANCHES.discard(b)
+    _AUTO_FOLD.add(b)
+
+
+def _fold_after_backward():
+  """Engine callback, end of the backward pass: the caller's stream waits for the side streams, then
+  p.grad (+)= the alias gradients."""
+  _FOLD_STATE["queued"] = False
+  main = _FOLD_STATE["main"] or torch.cuda.current_stream()
+  with torch.cuda.stream(main):
+    for (_, idx), st in list(_BRANCH_STREAM.items()):
+      if idx in _AUTO_FOLD:
+        main.wait_stream(st)
+    tgt, src = [], []
+    for p, d in list(_PROXIES.values()):
+      for idx, q in d.items():
+        if idx in _AUTO_FOLD and q.grad is not None:
+          if p.grad is None:
+            p.grad = q.grad
+          else:
+            tgt.append(p.grad)
+            src.append(q.grad)
+          q.grad = None
+    if tgt:
+      torch._foreach_add_(tgt, src)
 
 
 _CAPTURE_PROXIES = [None]   # iic_amd.graphed: {id(param): leaf alias} while a view's graphs are captured
@@ -119,14 +160,17 @@ def clear_branch_grads():
 class branch(object):
   """Fork the enclosed forward onto a side stream / graph branch (see above).  Not re-entrant."""
 
-  def __init__(self, index=1, proxies=True):
+  def __init__(self, index=1, proxies=True, auto_fold=False):
     assert index >= 1
     self.index = index
     self.proxies = proxies
+    self.auto_fold = auto_fold and proxies
 
   def __enter__(self):
     assert BRANCH[0] == 0, "branches do not nest"
     (_NO_PROXY_BRANCHES.discard if self.proxies else _NO_PROXY_BRANCHES.add)(self.index)
+    (_AUTO_FOLD.add if self.auto_fold else _AUTO_FOLD.discard)(self.index)
+    _FOLD_STATE["queued"] = False
     dev = torch.cuda.current_device()
     key = (dev, self.index)
     st = _BRANCH_STREAM.get(key)
@@ -143,10 +187,13 @@ class branch(object):
     self.ctx = torch.cuda.stream(st)
     self.ctx.__enter__()
     BRANCH[0] = self.index
+    _BRANCH_MAIN[0] = self.main
+    _FOLD_STATE["main"] = self.main
     return self
 
   def __exit__(self, *exc):
     BRANCH[0] = 0
+    _BRANCH_MAIN[0] = None
     self.ctx.__exit__(*exc)
     _PENDING_JOIN.append((self.main, self.side))    # joined later: the main view runs meanwhile
     if exc and exc[0] is not None:
@@ -232,15 +279,22 @@ def auto_branch(fwd):
         not self.training or not torch.is_grad_enabled() or len(_DEFERRED_RUNNING) > _DEFERRED_LIMIT):
       join()      # evaluation must see up-to-date running statistics; bound the postponed list
     run = fwd
+    will_branch = (AUTO_BRANCH[0] and self.training and torch.is_grad_enabled() and BRANCH[0] == 0
+                   and not _PENDING_JOIN and torch.is_tensor(x) and x.is_cuda
+                   and not any(k.get(f) for f in _FEATURE_FLAGS))
+    pl = None
     if GRAPH_FORWARD[0]:
       from . import graphed
       if graphed.eligible(self, x, a, k):
+        pl = graphed.plan(self, x, k, 1 if will_branch else BRANCH[0])
+
         def run(self_, x_, *a_, **k_):      # captured-graph replay once this (shape, head, position) is warm
-          return graphed.forward(fwd, self_, x_, a_, k_)
-    if (AUTO_BRANCH[0] and self.training and torch.is_grad_enabled() and BRANCH[0] == 0
-        and not _PENDING_JOIN and torch.is_tensor(x) and x.is_cuda
-        and not any(k.get(f) for f in _FEATURE_FLAGS)):
-      with branch(proxies=False) as br:
+          return graphed.forward(fwd, self_, x_, a_, k_, pl)
+    if will_branch:
+      # a replayed / captured view accumulates its gradients itself; an eager side view sees the parameters through
+      # leaf aliases whose gradients are folded into .grad at the end of backward (_AUTO_FOLD: any optimiser works)
+      aliases = pl is None or pl.mode == "eager"
+      with branch(proxies=aliases, auto_fold=aliases) as br:
         x.record_stream(br.side)         # allocated on the caller's stream, consumed on the side stream
         return run(self, x, *a, **k)
     if not torch.is_grad_enabled():
@@ -291,6 +345,9 @@ def branch_backward(fn):
     prev, prev_dt = BRANCH[0], PT_DTYPE[0]
     BRANCH[0] = getattr(ctx, "branch", 0)
     PT_DTYPE[0] = getattr(ctx, "pt_dtype", prev_dt)     # (fp32_mode() forwards allocate fp32 in backward too)
+    if BRANCH[0] in _AUTO_FOLD and not _FOLD_STATE["queued"]:
+      _FOLD_STATE["queued"] = True
+      torch.autograd.Variable._execution_engine.queue_callback(_fold_after_backward)
     try:
       return fn(ctx, *grads)
     finally:

@@ -12,7 +12,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run(graph, auto_branch, steps=7, lr_cut_at=None, odd_batch_at=None, two_head=False):
+def _run(graph, auto_branch, steps=7, lr_cut_at=None, odd_batch_at=None, two_head=False, n_base=8, sz=32):
   from iic_amd import archs, ops
   from iic_amd.losses import IID_loss
   from iic_amd.optim import Adam
@@ -24,11 +24,11 @@ def _run(graph, auto_branch, steps=7, lr_cut_at=None, odd_batch_at=None, two_hea
                                 output_k_A=12, output_k_B=5)
     net = archs.ClusterNet5gTwoHead(cfg).to(dev).train()
   else:
-    cfg = types.SimpleNamespace(in_channels=2, input_sz=32, batchnorm_track=True, num_sub_heads=2, output_k=10)
+    cfg = types.SimpleNamespace(in_channels=2, input_sz=sz, batchnorm_track=True, num_sub_heads=2, output_k=10)
     net = archs.ClusterNet5g(cfg).to(dev).train()
   opt = Adam(net.parameters(), lr=1e-3)
   g = torch.Generator().manual_seed(1)
-  base = torch.rand(8, 1, 32, 32, generator=g)
+  base = torch.rand(n_base, 1, sz, sz, generator=g)
   imgs = base.repeat(3, 1, 1, 1).to(dev)
   imgs_tf = (torch.flip(imgs, dims=[3]) * 0.9 + 0.03).clamp(0, 1)
   prev = ops.AUTO_BRANCH[0], ops.GRAPH_FORWARD[0]
@@ -72,6 +72,20 @@ def test_graphed_forward_is_bit_identical_to_eager(auto_branch):
   for k in s0:
     assert torch.equal(s0[k], s1[k]), k
   assert s1["trunk.bn1.num_batches_tracked"].item() == 2 * 7
+
+
+def test_graphed_two_streams_are_ordered_before_the_optimiser_when_the_gpu_is_the_bottleneck():
+  """At 24 images the host is slower than the GPU and every stream has drained by the time the optimiser is launched; at
+  300 images of 96 x 96 the optimiser is enqueued while both views' backward graphs still run, so this is the case
+  that shows whether the second view's gradients (side stream) are ordered before the optimiser's reads (caller's
+  stream).  Two streams must equal one stream bit for bit, graph replay must equal eager launches."""
+  l1, s1, _ = _run(True, False, steps=5, n_base=100, sz=96)
+  l2, s2, n2 = _run(True, True, steps=5, n_base=100, sz=96)
+  l3, s3, _ = _run(False, True, steps=5, n_base=100, sz=96)
+  assert n2 == 2
+  assert l1 == l2 == l3, (l1, l2, l3)
+  for k in s1:
+    assert torch.equal(s1[k], s2[k]) and torch.equal(s1[k], s3[k]), k
 
 
 def test_graphed_two_head_net_keys_graphs_by_head():

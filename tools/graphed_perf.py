@@ -13,8 +13,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--no-item", action="store_true")
 ap.add_argument("--modes", default="eager2,graphed2,graphed1")
+ap.add_argument("--profile", action="store_true", help="cProfile of the timed steps (host side), top 30 by cumulative time")
+ap.add_argument("--user-stream", action="store_true", help="run the whole script-side sequence on a non-default stream")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
+if a.user_stream:
+  torch.cuda.set_stream(torch.cuda.Stream())
 cfg = types.SimpleNamespace(in_channels=2, input_sz=96, batchnorm_track=True, num_sub_heads=5, output_k=70)
 imgs, imgs_tf = bench.make_batch(660, 96, dev)
 for mode in a.modes.split(","):
@@ -47,8 +51,15 @@ for mode in a.modes.split(","):
   torch.cuda.synchronize()
   t_host[0] = 0.0
   t0 = time.perf_counter()
+  if a.profile:
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    pr.enable()
   for _ in range(a.steps):
     step()
+  if a.profile:
+    pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(32)
   torch.cuda.synchronize()
   dt = (time.perf_counter() - t0) / a.steps
   print("%-10s %.2f ms/step (%.0f pairs/s), host time in python calls %.2f ms/step" % (mode, 1e3 * dt, 660 / dt, 1e3 * t_host[0] / a.steps))
