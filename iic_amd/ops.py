@@ -45,9 +45,9 @@ _PENDING_JOIN = []        # (main stream, side stream) of branches not joined ye
 _BRANCH_MAIN = [None]     # inside `with branch():` the stream the caller was on (iic_amd.graphed orders it after a view's backward)
 
 
-# IIC_BRANCH_PROXIES=0: side branches use the parameters themselves.  Autograd then accumulates
-# both views' gradients into p.grad (correct with ANY optimiser, e.g. stock torch.optim.Adam) at
-# the price of cross-stream synchronisation in the backward pass.
+# IIC_BRANCH_PROXIES=0 (debugging only): side branches use the parameters themselves and autograd accumulates both
+# views' gradients into p.grad ACROSS the two streams.  Not safe with torch 2.10 once the GPU is the bottleneck (see
+# _AUTO_FOLD below: the accumulation races the other view's producer) -- auto_branch does not use this mode any more.
 USE_PROXIES = [os.environ.get("IIC_BRANCH_PROXIES", "1") != "0"]
 
 
