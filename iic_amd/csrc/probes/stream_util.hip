@@ -18,7 +18,7 @@ void* iic_debug_stream_create_cumask(const uint32_t* mask, int words) {
   return (void*)s;
 }
 
-// "Matrix token" (round-4 experiment, iic_amd/ops.py MFMA_TOKEN): a device-side lock taken by a one-wave kernel in front of
+// "Matrix token" (round-4 experiment; its Python hook around the conv / weight-gradient launches lived in commit 088dc05): a device-side lock taken by a one-wave kernel in front of
 // every matrix-bound launch and dropped by another behind it, so that the two views' streams never run two matrix-bound
 // kernels at once and fall into anti-phase (one view's convolution beside the other view's BatchNorm passes).  The wait is
 // bounded (timeout_us): a lost token degrades to the unsynchronised schedule, it cannot hang the queue.

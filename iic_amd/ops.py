@@ -648,42 +648,8 @@ def red_supported(g, w_t):
   return ok
 
 
-# Round-4 experiment (IIC_MFMA_TOKEN=<timeout us>, needs `make probes`): a device-side lock around every matrix-bound
-# launch, so that the two views' streams never run two of them at once (csrc/probes/stream_util.hip).  Measured result:
-# DESIGN.md section 7.
-MFMA_TOKEN = [int(os.environ.get("IIC_MFMA_TOKEN", "0") or 0)]
-_TOKEN_LIB = [None]
-
-
-def _token_lib():
-  if _TOKEN_LIB[0] is None:
-    L = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libiic_probe.so"))
-    L.iic_debug_token_acquire.argtypes = [ctypes.c_void_p, ctypes.c_int]
-    L.iic_debug_token_release.argtypes = [ctypes.c_void_p]
-    assert L.iic_debug_token_init() == 1
-    _TOKEN_LIB[0] = L
-  return _TOKEN_LIB[0]
-
-
-class _mfma_token(object):
-  def __enter__(self):
-    if MFMA_TOKEN[0] > 0:
-      check(_token_lib().iic_debug_token_acquire(stream_ptr(), MFMA_TOKEN[0]), "token acquire")
-
-  def __exit__(self, *exc):
-    if MFMA_TOKEN[0] > 0:
-      check(_token_lib().iic_debug_token_release(stream_ptr()), "token release")
-    return False
-
-
 def conv_igemm(g, x_pt, w_t, out_pt, stats=None, res_grad=None, res_act=None, accumulate=False,
                premask=False, red=None):
-  with _mfma_token():
-    return _conv_igemm(g, x_pt, w_t, out_pt, stats, res_grad, res_act, accumulate, premask, red)
-
-
-def _conv_igemm(g, x_pt, w_t, out_pt, stats=None, res_grad=None, res_act=None, accumulate=False,
-                premask=False, red=None):
   """w_t: a row-major bf16 operand tensor (first-generation kernel) or a WOperand handle
   (second-generation weights-direct kernel wherever the geometry supports it).
   premask: out = (value [+ previous] [+ res_grad]) where res_act > 0 else 0 (IIC_ACC_PREMASK).
@@ -785,13 +751,12 @@ def _conv_wgrad_launch(g, x_pt, dy_pt, wtaps, use_tr, out, accumulate, ns, x_coe
   if part is None or part.numel() < need:
     part = torch.empty(max(need, 1 << 22), dtype=F32, device=x_pt.device)
     _WG_PART[key] = part
-  with _mfma_token():
-    if x_coef is not None:
-      check(lib().iic_conv_wgrad_apply(ctypes.byref(g), ptr(x_pt), ptr(x_coef), x_pad, ptr(dy_pt), ptr(part), ns,
-                                       stream_ptr()), "iic_conv_wgrad_apply")
-    else:
-      check(lib().iic_conv_wgrad(ctypes.byref(g), ptr(x_pt), ptr(dy_pt), ptr(part), ns,
-                                 1 if use_tr else 0, stream_ptr()), "iic_conv_wgrad")
+  if x_coef is not None:
+    check(lib().iic_conv_wgrad_apply(ctypes.byref(g), ptr(x_pt), ptr(x_coef), x_pad, ptr(dy_pt), ptr(part), ns,
+                                     stream_ptr()), "iic_conv_wgrad_apply")
+  else:
+    check(lib().iic_conv_wgrad(ctypes.byref(g), ptr(x_pt), ptr(dy_pt), ptr(part), ns,
+                               1 if use_tr else 0, stream_ptr()), "iic_conv_wgrad")
   check(lib().iic_conv_wgrad_reduce(ptr(part), ns, wtaps, g.Cout, g.Cin, ptr(out),
                                     1 if accumulate else 0, stream_ptr()), "iic_conv_wgrad_reduce")
 
