@@ -273,9 +273,11 @@ def reference_api_rate(cfg, dev, imgs, imgs_tf, pairs, steps, auto_branch=False,
     opt = Adam(net.parameters(), lr=1e-4)
   else:
     opt = torch.optim.Adam(net.parameters(), lr=1e-4)
-  prev_auto, prev_graph = ops.AUTO_BRANCH[0], ops.GRAPH_FORWARD[0]
+  prev_auto, prev_graph, prev_eager2 = ops.AUTO_BRANCH[0], ops.GRAPH_FORWARD[0], ops.AUTO_BRANCH_EAGER[0]
   ops.AUTO_BRANCH[0] = bool(auto_branch)
   ops.GRAPH_FORWARD[0] = bool(graph_forward)
+  # (eager launches on two streams are opt-in since round 4, iic_amd.ops.AUTO_BRANCH_EAGER: measured here all the same)
+  ops.AUTO_BRANCH_EAGER[0] = bool(auto_branch) and not graph_forward
 
   def step():
     net.zero_grad()
@@ -303,14 +305,14 @@ def reference_api_rate(cfg, dev, imgs, imgs_tf, pairs, steps, auto_branch=False,
     v = step()
   torch.cuda.synchronize()
   dt = (time.perf_counter() - t0) / steps
-  ops.AUTO_BRANCH[0], ops.GRAPH_FORWARD[0] = prev_auto, prev_graph
+  ops.AUTO_BRANCH[0], ops.GRAPH_FORWARD[0], ops.AUTO_BRANCH_EAGER[0] = prev_auto, prev_graph, prev_eager2
   what = ("list-returning net(x), IID_loss per sub-head, %s, loss .item() every step -- the unchanged script's "
           "call sequence" % ("the fused HIP Adam behind get_opt" if graph_forward else "torch.optim.Adam"))
   if graph_forward:
     what += (", its two forwards on two streams and each forward / backward replayed as a captured HIP graph "
              "(iic_amd/graphed.py: what `python -m iic_amd.run` does by default)")
   elif auto_branch:
-    what += ", eager launches, its two forwards on two streams (iic_amd.ops.auto_branch)"
+    what += ", eager launches, its two forwards on two streams (iic_amd.ops.auto_branch with the opt-in IIC_AUTO_BRANCH_EAGER=1)"
   else:
     what += ", eager launches, one stream"
   return {"paired_images_per_sec": pairs / dt, "ms_per_step": 1e3 * dt, "final_loss": v, "what": what}

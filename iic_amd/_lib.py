@@ -74,6 +74,10 @@ _SIGNATURES = {
   "iic_bn_bwd_finalize": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_long, _P]),
   "iic_bn_bwd_apply": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
   "iic_stem_stats": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+  "iic_stem_gram_supported": (c_int, [c_int, c_int, c_int]),
+  "iic_stem_gram_bytes": (c_long, [c_int]),
+  "iic_stem_gram": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+  "iic_stem_gram_finalize": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_long, c_long, c_float, c_float, _P]),
   "iic_stem_apply_pool": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
   "iic_stem_bwd_reduce": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
   "iic_stem_wgrad_partial_floats": (c_long, []),

@@ -190,6 +190,14 @@ class _ConvHolder(object):
       self._stats[key] = s
     return s
 
+  def gram_stats(self, device, cin):
+    key = (str(device), "gram", ops.BRANCH[0])
+    s = self._stats.get(key)
+    if s is None:
+      s = ops.new_gram_stats(cin, device)
+      self._stats[key] = s
+    return s
+
 
 def _bn_buffers(bn):
   if bn.track_running_stats:
@@ -219,7 +227,12 @@ class _StemFn(torch.autograd.Function):
     rm, rv, nbt = _bn_buffers(bn)
     training = _bn_training(bn)
     wd = w.detach()
-    if training:
+    if training and ops.stem_gram_supported(x):
+      # conv1 is linear: its batch statistics follow from the Gram matrix of the input patches (csrc/stem_gram.hip)
+      coef = ops.stem_gram_finalize(x, wd, mod._h_conv1.gram_stats(x.device, C), gamma.detach(), beta.detach(),
+                                    rm if bn.training else None, rv if bn.training else None,
+                                    nbt if bn.training else None, N * H * W)
+    elif training:
       st = mod._h_conv1.stats(x.device)
       ops.stem_stats(x, wd, st)
       coef = ops.bn_finalize(st, gamma.detach(), beta.detach(), rm if bn.training else None,

@@ -210,6 +210,10 @@ class on_branch(object):
 
   def __enter__(self):
     assert BRANCH[0] == 0, "branches do not nest"
+    # (this view sees the parameters through leaf aliases whatever an earlier auto_branch run left behind: with the
+    #  index still marked alias-free, its gradients would be accumulated into .grad across the two streams)
+    _NO_PROXY_BRANCHES.discard(self.index)
+    _AUTO_FOLD.discard(self.index)
     self.ctx = torch.cuda.stream(self.stream)
     self.ctx.__enter__()
     BRANCH[0] = self.index
@@ -230,6 +234,14 @@ class on_branch(object):
 # the outputs of the first forward must not be consumed by anything but this library's losses
 # before the join (true of every reference script); evaluation / no_grad forwards never branch.
 AUTO_BRANCH = [os.environ.get("IIC_AUTO_BRANCH", "0") == "1"]
+# EAGER launches of the pair on two streams (leaf aliases + end-of-backward fold, _AUTO_FOLD above): opt-in since the end
+# of round 4.  The mode is correct at GPU-bound sizes (tests/test_gpu_graphed.py, tools/race_check.py) but the
+# 24-image bit-identity tests differed from the one-stream run in about 1 of 13 runs on the MI355X boxes and the cause
+# was not found before the round's GPU budget ran out.  Default: a forward of the pair that
+# runs EAGERLY -- graph replay off, a warm-up occurrence, a shape that was not captured -- stays on the caller's stream;
+# the two streams are used for captured / replayed views, whose gradient hand-over is explicit (iic_amd/graphed.py).
+AUTO_BRANCH_EAGER = [os.environ.get("IIC_AUTO_BRANCH_EAGER", "0") == "1"]
+_SOLO_FIRST = [False]     # the first forward of a pair ran on the caller's stream: the second one must not fork either
 # forwards that hand back FEATURES (semisup heads: sup_head5.py:34-35, net6c_two_head.py:78-94,
 # k-means feature extraction) are consumed by modules outside this library, which know nothing about
 # the side stream: they never branch
@@ -280,7 +292,7 @@ def auto_branch(fwd):
       join()      # evaluation must see up-to-date running statistics; bound the postponed list
     run = fwd
     will_branch = (AUTO_BRANCH[0] and self.training and torch.is_grad_enabled() and BRANCH[0] == 0
-                   and not _PENDING_JOIN and torch.is_tensor(x) and x.is_cuda
+                   and not _PENDING_JOIN and not _SOLO_FIRST[0] and torch.is_tensor(x) and x.is_cuda
                    and not any(k.get(f) for f in _FEATURE_FLAGS))
     pl = None
     if GRAPH_FORWARD[0]:
@@ -291,9 +303,18 @@ def auto_branch(fwd):
         def run(self_, x_, *a_, **k_):      # captured-graph replay once this (shape, head, position) is warm
           return graphed.forward(fwd, self_, x_, a_, k_, pl)
     if will_branch:
-      # a replayed / captured view accumulates its gradients itself; an eager side view sees the parameters through
-      # leaf aliases whose gradients are folded into .grad at the end of backward (_AUTO_FOLD: any optimiser works)
+      # a replayed / captured view accumulates its gradients itself; an eager side view (opt-in) sees the parameters
+      # through leaf aliases whose gradients are folded into .grad at the end of backward (_AUTO_FOLD)
       aliases = pl is None or pl.mode == "eager"
+      if aliases and not AUTO_BRANCH_EAGER[0]:
+        # eager launches stay on the caller's stream.  A planned position keeps its resource namespace (so that its
+        # buffers exist before the capture) but sees the parameters themselves; the pair's second forward must not
+        # fork in its place, and the running-statistic updates of both are applied at the join, in call order.
+        _SOLO_FIRST[0] = True
+        if pl is not None:
+          _NO_PROXY_BRANCHES.add(pl.res)
+          _AUTO_FOLD.discard(pl.res)
+        return run(self, x, *a, **k)
       with branch(proxies=aliases, auto_fold=aliases) as br:
         x.record_stream(br.side)         # allocated on the caller's stream, consumed on the side stream
         return run(self, x, *a, **k)
@@ -316,6 +337,7 @@ def join():
   while _PENDING_JOIN:
     main, side = _PENDING_JOIN.pop()
     main.wait_stream(side)
+  _SOLO_FIRST[0] = False
   flush_deferred_running()
 
 
@@ -800,7 +822,7 @@ BN_REPLICAS = [1]
 def bn_finalize(stats, gamma, beta, running_mean, running_var, nbt, C, count, training):
   """coef [5][C]: scale, shift, mean, invstd, unbiased batch variance."""
   coef = torch.empty((5, C), dtype=F32, device=gamma.device)
-  if training and running_mean is not None and (BRANCH[0] != 0 or _PENDING_JOIN):
+  if training and running_mean is not None and (BRANCH[0] != 0 or _PENDING_JOIN or _SOLO_FIRST[0]):
     # a side branch is (or may still be) running: both views update the same running statistics,
     # so every update is postponed to the join and applied there in CALL order -- the order a
     # sequential run would have used (fork the view that comes first in the script)
@@ -872,6 +894,37 @@ def sobel(imgs, include_rgb, using_IR=False):
 def stem_stats(x, w, stats):
   n, c, h, wd = x.shape
   check(lib().iic_stem_stats(ptr(x), ptr(w), ptr(stats), n, c, h, wd, stream_ptr()), "iic_stem_stats")
+
+
+# The stem's batch statistics from the Gram matrix of the input patches instead of a convolution pass
+# (csrc/stem_gram.hip).  Built and parity-tested at the end of round 4, measured NEUTRAL on the step (the 210 us pass it
+# removes runs beside the other view's stem kernels either way: 37.33 / 37.43 ms without, 37.48 / 37.36 with), so it is
+# opt-in: IIC_STEM_GRAM=1.
+STEM_GRAM = [os.environ.get("IIC_STEM_GRAM", "0") == "1"]
+
+
+def stem_gram_supported(x):
+  n, c, h, wd = x.shape
+  return STEM_GRAM[0] and x.dtype == F32 and bool(lib().iic_stem_gram_supported(c, h, wd))
+
+
+def new_gram_stats(cin, device):
+  return torch.zeros(lib().iic_stem_gram_bytes(cin) // 8, dtype=torch.int64, device=device)
+
+
+def stem_gram_finalize(x, w, gstats, gamma, beta, running_mean, running_var, nbt, count):
+  """stem_stats + bn_finalize(training=True) of the 5g stem in two small launches (same deferral of the running
+  statistics inside a branch as bn_finalize)."""
+  n, c, h, wd = x.shape
+  check(lib().iic_stem_gram(ptr(x), ptr(gstats), n, c, h, wd, stream_ptr()), "iic_stem_gram")
+  coef = torch.empty((5, 64), dtype=F32, device=gamma.device)
+  if running_mean is not None and (BRANCH[0] != 0 or _PENDING_JOIN or _SOLO_FIRST[0]):
+    _DEFERRED_RUNNING.append((coef, running_mean, running_var, nbt, 64))
+    running_mean = running_var = nbt = None
+  check(lib().iic_stem_gram_finalize(ptr(gstats), ptr(w), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+                                     ptr(nbt), ptr(coef), c, count, count * BN_REPLICAS[0], BN_EPS, BN_MOMENTUM,
+                                     stream_ptr()), "iic_stem_gram_finalize")
+  return coef
 
 
 def stem_apply_pool(x, w, coef, out_pt):

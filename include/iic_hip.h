@@ -264,6 +264,19 @@ int iic_bn_bwd_apply(const void* dout, const void* act, const void* y, const flo
  * ------------------------------------------------------------------------------- */
 int iic_stem_stats(const float* x, const float* w, float* stats, int N, int Cin, int H, int W,
                    void* stream);
+/* The same statistics without a convolution pass (round 4): conv1 is linear in a pixel's zero-padded 3x3 patch p
+ * (K = Cin*9 values), so sum y_c = w_c . S and sum y_c^2 = w_c^T G w_c with S = sum p, G = sum p p^T -- K + K(K+1)/2
+ * weight-independent sums (189 for Cin = 2) instead of 64 x K MACs per pixel.  iic_stem_gram adds them, exactly, into
+ * `gstats` (iic_stem_gram_bytes(Cin) bytes, zeroed once by the caller; the finaliser re-zeroes it);
+ * iic_stem_gram_finalize evaluates mean / variance per channel in double and then does what iic_bn_finalize does in
+ * training mode (coef [5][64]; running_mean / running_var / num_batches_tracked may be NULL).  Cin <= 2
+ * (iic_stem_gram_supported); other inputs use iic_stem_stats + iic_bn_finalize. */
+int iic_stem_gram_supported(int Cin, int H, int W);
+long iic_stem_gram_bytes(int Cin);
+int iic_stem_gram(const float* x, float* gstats, int N, int Cin, int H, int W, void* stream);
+int iic_stem_gram_finalize(float* gstats, const float* w, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, long long* num_batches_tracked, float* coef,
+                           int Cin, long count, long ucount, float eps, float momentum, void* stream);
 int iic_stem_apply_pool(const float* x, const float* w, const float* coef, void* out_pt, int N,
                         int Cin, int H, int W, void* stream);
 int iic_stem_bwd_reduce(const float* x, const float* w, const float* coef, const void* dpool_pt,

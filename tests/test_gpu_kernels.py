@@ -660,6 +660,52 @@ def test_sobel_matches_reference_golden():
   assert np.abs(o.cpu().numpy() - g["sobel_out4"]).max() <= 1e-6
 
 
+@pytest.mark.parametrize("cin,N,H,W", [(2, 24, 96, 96), (2, 5, 33, 29), (1, 7, 20, 64), (2, 3, 8, 8), (2, 2, 3, 5)])
+def test_stem_gram_statistics_match_the_convolution_pass(cin, N, H, W):
+  """conv1 is linear in a pixel's 3x3 patch, so the stem's BatchNorm batch statistics follow from the patch sums and
+  the patch Gram matrix (csrc/stem_gram.hip) -- no convolution pass.  Against float64 statistics of F.conv2d on the
+  CPU (the reference's conv1 -> bn1, net5g.py:21-24) and against the recompute pass it replaces: mean, biased and
+  unbiased variance, the BatchNorm coefficients and the running-statistic update; partial row bands, a width that
+  is no multiple of anything, images smaller than one band; the accumulator is left zeroed for the next call."""
+  from iic_amd import ops
+  rng = np.random.default_rng(5)
+  x = torch.from_numpy((rng.standard_normal((N, cin, H, W)) * 0.7 + 0.3).astype(np.float32))     # a non-zero mean
+  w = torch.from_numpy((rng.standard_normal((64, cin, 3, 3)) * 0.3).astype(np.float32))
+  gamma = torch.from_numpy((1 + 0.2 * rng.standard_normal(64)).astype(np.float32))
+  beta = torch.from_numpy((0.1 * rng.standard_normal(64)).astype(np.float32))
+  y = F.conv2d(x.double(), w.double(), padding=1)
+  cnt = N * H * W
+  mean64, var64 = y.mean((0, 2, 3)), y.var((0, 2, 3), unbiased=False)
+  d = dev()
+  xd, wd, gd, bd = x.to(d), w.to(d), gamma.to(d), beta.to(d)
+  assert ops.stem_gram_supported(xd)
+  gst = ops.new_gram_stats(cin, d)
+  rm, rv = torch.zeros(64, device=d), torch.ones(64, device=d)
+  nbt = torch.zeros((), dtype=torch.int64, device=d)
+  for rep in range(2):           # twice: the finaliser must have re-zeroed the accumulator
+    coef = ops.stem_gram_finalize(xd, wd, gst, gd, bd, rm if rep == 0 else None, rv if rep == 0 else None,
+                                  nbt if rep == 0 else None, cnt)
+    torch.cuda.synchronize()
+    c = coef.double().cpu()
+    scale = 5e-6 * (mean64.abs().max() + var64.sqrt().max())
+    assert (c[2] - mean64).abs().max() <= 2 * scale + 1e-6 * mean64.abs().max(), (c[2] - mean64).abs().max()
+    assert torch.allclose(c[3], 1.0 / torch.sqrt(var64 + 1e-5), rtol=5e-5)
+    assert torch.allclose(c[4], var64 * cnt / (cnt - 1), rtol=5e-5, atol=1e-7)
+    assert torch.allclose(c[0], gamma.double() / torch.sqrt(var64 + 1e-5), rtol=5e-5)
+    assert torch.allclose(c[1], beta.double() - mean64 * gamma.double() / torch.sqrt(var64 + 1e-5), rtol=5e-5, atol=2e-6)
+  assert int(nbt) == 1
+  assert torch.allclose(rm.double().cpu(), 0.1 * mean64, rtol=5e-5, atol=1e-7)
+  assert torch.allclose(rv.double().cpu(), 0.9 + 0.1 * var64 * cnt / (cnt - 1), rtol=5e-5)
+  assert int(gst.abs().sum()) == 0
+  # the recompute pass it replaces (which, like the rest of the stem, takes even image sizes only)
+  if H % 2 or W % 2:
+    return
+  st = ops.new_stats(64, d)
+  ops.stem_stats(xd, wd, st)
+  old = ops.bn_finalize(st, gd, bd, None, None, None, 64, cnt, True).double().cpu()
+  assert torch.allclose(c[0], old[0], rtol=5e-5) and torch.allclose(c[1], old[1], rtol=5e-5, atol=2e-6)
+
+
 @pytest.mark.parametrize("cin,S", [(2, 32), (2, 96), (1, 24)])
 def test_stem_forward_backward(cin, S):
   from iic_amd import ops

@@ -27,6 +27,7 @@ for mode in a.modes.split(","):
   opt = Adam(net.parameters(), lr=1e-4)
   ops.AUTO_BRANCH[0] = mode.endswith("2")
   ops.GRAPH_FORWARD[0] = mode.startswith("graphed")
+  ops.AUTO_BRANCH_EAGER[0] = mode == "eager2"       # (eager launches on two streams are opt-in: ops.AUTO_BRANCH_EAGER)
   t_host = [0.0]
 
   def step():
