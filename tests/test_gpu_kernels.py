@@ -678,7 +678,7 @@ def test_stem_gram_statistics_match_the_convolution_pass(cin, N, H, W):
   mean64, var64 = y.mean((0, 2, 3)), y.var((0, 2, 3), unbiased=False)
   d = dev()
   xd, wd, gd, bd = x.to(d), w.to(d), gamma.to(d), beta.to(d)
-  assert ops.stem_gram_supported(xd)
+  assert ops.lib().iic_stem_gram_supported(cin, H, W) == 1      # (ops.STEM_GRAM, the opt-in switch, is not consulted here)
   gst = ops.new_gram_stats(cin, d)
   rm, rv = torch.zeros(64, device=d), torch.ones(64, device=d)
   nbt = torch.zeros((), dtype=torch.int64, device=d)
