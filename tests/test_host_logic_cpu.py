@@ -89,3 +89,58 @@ def test_plan_gives_one_stream_positions_their_own_namespace_and_notices_moved_p
   # a different batch shape (the ragged last batch) is a key of its own: eager until it has been seen twice
   graphed._cl.bump_weights_epoch()
   assert graphed.plan(net, torch.zeros(3, 4), {}, 0).mode == "eager"
+
+
+class _FakeDeviceTensor(torch.Tensor):
+  """A CPU tensor that claims to live on the device: lets the host-side decisions of ops.auto_branch run here."""
+  is_cuda = property(lambda self: True)
+
+
+def test_auto_branch_keeps_eager_pair_forwards_on_the_callers_stream(monkeypatch):
+  """Default since the end of round 4: a forward of the pair that runs eagerly does not fork (ops.AUTO_BRANCH_EAGER
+  is the opt-in); the first one marks the pair (_SOLO_FIRST) so that the second one does not fork in its place, both
+  postpone their running-statistic updates to the join, and the join clears the mark.  With graph replay on, the
+  two warm-up occurrences of a position run the same way inside the position's resource namespace, without
+  parameter aliases."""
+  calls = []
+
+  class Net(torch.nn.Module):
+    def __init__(self):
+      super(Net, self).__init__()
+      self.fc = torch.nn.Linear(4, 3)
+
+    @ops.auto_branch
+    def forward(self, x, head="B"):
+      calls.append((ops.BRANCH[0], ops._SOLO_FIRST[0], ops.pv(self.fc.weight) is self.fc.weight))
+      return [torch.as_tensor(x).as_subclass(torch.Tensor) @ self.fc.weight.t()]
+
+  monkeypatch.setattr(ops, "flush_deferred_running", lambda: None)
+  net = Net().train()
+  x = torch.zeros(5, 4).as_subclass(_FakeDeviceTensor)
+  prev = ops.AUTO_BRANCH[0], ops.GRAPH_FORWARD[0], ops.AUTO_BRANCH_EAGER[0]
+  try:
+    ops.AUTO_BRANCH[0], ops.GRAPH_FORWARD[0], ops.AUTO_BRANCH_EAGER[0] = True, False, False
+    net(x)
+    assert ops._SOLO_FIRST[0] and not ops._PENDING_JOIN and calls[-1] == (0, True, True)
+    net(x)
+    assert calls[-1] == (0, True, True) and not ops._PENDING_JOIN
+    ops.join()
+    assert not ops._SOLO_FIRST[0]
+    # graph replay on: warm-up occurrences of (position 0, branch 1) run on the caller's stream in namespace 1
+    ops.GRAPH_FORWARD[0] = True
+    monkeypatch.setattr(graphed, "eligible", lambda mod, x_, a, k: True)
+    for step in range(2):
+      graphed._cl.bump_weights_epoch()
+      net(x)
+      assert calls[-1] == (1, True, True) and 1 in ops._NO_PROXY_BRANCHES and 1 not in ops._AUTO_FOLD
+      net(x)
+      assert calls[-1] == (0, True, True)
+      ops.join()
+    st = graphed._state(net)
+    assert sorted((k[4], k[5]) for k in st["warm"]) == [(0, 1), (1, 0)] and all(v == 2 for v in st["warm"].values())
+    # the third occurrence would capture -- and, captured, fork onto the side stream
+    graphed._cl.bump_weights_epoch()
+    assert graphed.plan(net, x, {}, 1).mode == "capture"
+  finally:
+    ops.AUTO_BRANCH[0], ops.GRAPH_FORWARD[0], ops.AUTO_BRANCH_EAGER[0] = prev
+    ops._SOLO_FIRST[0] = False
