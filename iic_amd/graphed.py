@@ -202,6 +202,10 @@ class _GraphedFn(torch.autograd.Function):
       for other in (_state(mod)["graphs"].values() if mod is not None else ()):
         if other is not vg and other is not _FAILED and other.bwd_event is not None:
           cur.wait_event(other.bwd_event)
+      if ctx.caller_stream != cur:
+        # (the other view may have run EAGERLY on the caller's stream -- its capture failed, say -- and left no event:
+        #  everything the caller's stream has been given so far includes that view's gradient accumulation)
+        cur.wait_stream(ctx.caller_stream)
       torch._foreach_add_(tgt, src)
     # Whoever reads .grad next -- the script's optimiser, on the stream the script is on -- must come after this view's
     # graph and fold.  The engine only orders the caller's stream after LEAF streams (AccumulateGrad nodes), and none of
