@@ -55,12 +55,30 @@ __device__ __forceinline__ int wn_bt(int xi, int r) {
 
 // ABL (timing ablations, results WRONG): 1 no input transform, 2 no main MFMAs, 4 no stage-2 epilogue.
 // DBG: workgroup 0 copies its LDS image (after the first k-step's transform), its accumulators and Z to `dbg`.
-template <bool STATS, int ABL, bool DBG>
+template <bool STATS, int ABL, bool DBG, bool PROF = false>
 __global__ __launch_bounds__(256, 1) void wino_fwd_kernel(const wino_geom g, const bf16_t* __restrict__ in,
                                                           const unsigned char* __restrict__ ufrag,
                                                           bf16_t* __restrict__ out, float* __restrict__ stats,
                                                           unsigned char* __restrict__ dbg) {
   constexpr int abl = ABL;
+  // PROF: wave 0 sums s_memtime deltas per phase into dbg[blockIdx][16] (u64): 0 set-up, 1 prologue, then per k-step
+  // 2 top wait + barrier, 3 issue (weights, DMA, A reads, transposing reads) + A latency, 4 main MFMAs, 5 transform;
+  // 6 stage 1, 7 stage 2, 8 whole kernel, 9 k-steps
+  unsigned long long pt[10];
+  unsigned long long tp = 0;
+  if (PROF) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) pt[i] = 0;
+    tp = __builtin_readcyclecounter();
+    pt[8] = tp;
+  }
+  auto stamp = [&](int slot) {
+    if (PROF) {
+      const unsigned long long now = __builtin_readcyclecounter();
+      pt[slot] += now - tp;
+      tp = now;
+    }
+  };
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // LDS map: [raw 0][raw 1][V 0][V 1][tables]; the epilogue's Z (128 KB) overlays raw + V
   unsigned char* raw0 = smem;
@@ -238,23 +256,44 @@ __global__ __launch_bounds__(256, 1) void wino_fwd_kernel(const wino_geom g, con
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nu][mb][nb][r] = 0.f;
 
+  // Weight fragments one k-step ahead, as inline asm: hipcc must not count them (it does not see the LDS-DMA pieces issued
+  // behind them, so its vmcnt(N) in front of the MFMAs -- N = loads it knows to be younger -- made even k-steps wait for
+  // the loads they had just issued).  The k-step's top waits vmcnt(0) for everything issued one k-step earlier.
   u32x4 B0[4][2], B1[4][2];
   auto bload = [&](u32x4 (&B)[4][2], int ks) {
 #pragma unroll
     for (int nu = 0; nu < 4; ++nu) {
       const unsigned char* p = bptr(nu, ks);
-      B[nu][0] = *reinterpret_cast<const u32x4*>(p);
-      B[nu][1] = *reinterpret_cast<const u32x4*>(p + 1024);
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(B[nu][0]) : "v"(p) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(B[nu][1]) : "v"(p) : "memory");
     }
   };
-  auto mma = [&](int vsel, u32x4 (&B)[4][2]) {
-    bf16x8 a[4][2];
+  auto top_wait = [&](u32x4 (&B)[4][2]) {       // everything this wave has in flight: weights of this k-step, DMA pieces, V stores
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                 : "+v"(B[0][0]), "+v"(B[0][1]), "+v"(B[1][0]), "+v"(B[1][1]), "+v"(B[2][0]), "+v"(B[2][1]), "+v"(B[3][0]),
+                   "+v"(B[3][1]) :: "memory");
+  };
+  // A fragments of a k-step: all 8 reads issued back to back (asm: left to itself hipcc issues them two at a time in
+  // front of the MFMAs that use them and exposes the LDS latency four times per k-step -- 1 400 cycles per k-step
+  // measured for 512 cycles of MFMAs), then the 16 transposing reads of the next transform (compiler-visible), then ONE
+  // wait that lets exactly those 16 younger reads stay in flight.
+  auto a_issue = [&](bf16x8 (&a)[4][2], int vsel) {
+    const uint32_t base = AR + vsel * WN_VBYTES;
 #pragma unroll
     for (int nu = 0; nu < 4; ++nu)
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb)
-        a[nu][mb] = *reinterpret_cast<__attribute__((address_space(3))) const bf16x8*>(
-            (uintptr_t)(AR + vsel * WN_VBYTES + nu * (2 * WN_VPITCH + 16) + mb * 512));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[nu][mb]) : "v"(base), "i"(nu * (2 * WN_VPITCH + 16) + mb * 512));
+  };
+  auto a_wait16 = [&](bf16x8 (&a)[4][2]) {      // 16 younger LDS reads may still be in flight
+    asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[2][0]),
+                 "+v"(a[2][1]), "+v"(a[3][0]), "+v"(a[3][1]) :: "memory");
+  };
+  auto a_wait0 = [&](bf16x8 (&a)[4][2]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[2][0]),
+                 "+v"(a[2][1]), "+v"(a[3][0]), "+v"(a[3][1]) :: "memory");
+  };
+  auto mma = [&](const bf16x8 (&a)[4][2], u32x4 (&B)[4][2]) {
 #pragma unroll
     for (int nu = 0; nu < 4; ++nu)
 #pragma unroll
@@ -266,22 +305,26 @@ __global__ __launch_bounds__(256, 1) void wino_fwd_kernel(const wino_geom g, con
   };
 
   // ---- prologue ----
+  stamp(0);
   const int NCH = g.Cin >> 5;
   s16x4 t[16];
+  bf16x8 a[4][2];
   dma_chunk(0, 0);
   bload(B0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   tr_issue(t, 0, 0);
   tr_run(t, VW);
+  stamp(1);
 
   // The last chunk's look-ahead work (DMA of chunk NCH, transform of k-step 2 NCH, weights of k-step 2 NCH) is
   // done on clamped indices instead of being branched around: it lands in buffers nobody reads again.
   for (int c = 0; c < NCH; ++c) {
     const int cn = c + 1 < NCH ? c + 1 : c;
     // ---- k-step 2c: V[0], B0 ----  (lgkmcnt: the transform's ds_writes are invisible to hipcc)
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    top_wait(B0);
     __syncthreads();
+    stamp(2);
     if (DBG && c == 0 && blockIdx.x == 0) {       // checkpoint 1: raw[0], V[0], tables as they sit in LDS
       const int total = tab_off + 64 * 3 * 4 + 4 * 2 * 64 * 4 + npix;
       for (int i = tid; i < (total + 3) / 4; i += 256)
@@ -290,24 +333,41 @@ __global__ __launch_bounds__(256, 1) void wino_fwd_kernel(const wino_geom g, con
     bload(B1, 2 * c + 1);
     dma_chunk(cn, (c + 1) & 1);
     __builtin_amdgcn_sched_barrier(0);
-    if (!(abl & 1)) tr_issue(t, c & 1, 1);
-    if (!(abl & 2)) mma(0, B0);
+    if (!(abl & 2)) a_issue(a, 0);
     __builtin_amdgcn_sched_barrier(0);
+    if (!(abl & 1)) tr_issue(t, c & 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(abl & 2)) { if (abl & 1) a_wait0(a); else a_wait16(a); }
+    stamp(3);
+    if (!(abl & 2)) mma(a, B0);
+    __builtin_amdgcn_sched_barrier(0);
+    stamp(4);
     if (!(abl & 1)) tr_run(t, VW + WN_VBYTES);
     __builtin_amdgcn_sched_barrier(0);
+    stamp(5);
     // ---- k-step 2c + 1: V[1], B1 ----
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    top_wait(B1);
     __syncthreads();
+    stamp(2);
     bload(B0, 2 * cn);
     __builtin_amdgcn_sched_barrier(0);
-    if (!(abl & 1)) tr_issue(t, (c + 1) & 1, 0);
-    if (!(abl & 2)) mma(1, B1);
+    if (!(abl & 2)) a_issue(a, 1);
     __builtin_amdgcn_sched_barrier(0);
+    if (!(abl & 1)) tr_issue(t, (c + 1) & 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(abl & 2)) { if (abl & 1) a_wait0(a); else a_wait16(a); }
+    stamp(3);
+    if (!(abl & 2)) mma(a, B1);
+    __builtin_amdgcn_sched_barrier(0);
+    stamp(4);
     if (!(abl & 1)) tr_run(t, VW);
     __builtin_amdgcn_sched_barrier(0);
+    stamp(5);
+    if (PROF) pt[9] += 2;
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();          // every wave is done with raw / V: the region becomes Z
+  stamp(2);
 
   if (DBG && blockIdx.x == 0) {                   // checkpoint 2: the accumulators, [wave][lane][nu][mb][nb][16]
     float* d2 = reinterpret_cast<float*>(dbg + 256 * 1024) + (long)tid * 256;
@@ -323,18 +383,23 @@ __global__ __launch_bounds__(256, 1) void wino_fwd_kernel(const wino_geom g, con
 
   // ---- output transform, stage 1: nu-reduction in registers -> Z[xi][b][tile][cout] (fp32, LDS) ----
   float* Z = reinterpret_cast<float*>(smem);
+  {
+    // one lane base + compile-time offsets: every store is ds_write_b32 base, value offset:imm
+    float* zb = Z + (wave * 2 * 64 + 4 * g5) * 64 + l31;
 #pragma unroll
-  for (int mb = 0; mb < 2; ++mb)
+    for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
+      for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float m0v = acc[0][mb][nb][r], m1v = acc[1][mb][nb][r], m2v = acc[2][mb][nb][r], m3v = acc[3][mb][nb][r];
-        const int row = mb * 32 + mfma32_row(r, lane), col = nb * 32 + l31;
-        Z[((wave * 2 + 0) * 64 + row) * 64 + col] = m0v + m1v + m2v;
-        Z[((wave * 2 + 1) * 64 + row) * 64 + col] = m1v - m2v - m3v;
-      }
+        for (int r = 0; r < 16; ++r) {
+          const float m0v = acc[0][mb][nb][r], m1v = acc[1][mb][nb][r], m2v = acc[2][mb][nb][r], m3v = acc[3][mb][nb][r];
+          const int off = (mb * 32 + (r & 3) + 8 * (r >> 2)) * 64 + nb * 32;      // row mfma32_row(r, lane) - 4 g5, column nb * 32
+          zb[off] = m0v + m1v + m2v;
+          zb[64 * 64 + off] = m1v - m2v - m3v;
+        }
+  }
   __syncthreads();
+  stamp(6);
   if (DBG && blockIdx.x == 0) {                   // checkpoint 3: Z
     for (int i = tid; i < WN_ZBYTES / 4; i += 256)
       reinterpret_cast<uint32_t*>(dbg + 1024 * 1024)[i] = reinterpret_cast<const uint32_t*>(smem)[i];
@@ -403,6 +468,16 @@ __global__ __launch_bounds__(256, 1) void wino_fwd_kernel(const wino_geom g, con
       const int stripe = blockIdx.x % IIC_STAT_STRIPES;
       iic_stat_add(stats, stripe, g.Cout, n0 + tid, 0, a0);
       iic_stat_add(stats, stripe, g.Cout, n0 + tid, 1, a1);
+    }
+  }
+  if (PROF) {
+    stamp(7);
+    if (tid == 0) {
+      unsigned long long* q = reinterpret_cast<unsigned long long*>(dbg) + (long)blockIdx.x * 16;
+      pt[8] = __builtin_readcyclecounter() - pt[8];
+#pragma unroll
+      for (int i = 0; i < 10; ++i) q[i] = pt[i];
+      q[10] = __builtin_amdgcn_s_memrealtime();
     }
   }
 }
@@ -523,7 +598,17 @@ int iic_probe_wino_fwd(const void* in, const void* ufrag, void* out, float* stat
     hipLaunchKernelGGL((wino_fwd_kernel<ST_, AB_, DB_>), dim3(grid), dim3(256), lds, s, g, (const bf16_t*)in,         \
                        (const unsigned char*)ufrag, (bf16_t*)out, stats, (unsigned char*)dbg);                       \
   } while (0)
-  if (dbg) { if (!stats || abl) return IIC_ERR_ARG; WN_LAUNCH(true, 0, true); }
+  if (dbg && abl == 8) {            // phase profile: dbg = grid x 16 u64
+    if (!stats) return IIC_ERR_ARG;
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_fwd_kernel<true, 0, false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr = true;
+    }
+    hipLaunchKernelGGL((wino_fwd_kernel<true, 0, false, true>), dim3(grid), dim3(256), lds, s, g, (const bf16_t*)in,
+                       (const unsigned char*)ufrag, (bf16_t*)out, stats, (unsigned char*)dbg);
+  } else if (dbg) { if (!stats || abl) return IIC_ERR_ARG; WN_LAUNCH(true, 0, true); }
   else if (!stats) { if (abl) return IIC_ERR_ARG; WN_LAUNCH(false, 0, false); }
   else switch (abl) {
     case 0: WN_LAUNCH(true, 0, false); break;

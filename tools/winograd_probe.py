@@ -117,15 +117,25 @@ def run_layer(L, name, N, iters, dev, dbg):
   border_clean = bool((yw[:, 0].abs().max() == 0) & (yw[:, -1].abs().max() == 0) & (yw[:, :, 0].abs().max() == 0) & (yw[:, :, -1].abs().max() == 0))
   whole = (yw.float() - yd.float()).abs().max().item()
   sw, sd = ops.stats_decode(st_w, C), ops.stats_decode(st_d, C)
-  st_rel = ((sw - sd).abs() / (sd.abs() + 1e-3)).max().item()
+  cnt_px = float(N * H * H)
+  mean_w, mean_d = sw[0] / cnt_px, sd[0] / cnt_px
+  var_w, var_d = sw[1] / cnt_px - mean_w ** 2, sd[1] / cnt_px - mean_d ** 2
+  # BatchNorm statistics as their consumer sees them: mean shift in units of the channel's std, variance ratio
+  st_rel = max(((mean_w - mean_d).abs() / var_d.sqrt()).max().item(), (var_w / var_d - 1).abs().max().item())
+  # each kernel's statistics against the sums of its own stored (bf16-rounded) outputs
+  def self_check(y, st):
+    yi = y[:, 1:-1, 1:-1, :].double()
+    s1, s2 = yi.sum((0, 1, 2)), (yi * yi).sum((0, 1, 2))
+    return max(((st[0] - s1).abs() / (s2.sqrt() + 1e-9)).max().item(), ((st[1] - s2).abs() / s2).max().item())
+  self_w, self_d = self_check(yw, sw), self_check(yd, sd)
   import math
   print("%s %d->%d @%d x %d images: LDS %d B | weight prep vs torch: max diff %.2e, differing bf16 %.4f%%" % (name, C, C, H, N, lds, prep_diff, 100 * prep_bits))
   print("  max|y| %.3f | vs fp64 conv (bf16 weights): winograd max %.3e = 2^%.2f max|y| rms %.3e | direct max %.3e rms %.3e" % (
     mx, ew_b[0], math.log2(max(ew_b[0], 1e-30) / mx), ew_b[1], ed_b[0], ed_b[1]))
   print("  vs fp64 conv (fp32 master weights): winograd max %.3e rms %.3e | direct max %.3e rms %.3e" % (ew_f[0], ew_f[1], ed_f[0], ed_f[1]))
-  print("  winograd vs direct over all %d images: max |diff| %.3e | border untouched %s | BatchNorm sums rel diff %.2e" % (N, whole, border_clean, st_rel))
-  ok = ew_b[0] <= 2.0 ** -6 * mx and border_clean and st_rel < 2e-2
-  print("  PARITY %s (gate: max error <= 2^-6 max|y| = %.3e)" % ("ok" if ok else "FAILED", 2.0 ** -6 * mx))
+  print("  winograd vs direct over all %d images: max |diff| %.3e | border untouched %s | BatchNorm mean (in std) / variance (ratio) diff %.2e | statistics vs own stored outputs: winograd %.2e direct %.2e" % (N, whole, border_clean, st_rel, self_w, self_d))
+  ok = ew_b[0] <= 2.0 ** -6 * mx and border_clean and st_rel < 1e-2 and self_w < max(1e-2, 1.5 * self_d)
+  print("  PARITY %s (gate: max error <= 2^-6 max|y| = %.3e; statistics no further from the stored outputs than the direct kernel's)" % ("ok" if ok else "FAILED", 2.0 ** -6 * mx))
   if dbg or not ok:
     decode_checkpoints(L, name, x, w, uf, N, H, C, dev, wino)
   # ---- timing, interleaved twice ----
@@ -138,11 +148,32 @@ def run_layer(L, name, N, iters, dev, dbg):
   for a in (1, 2, 3, 4, 7):
     abls[a] = timeit(lambda: wino(abl=a), iters)
   t_w, t_d = min(tw), min(td)
+  phase_profile(L, name, N, H, C, dev, wino)
   print("  TIME direct %.1f us (%.0f TF/s)  winograd %.1f us (%.0f TF/s direct-equivalent)  speed-up %.2fx  | runs direct %s wino %s" % (
     t_d, flops / t_d / 1e6, t_w, flops / t_w / 1e6, t_d / t_w, ["%.1f" % v for v in td], ["%.1f" % v for v in tw]))
   print("  ablations (us): no input transform %.1f | no main MFMAs %.1f | neither %.1f | no stage-2 epilogue %.1f | loads + barriers only %.1f" % (
     abls[1], abls[2], abls[3], abls[4], abls[7]))
   return {"name": name, "t_direct": t_d, "t_wino": t_w, "count": cnt, "ok": ok}
+
+
+def phase_profile(L, name, N, H, C, dev, wino):
+  """s_memtime sums of wave 0 of every workgroup (kernel template PROF): where a workgroup's cycles go."""
+  TH = (H + 1) // 2
+  grid = ((N * TH * TH + 63) // 64) * (C // 64)
+  buf = torch.zeros(grid * 16, dtype=torch.int64, device=dev)
+  wino(abl=8, dbgbuf=buf)
+  torch.cuda.synchronize()
+  q = buf.cpu().reshape(grid, 16).double()
+  ks = q[:, 9].mean().item()
+  m = q.mean(0)
+  rt = q[:, 10]
+  span_us = (rt.max() - rt.min()).item() / 100.0          # s_memrealtime: 100 MHz
+  names = ["set-up", "prologue", "top wait+barrier", "issue+A latency", "main MFMAs", "transform", "stage 1", "stage 2"]
+  per_step = {2: m[2].item() / (ks + 1), 3: m[3].item() / ks, 4: m[4].item() / ks, 5: m[5].item() / ks}
+  print("  PROF (cycles per workgroup, mean of %d; %d k-steps): %s | whole %.0f" % (
+    grid, int(ks), ", ".join("%s %.0f" % (names[i], m[i].item()) for i in range(8)), m[8].item()))
+  print("       per k-step: top wait+barrier %.0f, issue+A latency %.0f, main MFMAs %.0f (floor 512), transform %.0f (floor 512) | last-end minus first-end %.1f us" % (
+    per_step[2], per_step[3], per_step[4], per_step[5], span_us))
 
 
 def decode_checkpoints(L, name, x, w, uf, N, H, C, dev, wino):
