@@ -9,7 +9,12 @@ import os
 from ctypes import POINTER, Structure, c_double, c_float, c_int, c_int32, c_long, c_longlong, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libiic_hip.so")
+# Two flavours of the same sources (iic_amd/csrc/Makefile): libiic_hip.so, the product -- exports exactly the C ABI of
+# include/iic_hip.h, every measurement switch a compile-time constant -- and libiic_hip_dbg.so (`make dbg`), the same code
+# with the iic_debug_* switches compiled in.  IIC_HIP_LIB=dbg selects the instrumented one for a whole process (tests
+# marked `hooks`, tools/*.py); nothing in the product path depends on it.
+HAS_HOOKS = os.environ.get("IIC_HIP_LIB", "") == "dbg"
+LIB_PATH = os.path.join(_HERE, "libiic_hip_dbg.so" if HAS_HOOKS else "libiic_hip.so")
 
 IIC_MAX_TAPS = 32
 IIC_STAT_STRIPES = 32
@@ -57,10 +62,6 @@ _SIGNATURES = {
   "iic_conv_igemm_frag_supported": (c_int, [POINTER(ConvGeom)]),
   "iic_conv_igemm_frag": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P, _P, _P, c_int, _P]),
   "iic_conv_igemm_red_supported": (c_int, [POINTER(ConvGeom)]),
-  "iic_conv_igemm_apply_supported": (c_int, [POINTER(ConvGeom)]),
-  "iic_conv_igemm_frag_apply": (c_int, [POINTER(ConvGeom), _P, _P, c_int, _P, _P, _P, _P]),
-  "iic_conv_wgrad_apply_supported": (c_int, [POINTER(ConvGeom)]),
-  "iic_conv_wgrad_apply": (c_int, [POINTER(ConvGeom), _P, _P, c_int, _P, _P, c_int, _P]),
   "iic_conv_igemm_frag_red": (c_int, [POINTER(ConvGeom), _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P]),
   "iic_weight_prep_frag": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
   "iic_weight_prep_multi_blocks": (c_long, [c_int, c_int, c_int]),
@@ -74,10 +75,6 @@ _SIGNATURES = {
   "iic_bn_bwd_finalize": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_long, _P]),
   "iic_bn_bwd_apply": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
   "iic_stem_stats": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
-  "iic_stem_gram_supported": (c_int, [c_int, c_int, c_int]),
-  "iic_stem_gram_bytes": (c_long, [c_int]),
-  "iic_stem_gram": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
-  "iic_stem_gram_finalize": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_long, c_long, c_float, c_float, _P]),
   "iic_stem_apply_pool": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
   "iic_stem_bwd_reduce": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
   "iic_stem_wgrad_partial_floats": (c_long, []),
@@ -149,7 +146,7 @@ def lib():
   if _lib is None:
     if not os.path.exists(LIB_PATH):
       raise IICLibraryError(
-        "libiic_hip.so not found at %s -- build the HIP extension first "
+        "%s not found -- build the HIP extension first "
         "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU/PyTorch "
         "fallback for the IIC hot path." % LIB_PATH)
     h = ctypes.CDLL(LIB_PATH)
@@ -160,12 +157,14 @@ def lib():
         raise IICLibraryError("libiic_hip.so lacks symbol %s" % name) from e
       fn.restype = res
       fn.argtypes = args
-    # A/B switches for measurements, e.g. IIC_DEBUG="iic_debug_bd_ms=2,iic_debug_p64_red=1": calls the
-    # named iic_debug_* setters (int argument) of the library once at load.  Unset = defaults.
+    # A/B switches for measurements (instrumented library only), e.g. IIC_HIP_LIB=dbg IIC_DEBUG="iic_debug_bd_ms=2":
+    # calls the named iic_debug_* setters (int argument) once at load.  Unset = defaults.
     for item in filter(None, os.environ.get("IIC_DEBUG", "").split(",")):
       name, _, val = item.partition("=")
       if not name.startswith("iic_debug_"):
         raise IICLibraryError("IIC_DEBUG: %r is not an iic_debug_* switch" % name)
+      if not HAS_HOOKS:
+        raise IICLibraryError("IIC_DEBUG needs the instrumented library: IIC_HIP_LIB=dbg (make -C iic_amd/csrc dbg)")
       getattr(h, name)(int(val or 1))
     _lib = h
   return _lib

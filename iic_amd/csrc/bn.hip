@@ -498,8 +498,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply2_kernel(
 // (tools/bn_perf.py: every reduce, and the apply unless it reads the activation tensor for its mask
 // -- with 3 reads + 1 write per element the deeper prefetch costs occupancy: 161 vs 158 us at
 // layer1, against 122 vs 145 us for the mask-from-y apply); 2: second generation everywhere (tests).
+#ifdef IIC_DEBUG_HOOKS
 static int g_bn_v2 = 1;
 static int g_bn_v2_blocks = 1024;
+#else
+static constexpr int g_bn_v2 = 1;
+static constexpr int g_bn_v2_blocks = 1024;
+#endif
 
 // chunk of pixels per block: a multiple of 2*PL so that every thread's pair loop stays aligned
 // reduce != 0: the reduction kernels end with 2C (3C) integer atomics per block into the exact
@@ -657,10 +662,12 @@ int iic_bn_bwd_apply(const void* dout, const void* act, const void* y, const flo
   return iic_launch_status();
 }
 
-/* A/B switches for tools/bn_perf.py and the kernel-generation test (not part of the ABI contract) */
-void iic_debug_bn_v2(int on, int blocks) {
+#ifdef IIC_DEBUG_HOOKS
+/* A/B switches for tools/bn_perf.py and the kernel-generation test (instrumented library only) */
+IIC_HOOK void iic_debug_bn_v2(int on, int blocks) {
   g_bn_v2 = on;
   if (blocks > 0) g_bn_v2_blocks = blocks;
 }
+#endif
 
 }  // extern "C"

@@ -9,6 +9,23 @@
 #define IIC_ERR_LAUNCH (-2)
 #define IIC_ERR_UNSUPPORTED (-3)
 
+// ------------------------------------------------------------------------------------------
+// Measurement switches.  The product library (libiic_hip.so) has NO mutable global state besides its
+// kernel-attribute caches: every A/B switch below is a compile-time constant there and no iic_debug_*
+// symbol exists.  `make dbg` builds the same sources with -DIIC_DEBUG_HOOKS into libiic_hip_dbg.so, where
+// the switches are variables with exported setters (tests marked `hooks`, tools/*.py; IIC_HIP_LIB=dbg).
+// ------------------------------------------------------------------------------------------
+#ifdef IIC_DEBUG_HOOKS
+#define IIC_HOOK extern "C" __attribute__((visibility("default")))
+#define IIC_SWITCH(var, dflt, setter) \
+  static int var = dflt;              \
+  IIC_HOOK void setter(int v) { var = v; }
+IIC_HOOK int iic_debug_get_ablate(void);
+#else
+#define IIC_SWITCH(var, dflt, setter) static constexpr int var = dflt;
+static inline constexpr int iic_debug_get_ablate(void) { return 0; }
+#endif
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;

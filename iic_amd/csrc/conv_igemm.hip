@@ -281,11 +281,11 @@ __global__ void weight_prep_kernel(const float* __restrict__ w, bf16_t* __restri
   }
 }
 
-static int g_ablate = 0;
-static int g_force_bm = 0;
-extern "C" void iic_debug_set_ablate(int v) { g_ablate = v; }
-extern "C" int iic_debug_get_ablate(void) { return g_ablate; }
-extern "C" void iic_debug_force_bm(int v) { g_force_bm = v; }
+IIC_SWITCH(g_ablate, 0, iic_debug_set_ablate)
+IIC_SWITCH(g_force_bm, 0, iic_debug_force_bm)
+#ifdef IIC_DEBUG_HOOKS
+IIC_HOOK int iic_debug_get_ablate(void) { return g_ablate; }
+#endif
 
 static int pick_bn(int Cout) { return (Cout % 128 == 0) ? 128 : 64; }
 

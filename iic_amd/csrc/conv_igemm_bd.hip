@@ -482,7 +482,6 @@ __global__ void weight_prep_frag_kernel(const float* __restrict__ w, bf16_t* __r
   }
 }
 
-extern "C" int iic_debug_get_ablate(void);
 // conv_igemm_p64.hip: persistent DMA-fed kernel for the 64 -> 64 channel 3x3 layers
 int iic_p64_supported(const iic_conv_geom* g);
 int iic_p64_launch(const iic_conv_geom* g, const void* in, const void* wfrag, void* out, float* stats,
@@ -494,23 +493,23 @@ int iic_pw_supported(const iic_conv_geom* g);
 int iic_pw_launch(const iic_conv_geom* g, const void* in, const void* wfrag, void* out, float* stats,
                   const void* res_grad, const void* res_act, int accumulate, const void* red_y,
                   const float* red_coef, const void* red_y2, float* red_stats, float* red_stats2, void* stream);
-static int g_bd_one_wg = 1;      // also take LDS footprints that leave room for only one workgroup per CU
-                                 // (large-image segmentation layers: still 15-20 % faster than conv_igemm_kernel)
-extern "C" void iic_debug_bd_one_wg(int v) { g_bd_one_wg = v; }
-static int g_p64_enabled = 1;
-extern "C" void iic_debug_enable_p64(int v) { g_p64_enabled = v; }
-static int g_p64_red = 0;        // 1: allow the fused reduction in the persistent kernel (tests, A/B)
-extern "C" void iic_debug_p64_red(int v) { g_p64_red = v; }
+// also take LDS footprints that leave room for only one workgroup per CU (large-image segmentation layers: still
+// 15-20 % faster than conv_igemm_kernel)
+IIC_SWITCH(g_bd_one_wg, 1, iic_debug_bd_one_wg)
+IIC_SWITCH(g_p64_enabled, 1, iic_debug_enable_p64)
+IIC_SWITCH(g_p64_red, 0, iic_debug_p64_red)      // 1: allow the fused reduction in the persistent kernel (tests, A/B)
 
 extern "C" {
 
+#ifdef IIC_DEBUG_HOOKS
 static unsigned long long* g_bd_prof = nullptr;   // iic_debug_set_ablate(128): per-workgroup phase stamps go here
-extern "C" void iic_debug_bd_prof(void* buf) { g_bd_prof = (unsigned long long*)buf; }
-extern "C" int iic_debug_bd_prof_slots(void) { return BD_PROF_SLOTS; }
-static int g_bd_stagger = 0;    // cycles per tap by which odd-slot workgroups of the first round start late (0 = off)
-extern "C" void iic_debug_bd_stagger(int v) { g_bd_stagger = v; }
-static int g_bd_dma = 1;        // 1: LDS-DMA patch loads (128-B swizzled rows), 0: register-staged (144-B rows)
-extern "C" void iic_debug_bd_dma(int v) { g_bd_dma = v; }
+IIC_HOOK void iic_debug_bd_prof(void* buf) { g_bd_prof = (unsigned long long*)buf; }
+IIC_HOOK int iic_debug_bd_prof_slots(void) { return BD_PROF_SLOTS; }
+#else
+static constexpr unsigned long long* g_bd_prof = nullptr;
+#endif
+IIC_SWITCH(g_bd_stagger, 0, iic_debug_bd_stagger)   // cycles per tap by which odd-slot workgroups of the first round start late (0 = off)
+IIC_SWITCH(g_bd_dma, 1, iic_debug_bd_dma)           // 1: LDS-DMA patch loads (128-B swizzled rows), 0: register-staged (144-B rows)
 
 // ms: 4 = 256-row tiles, 2 = 128-row tiles (the kernel's MS)
 // (wn: the kernel's WN -- 1 = 64-cout tiles of ms*128 rows)
@@ -532,11 +531,10 @@ static long bd_row_pin_host(const iic_conv_geom* g, long m) {
   const long y = r / g->MX, x = r - y * g->MX;
   return (n * g->in_Hp + y * g->sy + g->oy) * g->in_Wp + x * g->sx + g->ox;
 }
-static int g_bd_mixed = 0;      // 1: last partial round in smaller tiles. Per launch alone -5 % (layer 2 / 3), but inside the
-                                // two-stream step the other view already fills those tails: 38.0 vs 37.7 ms/step (r03 A/B) => off
-extern "C" void iic_debug_bd_mixed(int v) { g_bd_mixed = v; }
-static int g_bd_dense_key = 1;  // 0: swizzle key from the raw pixel index (A/B: conflicts at row ends)
-extern "C" void iic_debug_bd_dense_key(int v) { g_bd_dense_key = v; }
+// 1: last partial round in smaller tiles. Per launch alone -5 % (layer 2 / 3), but inside the two-stream step the other
+// view already fills those tails: 38.0 vs 37.7 ms/step (r03 A/B) => off
+IIC_SWITCH(g_bd_mixed, 0, iic_debug_bd_mixed)
+IIC_SWITCH(g_bd_dense_key, 1, iic_debug_bd_dense_key)   // 0: swizzle key from the raw pixel index (A/B: conflicts at row ends)
 static long bd_key_bytes(const iic_conv_geom* g, int ms, int wn = 2) {    // swizzle-key table of the DMA patch (1 B / row)
   const int jskip = (g_bd_dense_key && g->ntaps > 1 && g->sx == 1 && ((g->in_Wp - g->MX) & 1) == 0) ? g->in_Wp - g->MX : 0;
   return (g_bd_dma && jskip != 0) ? (((long)(ms * 32 * (4 / wn) >= 192 ? g->NP256 : g->NP) + 15) & ~15L) : 0;
@@ -545,15 +543,13 @@ static long bd_lds_total(const iic_conv_geom* g, int ms, int wn = 2) {
   return bd_lds_a(g, ms, wn) + 2L * ms * 32 * (4 / wn) * 4 + 4L * BD_BN * 4 + bd_key_bytes(g, ms, wn);
 }
 // 64-cout tiles (kernel WN = 1, 256 rows): layers whose Cout is an odd multiple of 64
-static int g_bd_w1 = 1;
-extern "C" void iic_debug_bd_w1(int v) { g_bd_w1 = v; }
+IIC_SWITCH(g_bd_w1, 1, iic_debug_bd_w1)
 static bool bd_w1_ok(const iic_conv_geom* g) {
   return g_bd_w1 && g_bd_dma && g->Cout % 64 == 0 && g->Cout % BD_BN != 0 && g->ntaps > 1 && g->NP256 > 0 &&
          bd_lds_total(g, 2, 1) <= 160 * 1024;
 }
 // Tile height per geometry.  g_bd_ms: 0 = heuristic, 2 / 4 = forced (A/B runs, tests).
-static int g_bd_ms = 0;
-extern "C" void iic_debug_bd_ms(int v) { g_bd_ms = v; }
+IIC_SWITCH(g_bd_ms, 0, iic_debug_bd_ms)
 static int bd_pick_ms(const iic_conv_geom* g) {
   const bool ok4 = (g->ntaps == 1 || g->NP256 > 0) && bd_lds_total(g, 4) <= (g_bd_one_wg ? 160 : 80) * 1024;
   const bool ok2 = (g->ntaps == 1 || g->NP > 0) && bd_lds_total(g, 2) <= 160 * 1024;
@@ -567,27 +563,6 @@ static int bd_pick_ms(const iic_conv_geom* g) {
     if (((M + 255) / 256) * (g->Cout / BD_BN) * 2 <= 512) return 2;
   }
   return ok4 ? 4 : (ok2 ? 2 : 0);
-}
-
-int iic_pw_apply_supported(const iic_conv_geom* g);
-int iic_pw_launch_apply(const iic_conv_geom* g, const void* in, const float* in_coef, int in_pad, int apply_relu,
-                        const void* wfrag, void* out, float* stats, const void* res_grad, const void* res_act,
-                        int accumulate, const void* red_y, const float* red_coef, const void* red_y2,
-                        float* red_stats, float* red_stats2, void* stream);
-
-/* 1 if iic_conv_igemm_frag_apply can run this geometry. */
-int iic_conv_igemm_apply_supported(const iic_conv_geom* g) {
-  return g && g_bd_dma && iic_debug_get_ablate() == 0 && iic_pw_apply_supported(g);
-}
-
-/* Forward convolution whose input is relu(scale[c] * in + shift[c]) on the interior of `in` (0 on its border of width
- * in_pad): conv(bn-relu(in)) without the activation tensor. */
-int iic_conv_igemm_frag_apply(const iic_conv_geom* g, const void* in, const float* in_coef, int in_pad,
-                              const void* wfrag, void* out, float* stats, void* stream) {
-  if (!g || !in || !in_coef || !wfrag || !out || in_pad < 0) return IIC_ERR_ARG;
-  if (!iic_conv_igemm_apply_supported(g)) return IIC_ERR_UNSUPPORTED;
-  return iic_pw_launch_apply(g, in, in_coef, in_pad, 1, wfrag, out, stats, nullptr, nullptr, 0, nullptr, nullptr,
-                             nullptr, nullptr, nullptr, stream);
 }
 
 /* 1 if iic_conv_igemm_frag can run this geometry (else use iic_conv_igemm). */

@@ -343,15 +343,15 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_p64_kernel(
   }
 }
 
-extern "C" int iic_debug_get_ablate(void);
+#ifdef IIC_DEBUG_HOOKS
 static unsigned long long* g_p64_prof = nullptr;   // ablate 8: per-workgroup phase cycle sums go here
-extern "C" void iic_debug_p64_prof(void* buf) { g_p64_prof = (unsigned long long*)buf; }
-static int g_p64_spread = 1; // 1: plain output stores spread over the K loop's taps (see the kernel)
-extern "C" void iic_debug_p64_spread(int v) { g_p64_spread = v; }
-static int g_p64_wide = 0;   // 1: four "wide" waves per workgroup (64 x 64 wave tiles), 0: eight 64 x 32 waves
-extern "C" void iic_debug_p64_wide(int v) { g_p64_wide = v; }
-static int g_p64_grid = 0;   // tests: force a small persistent grid (many tiles per workgroup)
-extern "C" void iic_debug_p64_grid(int v) { g_p64_grid = v; }
+IIC_HOOK void iic_debug_p64_prof(void* buf) { g_p64_prof = (unsigned long long*)buf; }
+#else
+static constexpr unsigned long long* g_p64_prof = nullptr;
+#endif
+IIC_SWITCH(g_p64_spread, 1, iic_debug_p64_spread)   // 1: plain output stores spread over the K loop's taps (see the kernel)
+IIC_SWITCH(g_p64_wide, 0, iic_debug_p64_wide)       // 1: four "wide" waves per workgroup (64 x 64 wave tiles), 0: eight 64 x 32 waves
+IIC_SWITCH(g_p64_grid, 0, iic_debug_p64_grid)       // tests: force a small persistent grid (many tiles per workgroup)
 
 static int p64_num_cus() {
   if (g_p64_grid > 0) return g_p64_grid;

@@ -59,7 +59,6 @@ struct pw_args {
   pw_div d_rows;       // by rows per image (g.MP or the plane)
   pw_div d_mx;         // by g.MX
   pw_div d_wp;         // by g.in_Wp
-  pw_div d_hp;         // by g.in_Hp
   int rows_per_img;    // g.MP > 0 ? g.MP : plane
   int plane;           // g.MY * g.MX
   int jskip;           // dense-count skip per image row (0: key from the raw pixel index)
@@ -70,8 +69,6 @@ struct pw_args {
   int in_pixels;       // N * in_Hp * in_Wp
   int pad_rows;        // 1: g.MP pads the per-image row count (rows >= plane are invalid)
   int dbg;             // timing experiments (results WRONG): 1 = every B fragment from the same 8 KB (L1-hot)
-  int in_pad;          // APPLY: zero-border width of the input PT tensor
-  int apply_relu;      // APPLY: 1 = relu(scale * x + shift), 0 = scale * x + shift (and no border zeroing: identity tests)
 };
 
 // B fragment: 16 bytes per lane from (scalar base + per-lane offset + immediate); inline asm so that hipcc's
@@ -211,15 +208,9 @@ __device__ __forceinline__ void pw_store_pass(const bf16_t* sW, int u0, const in
 // PROF (results correct): wave 0 sums s_memtime per phase over its tiles into prof[blockIdx][PW_PROF_SLOTS]:
 // 0 waiting for the patch (tile top), 1 K loop incl. boundaries, 2 boundaries, 3 epilogue, 4 everything, 5 tiles,
 // 6 boundary count, 7 XCC id
-// APPLY: the convolution's input is act(scale[c] * in + shift[c]) on the interior of `in` and 0 on its border -- the
-// BatchNorm + ReLU that sits between two convolutions (residual.py:19-23: conv1 -> bn1 -> relu -> conv2), applied to
-// the patch in LDS right after its DMA has landed instead of in a separate HBM pass that reads the raw tensor and writes
-// the activation (bn_apply_kernel).  A thread owns 8 channels (its coefficients sit in 16 registers per chunk) and walks
-// the patch rows; bit 3 of a row's key marks border pixels.
-template <int RED, bool PROF, bool APPLY>
+template <int RED, bool PROF>
 __global__ __launch_bounds__(PW_THREADS, 2) void conv_igemm_pw_kernel(
-    const iic_conv_geom g, const pw_args A, const bf16_t* __restrict__ in, const float* __restrict__ in_coef,
-    const unsigned char* __restrict__ wfrag,
+    const iic_conv_geom g, const pw_args A, const bf16_t* __restrict__ in, const unsigned char* __restrict__ wfrag,
     bf16_t* __restrict__ out, float* __restrict__ stats, const bf16_t* __restrict__ res_grad,
     const bf16_t* __restrict__ res_act, int accumulate, const bf16_t* __restrict__ red_y,
     const float* __restrict__ red_coef, const bf16_t* __restrict__ red_y2, float* __restrict__ red_stats,
@@ -289,11 +280,7 @@ __global__ __launch_bounds__(PW_THREADS, 2) void conv_igemm_pw_kernel(
       const int p = p_lo_t + r;
       const int prow = pw_divide(p, A.d_wp);
       const int D = p - A.jskip * prow;
-      int key = (D >> 1) & 7;
-      if (APPLY) {
-        const int xx = p - prow * g.in_Wp, yy = prow - pw_divide(prow, A.d_hp) * g.in_Hp;
-        if (xx < A.in_pad || xx >= g.in_Wp - A.in_pad || yy < A.in_pad || yy >= g.in_Hp - A.in_pad) key |= 8;
-      }
+      const int key = (D >> 1) & 7;
       s_key[kb * PW_KEYS + r] = (unsigned char)key;
     }
   };
@@ -307,34 +294,6 @@ __global__ __launch_bounds__(PW_THREADS, 2) void conv_igemm_pw_kernel(
       p = p < A.in_pixels ? p : A.in_pixels - 1;
       pw_dma16(in + (p * g.Cin + c0 + ls * 8),
                (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)(blk * 1024))));
-    }
-  };
-
-  // APPLY: in-LDS transform of the landed patch (all waves' pieces must have landed: callers put a barrier in front)
-  auto apply_patch = [&](int c0, int kb) {
-    const int lg = tid & 7;
-    float sc[8], sh[8];
-    {
-      const float4* c4 = reinterpret_cast<const float4*>(in_coef + c0 + lg * 8);
-      const float4* h4 = reinterpret_cast<const float4*>(in_coef + g.Cin + c0 + lg * 8);
-      const float4 a0 = c4[0], a1 = c4[1], b0 = h4[0], b1 = h4[1];
-      sc[0] = a0.x; sc[1] = a0.y; sc[2] = a0.z; sc[3] = a0.w; sc[4] = a1.x; sc[5] = a1.y; sc[6] = a1.z; sc[7] = a1.w;
-      sh[0] = b0.x; sh[1] = b0.y; sh[2] = b0.z; sh[3] = b0.w; sh[4] = b1.x; sh[5] = b1.y; sh[6] = b1.z; sh[7] = b1.w;
-    }
-    const int nrow = nblk * 8;
-    for (int r = tid >> 3; r < nrow; r += PW_THREADS / 8) {
-      const int key = s_key[kb * PW_KEYS + r];
-      uint4* cell = reinterpret_cast<uint4*>(sA + r * 128 + ((lg ^ (key & 7)) << 4));
-      uint4 v = *cell;
-      uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float lo = bf16lo(w[i]) * sc[2 * i] + sh[2 * i], hi = bf16hi(w[i]) * sc[2 * i + 1] + sh[2 * i + 1];
-        if (A.apply_relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
-        w[i] = pack_bf16x2(lo, hi);
-      }
-      const bool border = A.apply_relu && (key & 8);
-      *cell = border ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(w[0], w[1], w[2], w[3]);
     }
   };
 
@@ -399,11 +358,6 @@ __global__ __launch_bounds__(PW_THREADS, 2) void conv_igemm_pw_kernel(
     }
     asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (APPLY) {
-      apply_patch(0, kb);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    }
     if (PROF) {
       t1 = __builtin_readcyclecounter(); t_wait += t1 - t0; t0 = t1;
 #pragma unroll
@@ -496,11 +450,6 @@ __global__ __launch_bounds__(PW_THREADS, 2) void conv_igemm_pw_kernel(
         dma_patch(p_lo, chunk_n * 64, kb);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (APPLY) {
-          apply_patch(chunk_n * 64, kb);
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_barrier();
-        }
         if (PROF) { t_b += __builtin_readcyclecounter() - t1; ++n_b; }
 #pragma unroll
         for (int ms = 0; ms < 4; ++ms) a[0][ms] = lds16(pa[Q][ms] + ka[Q][ms]);
@@ -664,20 +613,19 @@ __global__ __launch_bounds__(PW_THREADS, 2) void conv_igemm_pw_kernel(
   }
 }
 
-static int g_pw_enabled = 1;
-extern "C" void iic_debug_enable_pw(int v) { g_pw_enabled = v; }
-static int g_pw_stagger = 0;         // start offset (cycles) of the workgroups in odd threadgroup slots (A/B)
-extern "C" void iic_debug_pw_stagger(int v) { g_pw_stagger = v; }
-static int g_pw_min_tiles10 = 25;    // take a launch only if it has >= this many tiles per workgroup slot (x 10)
-extern "C" void iic_debug_pw_min_tiles10(int v) { g_pw_min_tiles10 = v; }
-static int g_pw_dbg = 0;
-extern "C" void iic_debug_pw_dbg(int v) { g_pw_dbg = v; }
-static int g_pw_one_wg = 0;          // 1: pad the LDS request so that only one workgroup fits a CU (A/B: a wave alone on its SIMD)
-extern "C" void iic_debug_pw_one_wg(int v) { g_pw_one_wg = v; }
+IIC_SWITCH(g_pw_enabled, 1, iic_debug_enable_pw)
+IIC_SWITCH(g_pw_stagger, 0, iic_debug_pw_stagger)             // start offset (cycles) of the workgroups in odd threadgroup slots (A/B)
+IIC_SWITCH(g_pw_min_tiles10, 25, iic_debug_pw_min_tiles10)    // take a launch only if it has >= this many tiles per workgroup slot (x 10)
+IIC_SWITCH(g_pw_dbg, 0, iic_debug_pw_dbg)                     // timing experiment (results WRONG): 1 = every B fragment from the same 8 KB
+IIC_SWITCH(g_pw_one_wg, 0, iic_debug_pw_one_wg)               // 1: pad the LDS request so that only one workgroup fits a CU (A/B)
+#ifdef IIC_DEBUG_HOOKS
 static unsigned long long* g_pw_prof = nullptr;
-extern "C" void iic_debug_pw_prof(void* buf) { g_pw_prof = (unsigned long long*)buf; }
-extern "C" int iic_debug_pw_prof_slots(void) { return PW_PROF_SLOTS; }
-extern "C" int iic_debug_pw_grid(const iic_conv_geom* g);
+IIC_HOOK void iic_debug_pw_prof(void* buf) { g_pw_prof = (unsigned long long*)buf; }
+IIC_HOOK int iic_debug_pw_prof_slots(void) { return PW_PROF_SLOTS; }
+IIC_HOOK int iic_debug_pw_grid(const iic_conv_geom* g);
+#else
+static constexpr unsigned long long* g_pw_prof = nullptr;
+#endif
 
 static long pw_lds_bytes(const iic_conv_geom* g) {
   const long patch = ((long)g->NP256 * 128 + 1023) & ~1023L;
@@ -692,7 +640,6 @@ int iic_pw_supported(const iic_conv_geom* g) {
   if (g_pw_min_tiles10 > 0 && ((M + 255) / 256) * (g->Cout / 128) * 10 < (long)g_pw_min_tiles10 * 2 * pw_num_cus()) return 0;
   return 1;
 }
-// (the shape alone: launches with the fused input transform come here whatever their size)
 static int pw_supported_shape(const iic_conv_geom* g) {
   if (!g) return 0;
   if (g->ntaps < 2 || g->ntaps > IIC_MAX_TAPS || g->Cin % 64 != 0 || g->Cout % 128 != 0) return 0;
@@ -704,7 +651,6 @@ static int pw_supported_shape(const iic_conv_geom* g) {
   if (M <= 0 || M + 256 >= (1L << 31) || (long)g->N * g->in_Hp * g->in_Wp >= (1L << 31)) return 0;
   return 1;
 }
-extern "C" int iic_pw_apply_supported(const iic_conv_geom* g) { return pw_supported_shape(g); }
 
 static int pw_num_cus() {
   static int n = 0;
@@ -732,41 +678,14 @@ static int pw_grid(const iic_conv_geom* g, long lds) {
   if (gx < 1) gx = 1;
   return gx * 8;
 }
-extern "C" int iic_debug_pw_grid(const iic_conv_geom* g) { return g ? pw_grid(g, pw_lds_bytes(g)) : 0; }
-
-extern "C" int iic_pw_launch_apply(const iic_conv_geom* g, const void* in, const float* in_coef, int in_pad, int apply_relu,
-                        const void* wfrag, void* out, float* stats, const void* res_grad, const void* res_act,
-                        int accumulate, const void* red_y, const float* red_coef, const void* red_y2,
-                        float* red_stats, float* red_stats2, void* stream);
+#ifdef IIC_DEBUG_HOOKS
+IIC_HOOK int iic_debug_pw_grid(const iic_conv_geom* g) { return g ? pw_grid(g, pw_lds_bytes(g)) : 0; }
+#endif
 
 int iic_pw_launch(const iic_conv_geom* g, const void* in, const void* wfrag, void* out, float* stats,
                   const void* res_grad, const void* res_act, int accumulate, const void* red_y,
                   const float* red_coef, const void* red_y2, float* red_stats, float* red_stats2, void* stream) {
-  return iic_pw_launch_apply(g, in, nullptr, 0, 0, wfrag, out, stats, res_grad, res_act, accumulate, red_y, red_coef,
-                             red_y2, red_stats, red_stats2, stream);
-}
-
-extern "C" int iic_pw_launch_apply(const iic_conv_geom* g, const void* in, const float* in_coef, int in_pad, int apply_relu,
-                        const void* wfrag, void* out, float* stats, const void* res_grad, const void* res_act,
-                        int accumulate, const void* red_y, const float* red_coef, const void* red_y2,
-                        float* red_stats, float* red_stats2, void* stream) {
-  if (!(in_coef ? pw_supported_shape(g) : iic_pw_supported(g))) return IIC_ERR_UNSUPPORTED;
-  if (!in_coef && (g_pw_dbg & 2) && g->Cin <= 4096 && !red_y && stats) {     // timing experiment: identity apply pass on the forward launches, results unchanged
-    // (coefficients laid out [scale[Cin]][shift[Cin]]: the identity buffer is all ones then all zeros only for
-    //  Cin = 4096, so it is addressed as scale = buf, shift = buf + Cin through a per-Cin view)
-    static float* views[65] = {nullptr};
-    const int slot = g->Cin / 64;
-    if (!views[slot]) {
-      float* host = (float*)malloc(sizeof(float) * 2 * g->Cin);
-      for (int i = 0; i < g->Cin; ++i) { host[i] = 1.f; host[g->Cin + i] = 0.f; }
-      if (hipMalloc(&views[slot], sizeof(float) * 2 * g->Cin) == hipSuccess)
-        (void)hipMemcpy(views[slot], host, sizeof(float) * 2 * g->Cin, hipMemcpyHostToDevice);
-      free(host);
-    }
-    in_coef = views[slot];
-    in_pad = 0;
-    apply_relu = 0;
-  }
+  if (!iic_pw_supported(g)) return IIC_ERR_UNSUPPORTED;
   const long M = igemm_rows_host(g);
   pw_args A;
   A.plane = g->MY * g->MX;
@@ -774,9 +693,6 @@ extern "C" int iic_pw_launch_apply(const iic_conv_geom* g, const void* in, const
   A.d_rows = pw_make_div(A.rows_per_img);
   A.d_mx = pw_make_div(g->MX);
   A.d_wp = pw_make_div(g->in_Wp);
-  A.d_hp = pw_make_div(g->in_Hp);
-  A.in_pad = in_pad;
-  A.apply_relu = apply_relu;
   A.jskip = (g->sx == 1 && ((g->in_Wp - g->MX) & 1) == 0) ? g->in_Wp - g->MX : 0;
   A.npix = g->NP256;
   A.patch_bytes = (int)(((long)g->NP256 * 128 + 1023) & ~1023L);
@@ -790,26 +706,25 @@ extern "C" int iic_pw_launch_apply(const iic_conv_geom* g, const void* in, const
   if (g_pw_one_wg) lds = 96 * 1024;
   const int red = red_y ? (red_y2 ? 2 : 1) : 0;
   hipStream_t s = (hipStream_t)stream;
-#define PW_LAUNCH(RD_, PR_, AP_)                                                                              \
+#define PW_LAUNCH(RD_, PR_)                                                                                   \
   do {                                                                                                        \
     static bool attr = false;                                                                                 \
     if (!attr) {                                                                                              \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_pw_kernel<RD_, PR_, AP_>),          \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_pw_kernel<RD_, PR_>),               \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                      \
       attr = true;                                                                                            \
     }                                                                                                         \
-    hipLaunchKernelGGL((conv_igemm_pw_kernel<RD_, PR_, AP_>), dim3(grid), dim3(PW_THREADS), lds, s, *g, A,    \
-                       (const bf16_t*)in, in_coef, (const unsigned char*)wfrag, (bf16_t*)out, stats,          \
+    hipLaunchKernelGGL((conv_igemm_pw_kernel<RD_, PR_>), dim3(grid), dim3(PW_THREADS), lds, s, *g, A,         \
+                       (const bf16_t*)in, (const unsigned char*)wfrag, (bf16_t*)out, stats,                   \
                        (const bf16_t*)res_grad, (const bf16_t*)res_act, accumulate, (const bf16_t*)red_y,     \
-                       red_coef, (const bf16_t*)red_y2, red_stats, red_stats2, g_pw_prof, g_pw_stagger);                    \
+                       red_coef, (const bf16_t*)red_y2, red_stats, red_stats2, g_pw_prof, g_pw_stagger);      \
   } while (0)
-  if (in_coef) {       // (forward launches: no fused reduction there)
-    if (red != 0) return IIC_ERR_UNSUPPORTED;
-    if (g_pw_prof) PW_LAUNCH(0, true, true); else PW_LAUNCH(0, false, true);
-  } else if (g_pw_prof) {
-    if (red == 0) PW_LAUNCH(0, true, false); else if (red == 1) PW_LAUNCH(1, true, false); else PW_LAUNCH(2, true, false);
-  } else {
-    if (red == 0) PW_LAUNCH(0, false, false); else if (red == 1) PW_LAUNCH(1, false, false); else PW_LAUNCH(2, false, false);
+#ifdef IIC_DEBUG_HOOKS
+  if (g_pw_prof) {
+    if (red == 0) PW_LAUNCH(0, true); else if (red == 1) PW_LAUNCH(1, true); else PW_LAUNCH(2, true);
+    return iic_launch_status();
   }
+#endif
+  if (red == 0) PW_LAUNCH(0, false); else if (red == 1) PW_LAUNCH(1, false); else PW_LAUNCH(2, false);
   return iic_launch_status();
 }

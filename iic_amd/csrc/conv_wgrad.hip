@@ -336,9 +336,6 @@ __global__ void probe_tr16_kernel(uint16_t* out) {
 int iic_wgrad_dma_supported(const iic_conv_geom* g);
 int iic_wgrad_dma_launch(const iic_conv_geom* g, const void* x, const void* dy, float* partials,
                          int nsplit, void* stream);
-int iic_wgrad_dma_apply_supported(const iic_conv_geom* g);
-int iic_wgrad_dma_launch_apply(const iic_conv_geom* g, const void* x, const float* x_coef, int x_pad, int relu,
-                               const void* dy, float* partials, int nsplit, void* stream);
 
 extern "C" {
 
@@ -349,8 +346,12 @@ static int wgrad_cot(const iic_conv_geom* g) { return (g->Cout % 128 == 0) ? 128
 // launch's last workgroup; 224 also writes 1/8 less split-K partial traffic.  Measured on three boxes, default step,
 // interleaved (tools/ab_env.sh, profiles/r04_wgrad_target_wgs.txt): 224 / 192 / 128 are 0.2-0.35 ms per step faster than 256,
 // 160 and 96 slower (K-tile quantisation), 64 much slower.
+#ifdef IIC_DEBUG_HOOKS
 static int g_wgrad_target_wgs = 224;
-void iic_debug_wgrad_target_wgs(int v) { g_wgrad_target_wgs = v > 0 ? v : 224; }
+IIC_HOOK void iic_debug_wgrad_target_wgs(int v) { g_wgrad_target_wgs = v > 0 ? v : 224; }
+#else
+static constexpr int g_wgrad_target_wgs = 224;
+#endif
 
 int iic_conv_wgrad_nsplit(const iic_conv_geom* g) {
   const long M = igemm_rows_host(g);
@@ -398,20 +399,6 @@ int iic_conv_wgrad(const iic_conv_geom* g, const void* x, const void* dy, float*
   if (use_tr) { if (ga) WGRAD_LAUNCH2(true, true); else WGRAD_LAUNCH2(true, false); }
   else        { if (ga) WGRAD_LAUNCH2(false, true); else WGRAD_LAUNCH2(false, false); }
   return iic_launch_status();
-}
-
-int iic_conv_wgrad_apply_supported(const iic_conv_geom* g) {
-  if (!g || g->Cin % 64 != 0 || g->Cout % 64 != 0) return 0;
-  const long M = igemm_rows_host(g);
-  if (M >= (1L << 31) || (long)g->N * g->in_Hp * g->in_Wp >= (1L << 31)) return 0;
-  return iic_wgrad_dma_apply_supported(g);
-}
-
-int iic_conv_wgrad_apply(const iic_conv_geom* g, const void* x, const float* x_coef, int x_pad, const void* dy,
-                         float* partials, int nsplit, void* stream) {
-  if (!g || !x || !x_coef || !dy || !partials || nsplit < 1 || x_pad < 0) return IIC_ERR_ARG;
-  if (!iic_conv_wgrad_apply_supported(g)) return IIC_ERR_UNSUPPORTED;
-  return iic_wgrad_dma_launch_apply(g, x, x_coef, x_pad, 1, dy, partials, nsplit, stream);
 }
 
 int iic_conv_wgrad_reduce(const float* partials, int nsplit, int T, int Cout, int Cin, float* dW,

@@ -137,21 +137,10 @@ __device__ __forceinline__ void wd_walk_pixels(const WdWalk& w, const iic_conv_g
   pout = valid ? (n * g.out_Hp + y * g.ty + g.py) * g.out_Wp + x * g.tx + g.px : -1;
 }
 
-// APPLY (round 4): the X operand is act(scale[c] * x + shift[c]) on the interior of `x` and 0 on its border -- the
-// BatchNorm + ReLU between conv1 and conv2 of a BasicBlock (residual.py:19-23), applied to the landed patch in LDS
-// (one extra barrier per K-tile) so that the activation tensor never has to exist in HBM: conv_igemm_pw_kernel<APPLY>
-// does the same on the forward side.  Same arithmetic as bn_apply_kernel => the weight gradient is bit-identical.
-struct wd_apply {
-  const float* coef;   // [2][Cin]: scale, shift
-  iic_mdiv d_wp, d_hp;
-  int pad, relu;
-};
-
-template <int COT, int WD_BM, int NBUF, bool ASMRD, bool PF, bool APPLY = false>
+template <int COT, int WD_BM, int NBUF, bool ASMRD, bool PF>
 __global__ __launch_bounds__(PF ? 256 : WD_THREADS) void conv_wgrad_dma_kernel(
     const iic_conv_geom g, const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
-    float* __restrict__ partials, int nsplit, int num_ktiles, int xb_bytes, int max_tap_off, int abl,
-    const wd_apply ap) {
+    float* __restrict__ partials, int nsplit, int num_ktiles, int xb_bytes, int max_tap_off, int abl) {
   constexpr int CS = COT / 64;                  // 32-wide co sub-tiles per wave
   // PF: 4 fat waves (one per SIMD), each with all 9 taps of its (co half, ci half): 11 operand
   // fragments feed 18 MFMAs per k-step (22 transposing reads per 18 MFMAs instead of 10 per 6: the
@@ -300,42 +289,8 @@ __global__ __launch_bounds__(PF ? 256 : WD_THREADS) void conv_wgrad_dma_kernel(
       const int ahead = min(NBUF - 2, kt1 - 1 - kt);
       wd_wait_vmcnt(ahead * NI);
       __syncthreads();                                    // everyone's share landed; tile kt-1 consumed
-      // (APPLY: the next tile's DMA is issued AFTER the transform -- hipcc puts s_waitcnt vmcnt(0) in front of the first
-      //  LDS access that follows an LDS-DMA it knows about, which would make the transform wait for the tile just requested)
-      if (!APPLY && kt + NBUF - 1 < kt1 && !(abl & 1)) dma_issue((b + NBUF - 1) % NBUF, kt + NBUF - 1);   // abl 1: timing only
+      if (kt + NBUF - 1 < kt1 && !(abl & 1)) dma_issue((b + NBUF - 1) % NBUF, kt + NBUF - 1);   // abl 1: timing only
       tabulate(kt + NBUF);
-      if (APPLY) {
-        // in-LDS transform of this K-tile's input patch (its own pieces AND everyone else's have landed: the barrier
-        // above); thread = (8-channel group, row lane), physical unit = group ^ row swizzle (dma_issue)
-        const int tabi = kt & (WD_NTAB - 1);
-        const int plo = __builtin_amdgcn_readfirstlane(s_plo[tabi * 2]);
-        const int nrow = __builtin_amdgcn_readfirstlane(s_plo[tabi * 2 + 1]) * 8;
-        const int lg = tid & 7;
-        const float4* c4 = reinterpret_cast<const float4*>(ap.coef + ci0 + lg * 8);
-        const float4* h4 = reinterpret_cast<const float4*>(ap.coef + g.Cin + ci0 + lg * 8);
-        const float4 a0 = c4[0], a1 = c4[1], b0 = h4[0], b1 = h4[1];
-        const float sc[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-        const float sh[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-        unsigned char* const dX = sX + b * xb_bytes;
-        for (int r = tid >> 3; r < nrow; r += NTH / 8) {
-          const int p = plo + r;
-          const int prow = iic_mdivide(p, ap.d_wp);
-          const int xx = p - prow * g.in_Wp, yy = prow - iic_mdivide(prow, ap.d_hp) * g.in_Hp;
-          const bool border = ap.relu && (xx < ap.pad || xx >= g.in_Wp - ap.pad || yy < ap.pad || yy >= g.in_Hp - ap.pad);
-          uint4* cell = reinterpret_cast<uint4*>(dX + r * 128 + ((lg ^ (((r >> 1) & 1) << 2)) << 4));
-          const uint4 v = *cell;
-          uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            float lo = bf16lo(w[i]) * sc[2 * i] + sh[2 * i], hi = bf16hi(w[i]) * sc[2 * i + 1] + sh[2 * i + 1];
-            if (ap.relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
-            w[i] = pack_bf16x2(lo, hi);
-          }
-          *cell = border ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(w[0], w[1], w[2], w[3]);
-        }
-        __syncthreads();
-        if (kt + NBUF - 1 < kt1 && !(abl & 1)) dma_issue((b + NBUF - 1) % NBUF, kt + NBUF - 1);
-      }
       const unsigned short* prow = s_prow + (kt & (WD_NTAB - 1)) * WD_BM;
       const uint32_t xb = sXo + b * xb_bytes + xoff;
       const uint32_t db = sDo + b * DB;
@@ -458,20 +413,16 @@ static long wd_lds(int np, int cot, int bmk, int nbuf) {
 // the compiler's vmcnt(0) disappears from the K-tile loop, the time does not change (layer1 187 ->
 // 181 us, layer2 144 -> 143, layer3 143 -> 145, layer4 169 -> 172): the DMA wait was not what parks
 // the waves.  Default stays on the builtin; the switch is kept for the next experiments.
-static int g_wd_asm = 0;
-extern "C" void iic_debug_wgrad_asm(int v) { g_wd_asm = v; }
+IIC_SWITCH(g_wd_asm, 0, iic_debug_wgrad_asm)
 // 1: "fat wave" variant -- 4 waves (one per SIMD) with all 9 taps each, 22 transposing reads per 18
 // MFMAs instead of 10 per 6, the next pipeline unit's fragments read under the current MFMAs.
 // Measured (tools/wgrad_ab.sh, per launch incl. the reduce pass): layer2-4 within 2 % of the 12-wave
 // kernel, layer1 28 % slower -- 27 % less LDS-read traffic buys nothing, i.e. the kernel is not
 // LDS-read-bound as round 1 assumed.  Default 0 (12 waves).
 // timing ablation (WRONG results): 1 = no DMA after the prologue (compute-only time of the K loop)
-static int g_wd_ablate = 0;
-extern "C" void iic_debug_wgrad_ablate(int v) { g_wd_ablate = v; }
-static int g_wd_prefetch = 0;
-extern "C" void iic_debug_wgrad_prefetch(int v) { g_wd_prefetch = v; }
-static int g_wd_enabled = 1;     // 0: register-staged kernel, 1: DMA kernel, 3: force 64-pixel K-tiles
-extern "C" void iic_debug_enable_wgrad_dma(int v) { g_wd_enabled = v; }
+IIC_SWITCH(g_wd_ablate, 0, iic_debug_wgrad_ablate)
+IIC_SWITCH(g_wd_prefetch, 0, iic_debug_wgrad_prefetch)
+IIC_SWITCH(g_wd_enabled, 1, iic_debug_enable_wgrad_dma)     // 0: register-staged kernel, 1: DMA kernel, 3: force 64-pixel K-tiles
 
 // K-tile size / ring depth.  Measured at the ClusterNet5g shapes (tools/conv_perf.py): 128-pixel
 // tiles with 2 buffers beat 64-pixel tiles with 3-4 buffers by 10-20 % -- the halo makes a 64-row
@@ -509,45 +460,10 @@ int iic_wgrad_dma_supported(const iic_conv_geom* g) {
   return g_wd_enabled && wd_config(g, &bmk, &nbuf);
 }
 
-int iic_wgrad_dma_launch_apply(const iic_conv_geom* g, const void* x, const float* x_coef, int x_pad, int relu,
-                               const void* dy, float* partials, int nsplit, void* stream);
 int iic_wgrad_dma_launch(const iic_conv_geom* g, const void* x, const void* dy, float* partials,
                          int nsplit, void* stream) {
-  return iic_wgrad_dma_launch_apply(g, x, nullptr, 0, 0, dy, partials, nsplit, stream);
-}
-/* 1 if the DMA kernel can take this geometry with the fused input transform (128-pixel K-tiles, 2 buffers). */
-int iic_wgrad_dma_apply_supported(const iic_conv_geom* g) {
-  int bmk = 0, nbuf = 0;
-  return g_wd_enabled && wd_config(g, &bmk, &nbuf) && bmk == 128 && nbuf == 2 && !g_wd_asm && !g_wd_prefetch;
-}
-static int g_wd_identity = 0;      // timing experiment: run the APPLY variant with identity coefficients (results unchanged)
-extern "C" void iic_debug_wgrad_identity_apply(int v) { g_wd_identity = v; }
-
-int iic_wgrad_dma_launch_apply(const iic_conv_geom* g, const void* x, const float* x_coef, int x_pad, int relu,
-                               const void* dy, float* partials, int nsplit, void* stream) {
   int bmk = 0, nbuf = 0;
   if (!wd_config(g, &bmk, &nbuf)) return IIC_ERR_UNSUPPORTED;
-  if (x_coef && !iic_wgrad_dma_apply_supported(g)) return IIC_ERR_UNSUPPORTED;
-  if (!x_coef && g_wd_identity && iic_wgrad_dma_apply_supported(g) && g->Cin <= 4096) {
-    static float* views[65] = {nullptr};
-    const int slot = g->Cin / 64;
-    if (!views[slot]) {
-      float* host = (float*)malloc(sizeof(float) * 2 * g->Cin);
-      for (int i = 0; i < g->Cin; ++i) { host[i] = 1.f; host[g->Cin + i] = 0.f; }
-      if (hipMalloc(&views[slot], sizeof(float) * 2 * g->Cin) == hipSuccess)
-        (void)hipMemcpy(views[slot], host, sizeof(float) * 2 * g->Cin, hipMemcpyHostToDevice);
-      free(host);
-    }
-    x_coef = views[slot];
-    x_pad = 0;
-    relu = 0;
-  }
-  wd_apply ap;
-  ap.coef = x_coef;
-  ap.d_wp = iic_make_mdiv(g->in_Wp);
-  ap.d_hp = iic_make_mdiv(g->in_Hp);
-  ap.pad = x_pad;
-  ap.relu = relu;
   const long M = (long)g->N * (g->MP > 0 ? g->MP : g->MY * g->MX);
   const int kt = (int)((M + bmk - 1) / bmk);
   const int cot = (g->Cout % 128 == 0) ? 128 : 64;
@@ -570,30 +486,19 @@ int iic_wgrad_dma_launch_apply(const iic_conv_geom* g, const void* x, const floa
     hipLaunchKernelGGL((conv_wgrad_dma_kernel<COT_, BMK_, NBUF_, ASM_, PF_>), grid,             \
                        dim3(PF_ ? 256 : WD_THREADS), lds, s, *g, (const bf16_t*)x,              \
                        (const bf16_t*)dy,                                                       \
-                       partials, nsplit, kt, xb, mto, g_wd_ablate, ap);                         \
+                       partials, nsplit, kt, xb, mto, g_wd_ablate);                             \
   } while (0)
-#define WD_LAUNCH_APPLY(COT_)                                                                    \
-  do {                                                                                          \
-    static bool attr = false;                                                                   \
-    if (!attr) {                                                                                \
-      (void)hipFuncSetAttribute(                                                                \
-          reinterpret_cast<const void*>(&conv_wgrad_dma_kernel<COT_, 128, 2, false, false, true>), \
-          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                              \
-      attr = true;                                                                              \
-    }                                                                                           \
-    hipLaunchKernelGGL((conv_wgrad_dma_kernel<COT_, 128, 2, false, false, true>), grid,         \
-                       dim3(WD_THREADS), lds, s, *g, (const bf16_t*)x, (const bf16_t*)dy,       \
-                       partials, nsplit, kt, xb, mto, g_wd_ablate, ap);                         \
-  } while (0)
+#ifdef IIC_DEBUG_HOOKS
 #define WD_LAUNCH(COT_, BMK_, NBUF_)                                                             \
   do {                                                                                          \
     if (g_wd_asm) WD_LAUNCH2(COT_, BMK_, NBUF_, true, false);                                   \
     else if (g_wd_prefetch) WD_LAUNCH2(COT_, BMK_, NBUF_, false, true);                         \
     else WD_LAUNCH2(COT_, BMK_, NBUF_, false, false);                                           \
   } while (0)
-  if (x_coef) {
-    if (cot == 128) WD_LAUNCH_APPLY(128); else WD_LAUNCH_APPLY(64);
-  } else if (bmk == 64 && nbuf == 4) {
+#else
+#define WD_LAUNCH(COT_, BMK_, NBUF_) WD_LAUNCH2(COT_, BMK_, NBUF_, false, false)
+#endif
+  if (bmk == 64 && nbuf == 4) {
     if (cot == 128) WD_LAUNCH(128, 64, 4); else WD_LAUNCH(64, 64, 4);
   } else if (bmk == 64 && nbuf == 3) {
     if (cot == 128) WD_LAUNCH(128, 64, 3); else WD_LAUNCH(64, 64, 3);

@@ -16,6 +16,7 @@
 // clamped entries, marginals taken before clamping) is restated and checked against the
 // reference's autograd in oracle/iid_oracle.py::loss_and_grad_from_raw_np.
 #include "common.h"
+#include "../../include/iic_hip.h"
 
 // ---------------------------------------------------------------------------------
 // 1. raw joint.  grid = (nsplit, TI*TJ, H), block = 64 (one wave per 32x32 tile).

@@ -638,8 +638,7 @@ extern "C" {
 
 static int seg_tk(int k) { return (k + 15) / 16; }
 // streaming kernels: float4 rows (w % 4 == 0, 16-byte aligned tensors), k <= 32.  A/B: iic_debug_seg_stream(0).
-static int g_seg_stream = 1;
-extern "C" void iic_debug_seg_stream(int v) { g_seg_stream = v; }
+IIC_SWITCH(g_seg_stream, 1, iic_debug_seg_stream)
 static bool seg_stream_ok(int k, int w, const void* a, const void* b, const void* c) {
   return g_seg_stream && (w & 3) == 0 && k <= 32 &&
          ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c)) & 15) == 0;

@@ -593,8 +593,7 @@ int iic_stem_bwd2_supported(int Cin, int W);
 int iic_stem_bwd2_launch(const float* x, const float* w, const float* coef, const void* dpool_pt,
                          float* sums, float* partials, int* nblocks_out, int N, int Cin, int H, int W,
                          void* stream);
-static int g_stem_bwd2 = 1;
-extern "C" void iic_debug_enable_stem_bwd2(int v) { g_stem_bwd2 = v; }
+IIC_SWITCH(g_stem_bwd2, 1, iic_debug_enable_stem_bwd2)
 
 extern "C" {
 

@@ -298,7 +298,6 @@ __global__ __launch_bounds__(512) void stem_bwd2_kernel(const float* __restrict_
   }
 }
 
-extern "C" int iic_debug_get_ablate(void);
 // used by stem.hip's iic_stem_bwd_fused
 int iic_stem_bwd2_supported(int Cin, int W) { return Cin * 9 <= 32 && W + 1 <= 8 * 32; }
 

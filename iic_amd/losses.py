@@ -105,6 +105,12 @@ def _packed_pair(x_out, x_tf_out, lamb, EPS):
 
 def IID_loss(x_out, x_tf_out, lamb=1.0, EPS=sys.float_info.epsilon):
   """Reference signature (IID_losses.py:6)."""
+  # The join comes FIRST: a view forked onto a side stream (ops.auto_branch) is only ordered before the caller's stream
+  # from here on, and the batched evaluation below already reads both views' outputs on the caller's stream
+  # (torch.stack) before _IIDLossFn.forward runs.  Round 5 (tools/race_hunt.py): with the stack in front of the join the
+  # drop-in path -- graph replay, two streams -- computed its loss from partly stale outputs of the side view in about
+  # half of all 4-step runs at 48 images (and the eager two-stream mode "in 1 of 13 runs" in round 4: the same read).
+  ops.join()
   _, k = x_out.size()
   assert x_tf_out.size(0) == x_out.size(0) and x_tf_out.size(1) == k
   if BATCH_SUB_HEADS[0]:
@@ -120,6 +126,7 @@ def IID_loss_heads(x_outs, x_tf_outs, lamb=1.0, EPS=sys.float_info.epsilon):
   """All sub-heads in 3 launches.  x_outs / x_tf_outs: the packed sample-major [bn, H, k]
   tensor the HIP head module produces (``net.forward_packed``), or lists of [bn, k].
   Returns (loss[H], loss_no_lamb[H])."""
+  ops.join()          # before anything reads a forked view's outputs on this stream (see IID_loss)
   if isinstance(x_outs, (list, tuple)):
     x_outs = torch.stack(list(x_outs), dim=1)
     x_tf_outs = torch.stack(list(x_tf_outs), dim=1)

@@ -155,6 +155,7 @@ class _SegLossFn(torch.autograd.Function):
 
 def _seg_loss(x1_outs, x2_outs, all_affine2_to_1, all_mask_img1, lamb, half_T_side_dense,
               half_T_side_sparse_min, half_T_side_sparse_max, collapsed):
+  ops.join()          # before anything below reads a forked view's outputs on this stream (iic_amd.losses.IID_loss)
   assert x1_outs.requires_grad
   assert x2_outs.requires_grad
   assert not all_affine2_to_1.requires_grad

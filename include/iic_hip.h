@@ -23,6 +23,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The prototypes below are the library's WHOLE exported surface: libiic_hip.so is built with -fvisibility=hidden
+ * and only what this header declares is visible (tests/test_cabi_cpu.py holds `nm -D` to it, both ways). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define IIC_OK 0
 #define IIC_ERR_ARG (-1)
@@ -185,21 +190,6 @@ int iic_conv_igemm_frag_red(const iic_conv_geom* g, const void* in, const void* 
                             float* red_stats, float* red_stats2, void* stream);
 int iic_weight_prep_frag(const float* w_oihw, void* w_frag, int Cout, int Cin, int T, int bwd,
                          void* stream);
-/* conv( relu(BatchNorm(in)) ) without the activation tensor (round 4): residual.py:19-23 runs conv1 -> bn1 -> relu ->
- * conv2; bn1's normalisation + ReLU used to be a separate HBM pass (iic_bn_apply: read the raw conv1 output, write the
- * activation) whose only consumers are conv2's forward and conv2's weight gradient.  These two entry points take the
- * RAW tensor and bn1's forward coefficients instead (coef: [0] = scale, [1] = shift, each [Cin] -- the first two rows
- * of iic_bn_finalize's output) and apply relu(scale * x + shift) to the staged patch in LDS, with the tensor's zero
- * border of width in_pad kept zero: the same arithmetic as iic_bn_apply, so outputs are bit-identical to the
- * two-step path.  Forward geometries of the persistent kernel only (csrc/conv_igemm_pw.hip); stats as
- * iic_conv_igemm.                                                                                              */
-int iic_conv_igemm_apply_supported(const iic_conv_geom* g);
-int iic_conv_igemm_frag_apply(const iic_conv_geom* g, const void* in, const float* in_coef, int in_pad,
-                              const void* w_frag, void* out, float* stats, void* stream);
-/* bwd-weight of such a convolution: partial[s][t][co][ci] as iic_conv_wgrad, with x = relu(scale * x_raw + shift). */
-int iic_conv_wgrad_apply_supported(const iic_conv_geom* g);
-int iic_conv_wgrad_apply(const iic_conv_geom* g, const void* x_raw, const float* x_coef, int x_pad, const void* dy,
-                         float* partials, int nsplit, void* stream);
 /* Every weight operand of a network in ONE launch (what the per-parameter calls above do once per conv and
  * layout after each optimiser step): `jobs_dev` = njobs records in DEVICE memory, sorted by first_block
  * (job i owns blocks [first_block, first_block + iic_weight_prep_multi_blocks(Cout, Cin, T))),
@@ -264,19 +254,6 @@ int iic_bn_bwd_apply(const void* dout, const void* act, const void* y, const flo
  * ------------------------------------------------------------------------------- */
 int iic_stem_stats(const float* x, const float* w, float* stats, int N, int Cin, int H, int W,
                    void* stream);
-/* The same statistics without a convolution pass (round 4): conv1 is linear in a pixel's zero-padded 3x3 patch p
- * (K = Cin*9 values), so sum y_c = w_c . S and sum y_c^2 = w_c^T G w_c with S = sum p, G = sum p p^T -- K + K(K+1)/2
- * weight-independent sums (189 for Cin = 2) instead of 64 x K MACs per pixel.  iic_stem_gram adds them, exactly, into
- * `gstats` (iic_stem_gram_bytes(Cin) bytes, zeroed once by the caller; the finaliser re-zeroes it);
- * iic_stem_gram_finalize evaluates mean / variance per channel in double and then does what iic_bn_finalize does in
- * training mode (coef [5][64]; running_mean / running_var / num_batches_tracked may be NULL).  Cin <= 2
- * (iic_stem_gram_supported); other inputs use iic_stem_stats + iic_bn_finalize. */
-int iic_stem_gram_supported(int Cin, int H, int W);
-long iic_stem_gram_bytes(int Cin);
-int iic_stem_gram(const float* x, float* gstats, int N, int Cin, int H, int W, void* stream);
-int iic_stem_gram_finalize(float* gstats, const float* w, const float* gamma, const float* beta,
-                           float* running_mean, float* running_var, long long* num_batches_tracked, float* coef,
-                           int Cin, long count, long ucount, float eps, float momentum, void* stream);
 int iic_stem_apply_pool(const float* x, const float* w, const float* coef, void* out_pt, int N,
                         int Cin, int H, int W, void* stream);
 int iic_stem_bwd_reduce(const float* x, const float* w, const float* coef, const void* dpool_pt,
@@ -484,6 +461,9 @@ int iic_augment(const void* imgs_u8, int B, int H, int W, int channels, const in
                 const int* bounds, const int* kk, int S, const float* lut, float* out,
                 int include_rgb, const float* norm, void* stream);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif
