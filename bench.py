@@ -273,11 +273,9 @@ def reference_api_rate(cfg, dev, imgs, imgs_tf, pairs, steps, auto_branch=False,
     opt = Adam(net.parameters(), lr=1e-4)
   else:
     opt = torch.optim.Adam(net.parameters(), lr=1e-4)
-  prev_auto, prev_graph, prev_eager2 = ops.AUTO_BRANCH[0], ops.GRAPH_FORWARD[0], ops.AUTO_BRANCH_EAGER[0]
+  prev_auto, prev_graph = ops.AUTO_BRANCH[0], ops.GRAPH_FORWARD[0]
   ops.AUTO_BRANCH[0] = bool(auto_branch)
   ops.GRAPH_FORWARD[0] = bool(graph_forward)
-  # (eager launches on two streams are opt-in since round 4, iic_amd.ops.AUTO_BRANCH_EAGER: measured here all the same)
-  ops.AUTO_BRANCH_EAGER[0] = bool(auto_branch) and not graph_forward
 
   def step():
     net.zero_grad()
@@ -305,14 +303,12 @@ def reference_api_rate(cfg, dev, imgs, imgs_tf, pairs, steps, auto_branch=False,
     v = step()
   torch.cuda.synchronize()
   dt = (time.perf_counter() - t0) / steps
-  ops.AUTO_BRANCH[0], ops.GRAPH_FORWARD[0], ops.AUTO_BRANCH_EAGER[0] = prev_auto, prev_graph, prev_eager2
+  ops.AUTO_BRANCH[0], ops.GRAPH_FORWARD[0] = prev_auto, prev_graph
   what = ("list-returning net(x), IID_loss per sub-head, %s, loss .item() every step -- the unchanged script's "
           "call sequence" % ("the fused HIP Adam behind get_opt" if graph_forward else "torch.optim.Adam"))
   if graph_forward:
     what += (", its two forwards on two streams and each forward / backward replayed as a captured HIP graph "
              "(iic_amd/graphed.py: what `python -m iic_amd.run` does by default)")
-  elif auto_branch:
-    what += ", eager launches, its two forwards on two streams (iic_amd.ops.auto_branch with the opt-in IIC_AUTO_BRANCH_EAGER=1)"
   else:
     what += ", eager launches, one stream"
   return {"paired_images_per_sec": pairs / dt, "ms_per_step": 1e3 * dt, "final_loss": v, "what": what}
@@ -767,8 +763,7 @@ def main():
   if use_branch:
     from iic_amd.graph import CapturedPairStep
     try:
-      side_wgrad = os.environ.get("IIC_WGRAD_SIDE", "0") == "1"
-      force_staged = side_wgrad or os.environ.get("IIC_FORCE_STAGED", "0") == "1"
+      force_staged = os.environ.get("IIC_FORCE_STAGED", "0") == "1"
       staged = (world > 1 and os.environ.get("IIC_DIST_STAGED", "1") != "0") or force_staged
       if staged:
         # backward captured per layer group: a group's gradient bucket is all-reduced (third stream, async)
@@ -777,7 +772,7 @@ def main():
                                lambda: net.forward_packed_taps(sobel_process(imgs_tf, False)),
                                loss_fn, finish, lambda: net.zero_grad(set_to_none=True),
                                warmup=max(1, args.warmup), grad_groups=groups, opt_step=opt.step,
-                               events=replay_events, force_staged=force_staged, side_wgrad=side_wgrad)
+                               events=replay_events, force_staged=force_staged)
         nseg = 2 + 3 * len(groups) + len(run.g_l.items) - run.g_l.cuts + len(run.g_opt.items) - run.g_opt.cuts
         ncoll = run.g_l.cuts + run.g_opt.cuts + len(groups)
         launch_mode = ("hip-graph replay: %d linear graph segments, the two views on two streams, backward staged "
@@ -877,7 +872,7 @@ def main():
   ref_api = None
   if world == 1 and not args.no_reference_api:
     ref_api = reference_api_rate(cfg, dev, imgs, imgs_tf, args.pairs, args.steps)
-    ref_api["two_streams"] = reference_api_rate(cfg, dev, imgs, imgs_tf, args.pairs, args.steps, auto_branch=True)
+    # (rounds 3-4 also measured an eager two-stream variant; round 5 removed that mode: iic_amd/ops.py)
     ref_api["graphed"] = reference_api_rate(cfg, dev, imgs, imgs_tf, args.pairs, args.steps, auto_branch=True,
                                             graph_forward=True)
   loss_val = float(last.detach())

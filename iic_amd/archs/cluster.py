@@ -31,23 +31,6 @@ __all__ = ["ClusterNet5g", "ClusterNet5gTwoHead"]
 import os
 import weakref
 
-# Weight-gradient kernels run on a second HIP stream, concurrently with the dependent
-# backward-data / BatchNorm chain of the same block (they only share inputs): two kernels in
-# flight could fill each other's tail waves.  Measured neutral on MI355X (two workgroups of either
-# kernel already fill a CU's registers), so it is opt-in: IIC_DUAL_STREAM=1.
-DUAL_STREAM = [os.environ.get("IIC_DUAL_STREAM", "0") == "1"]   # measured: no gain (CUs are register-full), opt-in
-_SIDE = {}
-
-
-def _side_stream(device):
-  key = str(device)
-  st = _SIDE.get(key)
-  if st is None:
-    st = torch.cuda.Stream(device=device)
-    _SIDE[key] = st
-  return st
-
-
 from ..dist import SHARD_INPUTS, shard_batch  # noqa: E402  (set by iic_amd.run under torchrun)
 # Replica de-duplication (opt-in: IIC_DEDUP=<r> or DEDUP[0] = r).  The reference
 # replicates imgs_curr num_dataloaders times in all_imgs (cluster_sobel.py:215-226).  When a training
@@ -190,14 +173,6 @@ class _ConvHolder(object):
       self._stats[key] = s
     return s
 
-  def gram_stats(self, device, cin):
-    key = (str(device), "gram", ops.BRANCH[0])
-    s = self._stats.get(key)
-    if s is None:
-      s = ops.new_gram_stats(cin, device)
-      self._stats[key] = s
-    return s
-
 
 def _bn_buffers(bn):
   if bn.track_running_stats:
@@ -227,12 +202,7 @@ class _StemFn(torch.autograd.Function):
     rm, rv, nbt = _bn_buffers(bn)
     training = _bn_training(bn)
     wd = w.detach()
-    if training and ops.stem_gram_supported(x):
-      # conv1 is linear: its batch statistics follow from the Gram matrix of the input patches (csrc/stem_gram.hip)
-      coef = ops.stem_gram_finalize(x, wd, mod._h_conv1.gram_stats(x.device, C), gamma.detach(), beta.detach(),
-                                    rm if bn.training else None, rv if bn.training else None,
-                                    nbt if bn.training else None, N * H * W)
-    elif training:
+    if training:
       st = mod._h_conv1.stats(x.device)
       ops.stem_stats(x, wd, st)
       coef = ops.bn_finalize(st, gamma.detach(), beta.detach(), rm if bn.training else None,
@@ -326,14 +296,6 @@ class _StemF32Fn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------
 # BasicBlock  (residual.py:10-43)
 # ------------------------------------------------------------------------------------
-# Timing ablation (results WRONG; bench.py --lr 0): skip the forward BatchNorm+ReLU apply between conv1 and conv2 of
-# the blocks of layers 2-4 -- the upper bound of what fusing that pass into conv2's loaders could give
-# (profiles/r04_bn_ablation.txt).  The first two steps still apply, so that the recycled activation
-# buffers hold realistic values afterwards: skipped from the start, conv2 multiplied the pool's zero-filled
-# buffers and the whole step ran 4.3 ms faster -- zero operands draw less power, the chip clocks higher.
-ABLATE_BN1_APPLY = [os.environ.get("IIC_ABLATE_BN1_APPLY", "0") != "0", 0]
-
-
 class _BlockFn(torch.autograd.Function):
   @staticmethod
   def forward(ctx, x, w1, g1, b1, w2, g2, b2, wd, gd, bd, blk, chain=None):
@@ -360,23 +322,14 @@ class _BlockFn(torch.autograd.Function):
     y1 = ops.pt_alloc(N, Ho, Wo, planes, 1, dev)
     ops.conv_igemm(gf1, x, h1.weights()[0], y1, stats=st1)
     coef1 = bn_coef(blk.bn1, h1, g1, b1, st1)
-    # conv2 reads relu(bn1(y1)): either a tensor a1 made by a separate pass, or -- fused -- y1 itself with bn1's
-    # coefficients applied to the staged patch (ops.conv_igemm_apply; the weight gradient does the same in backward,
-    # the data gradient's ReLU mask comes from (y1, coef1) anyway: BN_MASK_FROM_Y).  Needs the mask-from-y backward
-    # and an un-tapped activation (nobody else reads a1).
-    fuse_a1 = (need_grad or not torch.is_grad_enabled()) and BN_MASK_FROM_Y[0] and FUSE_RED[0] and \
-        ops.apply_supported(gf2, h2.weights()[0]) and not (ABLATE_BN1_APPLY[0])
+    # conv2 reads a1 = relu(bn1(y1)), made by a separate HBM pass.  (Round 4 built the fusion of that pass into conv2's
+    # patch loader -- in LDS after the DMA -- bit-identical and 0.6-0.9 ms per step SLOWER; removed in round 5,
+    # DESIGN.md R5.3 has the arithmetic of why the register variant cannot pay either.)
     st2 = h2.stats(dev) if _bn_training(blk.bn2) else None
     y2 = ops.pt_alloc(N, Ho, Wo, planes, 1, dev)
-    if fuse_a1:
-      a1 = None
-      ops.conv_igemm_apply(gf2, y1, coef1, 1, h2.weights()[0], y2, stats=st2)
-    else:
-      a1 = ops.pt_alloc(N, Ho, Wo, planes, 1, dev)
-      ABLATE_BN1_APPLY[1] += 1
-      if not (ABLATE_BN1_APPLY[0] and planes >= 128 and ABLATE_BN1_APPLY[1] > 2 * 2 * 16):
-        ops.bn_apply(y1, coef1, a1, N, Ho, Wo, 1, planes, relu=True)
-      ops.conv_igemm(gf2, a1, h2.weights()[0], y2, stats=st2)
+    a1 = ops.pt_alloc(N, Ho, Wo, planes, 1, dev)
+    ops.bn_apply(y1, coef1, a1, N, Ho, Wo, 1, planes, relu=True)
+    ops.conv_igemm(gf2, a1, h2.weights()[0], y2, stats=st2)
     coef2 = bn_coef(blk.bn2, h2, g2, b2, st2)
     out = ops.pt_alloc(N, Ho, Wo, planes, 1, dev)
     yd = coefd = None
@@ -411,7 +364,6 @@ class _BlockFn(torch.autograd.Function):
           chain.ctx, chain.y2, chain.yd, chain.blk = ctx, y2, yd, blk
         else:
           chain.ctx = None
-      ctx.fuse_a1 = fuse_a1
       ctx.save_for_backward(x, y1, a1, y2, out, yd, coef1, coef2, coefd, g1, g2, gd)
     else:
       if chain is not None:
@@ -452,29 +404,12 @@ class _BlockFn(torch.autograd.Function):
       dyd = ops.pt_alloc(N, Ho, Wo, planes, 1, dev)
     ops.bn_bwd_apply(dout, m_out, y2, bc2, dy2, N, Ho, Wo, 1, planes, y2=yd, bcoef2=bcd, dy2=dyd)
 
-    dual = DUAL_STREAM[0]
-    main = torch.cuda.current_stream()
-    side = _side_stream(dev) if dual else main
-
-    def on_side(fn):
-      """Run fn on the side stream after everything enqueued so far on the main stream."""
-      if not dual:
-        return fn()
-      side.wait_event(main.record_event())
-      with torch.cuda.stream(side):
-        r = fn()
-      r.record_stream(main)
-      return r
-
-    # ---- conv2 backward: weight grad (side stream) || data grad + bn1 backward (main)
-    if ctx.fuse_a1:      # X operand = relu(bn1(y1)) applied to the staged patch
-      dW2 = on_side(lambda: ops.conv_wgrad(gf2, y1, dy2, 9, use_tr, x_coef=coef1, x_pad=1)).view(planes, planes, 3, 3)
-    else:
-      dW2 = on_side(lambda: ops.conv_wgrad(gf2, a1, dy2, 9, use_tr)).view(planes, planes, 3, 3)
+    # ---- conv2 backward: weight grad, data grad + bn1 backward
+    dW2 = ops.conv_wgrad(gf2, a1, dy2, 9, use_tr).view(planes, planes, 3, 3)
     dWd = None
     if hd is not None:
       gfd, _ = hd.geoms(N, H, W)
-      dWd = on_side(lambda: ops.conv_wgrad(gfd, x, dyd, 1, use_tr)).view(planes, Cin, 1, 1)
+      dWd = ops.conv_wgrad(gfd, x, dyd, 1, use_tr).view(planes, Cin, 1, 1)
     da1 = ops.pt_alloc(N, Ho, Wo, planes, 1, dev)
     # ---- bn1 backward; g1 = da1 * (a1 > 0)
     s1 = h1.stats(dev, "bwd")
@@ -492,8 +427,8 @@ class _BlockFn(torch.autograd.Function):
     dy1 = ops.pt_alloc(N, Ho, Wo, planes, 1, dev)
     ops.bn_bwd_apply(da1, m_act, y1, bc1, dy1, N, Ho, Wo, 1, planes, mask_coef=m_coef)
 
-    # ---- conv1 backward: weight grad (side) || data grad (+ residual / downsample gradient)
-    dW1 = on_side(lambda: ops.conv_wgrad(gf1, x, dy1, 9, use_tr)).view(planes, Cin, 3, 3)
+    # ---- conv1 backward: weight grad, data grad (+ residual / downsample gradient)
+    dW1 = ops.conv_wgrad(gf1, x, dy1, 9, use_tr).view(planes, Cin, 3, 3)
     dx = ops.pt_alloc(N, H, W, Cin, 1, dev)
     # dx = bwd-data(conv1) + identity-branch gradient [, times the ReLU mask of x: mask_dx]
     mx = x if mask_dx else None
@@ -516,12 +451,22 @@ class _BlockFn(torch.autograd.Function):
       _, gbd = hd.geoms(N, H, W)
       for g in gbd:      # (the mask is idempotent: pixels this launch adds to are masked again)
         ops.conv_igemm(g, dyd, hd.weights()[1], dx, accumulate=True, res_act=mx, premask=mask_dx)
-    if dual:   # buffers below are recycled on the main stream: the side stream must be done
-      main.wait_event(side.record_event())
 
     for t in (dout, dy2, dyd, da1, dy1, y1, a1, y2, yd, out):
       ops.POOL.release(t)
     return dx, dW1, dg1, db1, dW2, dg2, db2, dWd, dgd, dbd, None, None
+
+
+# nn.Module._apply (.cpu() / .cuda() / .to(): the reference's scripts move the whole network around every checkpoint,
+# cluster_sobel.py:314-339) keeps the Parameter objects and REPLACES the buffer objects; iic_amd.graphed compares a
+# captured graph's baked-in addresses against a cached tensor list and must know when that list is stale.
+APPLY_GENERATION = [0]
+
+
+class _ApplyCounter(object):
+  def _apply(self, fn, *a, **k):
+    APPLY_GENERATION[0] += 1
+    return super(_ApplyCounter, self)._apply(fn, *a, **k)
 
 
 class BasicBlock(nn.Module):
@@ -732,7 +677,7 @@ def _initialize_weights(net):
       m.bias.data.zero_()
 
 
-class ClusterNet5g(nn.Module):
+class ClusterNet5g(_ApplyCounter, nn.Module):
   def __init__(self, config):
     super(ClusterNet5g, self).__init__()
     self.batchnorm_track = config.batchnorm_track
@@ -776,7 +721,7 @@ class ClusterNet5g(nn.Module):
     return self.head(x, kmeans_use_features=kmeans_use_features)
 
 
-class ClusterNet5gTwoHead(nn.Module):
+class ClusterNet5gTwoHead(_ApplyCounter, nn.Module):
   """net5g_two_head.py:42-81 (head A = overclustering output_k_A, head B = output_k_B)."""
 
   def __init__(self, config):

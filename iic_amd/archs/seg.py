@@ -15,6 +15,7 @@ import torch.nn as nn
 
 from .. import ops
 from .._lib import check, lib, ptr, stream_ptr
+from .cluster import _ApplyCounter
 from .vgg import VGGTrunkHIP, _initialize_weights_vgg
 
 __all__ = ["SegmentationNet10a", "SegmentationNet10aTwoHead"]
@@ -126,7 +127,7 @@ class SegmentationNet10aHead(nn.Module):
             for i in range(self.num_sub_heads)]
 
 
-class SegmentationNet10a(nn.Module):
+class SegmentationNet10a(_ApplyCounter, nn.Module):
   cfg = [(64, 1), (128, 1), ("M", None), (256, 1), (256, 1), (512, 2), (512, 2)]
 
   def __init__(self, config):
@@ -141,7 +142,7 @@ class SegmentationNet10a(nn.Module):
     return self.head(self.trunk(x))
 
 
-class SegmentationNet10aTwoHead(nn.Module):
+class SegmentationNet10aTwoHead(_ApplyCounter, nn.Module):
   """net10a_twohead.py:8-31."""
   cfg = SegmentationNet10a.cfg
 

@@ -16,7 +16,7 @@ import torch.nn as nn
 from .. import geom as G
 from .. import ops
 from ..dist import shard_batch
-from .cluster import FUSE_RED, _ConvHolder, _HeadsFn, _bn_buffers, _bn_training
+from .cluster import FUSE_RED, _ApplyCounter, _ConvHolder, _HeadsFn, _bn_buffers, _bn_training
 
 __all__ = ["ClusterNet6c", "ClusterNet6cTwoHead"]
 
@@ -279,7 +279,7 @@ def _initialize_weights_vgg(net, mode="fan_in"):
       m.bias.data.zero_()
 
 
-class ClusterNet6c(nn.Module):
+class ClusterNet6c(_ApplyCounter, nn.Module):
   cfg = [(64, 1), ("M", None), (128, 1), ("M", None), (256, 1), ("M", None), (512, 1)]
 
   def __init__(self, config):
@@ -308,7 +308,7 @@ def _to_chw_order(feats, head):
   return feats.view(N, head.sp, head.sp, head.num_features).permute(0, 3, 1, 2).reshape(N, -1)
 
 
-class ClusterNet6cTwoHead(nn.Module):
+class ClusterNet6cTwoHead(_ApplyCounter, nn.Module):
   """net6c_two_head.py:53-98."""
   cfg = ClusterNet6c.cfg
 

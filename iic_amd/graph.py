@@ -40,29 +40,10 @@ def _no_gc(fn):
 
 
 def _pair_streams():
-  """The two streams of a paired step.  IIC_PAIR_CUMASK=half|xcd|full (a measurement, needs `make probes`): streams
-  restricted to disjoint halves of the chip through hipExtStreamCreateWithCUMask -- `half`: half the CUs of every XCD
-  each (logical CU bit i sits on XCD i % 8), `xcd`: XCDs 0-3 / 4-7, `full`: both unrestricted (control for the
-  external-stream plumbing).  Measured result in DESIGN.md section 7."""
-  import os
-  mode = os.environ.get("IIC_PAIR_CUMASK", "")
-  if not mode:
-    if os.environ.get("IIC_PAIR_PRIO", "") == "1":       # (measurement) view A's stream at high priority
-      return torch.cuda.Stream(priority=-1), torch.cuda.Stream(priority=0)
-    return torch.cuda.Stream(), torch.cuda.Stream()
-  import ctypes
-  L = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libiic_probe.so"))
-  L.iic_debug_stream_create_cumask.restype = ctypes.c_void_p
-  L.iic_debug_stream_create_cumask.argtypes = [ctypes.POINTER(ctypes.c_uint32), ctypes.c_int]
-  masks = {"half": ([0xFFFFFFFF] * 4 + [0] * 4, [0] * 4 + [0xFFFFFFFF] * 4),
-           "xcd": ([0x0F0F0F0F] * 8, [0xF0F0F0F0] * 8),
-           "full": ([0xFFFFFFFF] * 8, [0xFFFFFFFF] * 8)}[mode]
-  out = []
-  for m in masks:
-    h = L.iic_debug_stream_create_cumask((ctypes.c_uint32 * len(m))(*m), len(m))
-    assert h, "hipExtStreamCreateWithCUMask failed"
-    out.append(torch.cuda.ExternalStream(h))
-  return tuple(out)
+  """The two streams of a paired step.  (Round 4 measured three alternatives -- the views on disjoint halves of the chip
+  through CU-masked streams, half the CUs of every XCD each, view A at high priority: neutral, worse, neutral;
+  DESIGN.md section 7.7 -- and round 5 removed the switches.)"""
+  return torch.cuda.Stream(), torch.cuda.Stream()
 
 
 class CapturedStep(object):
@@ -197,18 +178,12 @@ class CapturedPairStep(object):
 
   @_no_gc
   def __init__(self, view_a, view_b, loss_fn, finish, zero_grad, warmup=2, grad_groups=None, opt_step=None,
-               events=None, force_staged=False, side_wgrad=False):
+               events=None, force_staged=False):
     from . import dist as idist, ops
     assert torch.cuda.is_available(), "CapturedPairStep needs a device"
     # (force_staged: the staged capture without a process group -- tests / probes on one GPU)
     self.staged = grad_groups is not None and (idist.enabled() or force_staged)
     assert not self.staged or opt_step is not None, "staged backward: pass opt_step (the optimiser step alone)"
-    # side_wgrad (staged only): a group's weight gradients are recorded while its data-gradient / BatchNorm chain is
-    # captured (ops.deferring_wgrads) and captured as a graph of their own, replayed on a per-view side stream beside
-    # the NEXT group's chain -- matrix-bound filler for the chain's HBM-bound BatchNorm passes
-    self.side_wgrad = bool(side_wgrad) and self.staged
-    if self.side_wgrad:
-      self.sw = (torch.cuda.Stream(), torch.cuda.Stream())
     self.events = events
     if grad_groups is not None:      # views return (output, boundary activations)
       va, vb = view_a, view_b
@@ -275,8 +250,6 @@ class CapturedPairStep(object):
     taps_a, taps_b = self._taps["a"], self._taps["b"]
     assert len(taps_a) == n - 1 and len(taps_b) == n - 1, "one boundary activation between consecutive groups"
     self.g_ba, self.g_bb, self.g_fold, self.buckets = [], [], [], []
-    self.g_w = ([], [])
-    self._side_pools = (torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle())
     cur = [xa, xb]
     gcur = [ga, gb]
     keep = []
@@ -287,17 +260,8 @@ class CapturedPairStep(object):
         leaves = grp if v == 0 else [ops.branch_leaf(p, 1) for p in grp]
         ins = ([taps[g]] if g < n - 1 else []) + leaves
         gr = torch.cuda.CUDAGraph()
-        if self.side_wgrad:
-          with ops.deferring_wgrads() as dw:
-            with torch.cuda.graph(gr, pool=pool, stream=stream, capture_error_mode=mode):
-              r = torch.autograd.grad([cur[v]], ins, [gcur[v]], allow_unused=True)
-          gw = torch.cuda.CUDAGraph()
-          with torch.cuda.graph(gw, pool=self._side_pools[v], stream=self.sw[v], capture_error_mode=mode):
-            ops.run_deferred_wgrads(dw.items, v)
-          self.g_w[v].append(gw)
-        else:
-          with torch.cuda.graph(gr, pool=pool, stream=stream, capture_error_mode=mode):
-            r = torch.autograd.grad([cur[v]], ins, [gcur[v]], allow_unused=True)
+        with torch.cuda.graph(gr, pool=pool, stream=stream, capture_error_mode=mode):
+          r = torch.autograd.grad([cur[v]], ins, [gcur[v]], allow_unused=True)
         graphs.append(gr)
         if g < n - 1:
           assert r[0] is not None, "group %d: no gradient reaches its input activation" % g
@@ -330,7 +294,6 @@ class CapturedPairStep(object):
         if id(p) in absent:
           p.grad = None
     ops.clear_branch_grads()
-    ops.POOL.unpin_all()        # (side_wgrad: every group of both views is captured, nothing recycles these buffers now)
     s1.wait_stream(s3)
     self.g_opt = _Segmented(pool_a, s1, mode)
     with self.g_opt:
@@ -354,27 +317,6 @@ class CapturedPairStep(object):
       loss = loss_fn(xa_d, xb_d)
       loss.backward()
     s2.wait_stream(s1)
-    if self.side_wgrad:
-      # same buffer lifetimes as the capture: weight gradients recorded, run on the side streams, buffers pinned meanwhile
-      with ops.deferring_wgrads() as dwb:
-        with torch.cuda.stream(s2):
-          xb.backward(xb_d.grad)
-      self.sw[1].wait_stream(s2)
-      with torch.cuda.stream(self.sw[1]):
-        ops.run_deferred_wgrads(dwb.items, 1)
-      with ops.deferring_wgrads() as dwa:
-        with torch.cuda.stream(s1):
-          xa.backward(xa_d.grad)
-      self.sw[0].wait_stream(s1)
-      with torch.cuda.stream(self.sw[0]):
-        ops.run_deferred_wgrads(dwa.items, 0)
-      with torch.cuda.stream(s1):
-        s1.wait_stream(s2)
-        s1.wait_stream(self.sw[0])
-        s1.wait_stream(self.sw[1])
-        ops.POOL.unpin_all()
-        finish()
-      return loss.detach()
     with torch.cuda.stream(s2):
       xb.backward(xb_d.grad)
     with torch.cuda.stream(s1):
@@ -394,12 +336,6 @@ class CapturedPairStep(object):
         self.g_bb[g].replay()
       with torch.cuda.stream(s1):
         self.g_ba[g].replay()
-      if self.side_wgrad:
-        for v, sv in ((1, s2), (0, s1)):
-          self.sw[v].wait_stream(sv)
-          with torch.cuda.stream(self.sw[v]):
-            self.g_w[v][g].replay()
-          s3.wait_stream(self.sw[v])
       if ev is not None:
         ev.append(("bwd", g))
       s3.wait_stream(s1)

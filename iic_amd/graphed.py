@@ -125,6 +125,11 @@ def _storage_sig(mod):
 _SIG_FULL_EVERY = 256
 
 
+def _apply_generation(mod):
+  """How often nn.Module._apply ran on this module (or on a parent that holds it: the count lives in a shared cell)."""
+  return _cl.APPLY_GENERATION[0]
+
+
 def _sig_changed(mod, st, vg):
   """vg.sig != _storage_sig(mod), without walking the module tree at every forward (0.65 ms of host time per call for
   ClusterNet5g -- time by which the second view's forward graph starts after the first's): the Parameter / buffer
@@ -132,7 +137,12 @@ def _sig_changed(mod, st, vg):
   tree is walked again, which also catches a Parameter object that was replaced rather than moved."""
   ts = st.get("sig_tensors")
   n = st["sig_calls"] = st.get("sig_calls", 0) + 1
-  if ts is None or n % _SIG_FULL_EVERY == 0:
+  # nn.Module._apply (.cpu() / .cuda() / .to()) keeps the Parameter objects and REPLACES the buffer objects: the cached
+  # list would pin the old device buffers and keep comparing their unchanged addresses.  The architectures count their
+  # _apply calls (archs.cluster._ApplyCounter): a new count means a fresh walk.
+  gen = _apply_generation(mod)
+  if ts is None or n % _SIG_FULL_EVERY == 0 or st.get("sig_gen") != gen:
+    st["sig_gen"] = gen
     ts = st["sig_tensors"] = list(mod.parameters()) + list(mod.buffers())
   if len(ts) != len(vg.sig):
     return True
@@ -184,12 +194,14 @@ class _GraphedFn(torch.autograd.Function):
     # the autograd route).
     tgt, src, ret = [], [], []
     for p, g in zip(vg.params, vg.grads):
-      if g is not None and p.grad is not None and FUSED_ACCUMULATE[0] and p.grad.dtype == g.dtype:
+      # (parameters with hooks -- iic_amd.dist.GradReducer's post-accumulate hook, a user's register_hook -- keep the
+      #  autograd route in BOTH cases: the fused paths would skip the hooks)
+      hooked = bool(p._backward_hooks) or bool(getattr(p, "_post_accumulate_grad_hooks", None))
+      if g is not None and p.grad is not None and FUSED_ACCUMULATE[0] and p.grad.dtype == g.dtype and not hooked:
         tgt.append(p.grad)
         src.append(g)
         ret.append(None)
-      elif (g is not None and p.grad is None and FUSED_ACCUMULATE[0] and not p._backward_hooks
-            and not getattr(p, "_post_accumulate_grad_hooks", None)):
+      elif g is not None and p.grad is None and FUSED_ACCUMULATE[0] and not hooked:
         p.grad = g.detach()
         ret.append(None)
       else:
@@ -299,8 +311,19 @@ def forward(fwd, mod, x, args, kwargs, pl=None):
   st, key, res, vg = pl.st, pl.key, pl.res, pl.vg
 
   def eager():
-    if ops.BRANCH[0] in ops._NO_PROXY_BRANCHES:     # (a failed capture inside a branch that was entered without aliases)
-      ops.use_aliases_in_current_branch()
+    main = ops._BRANCH_MAIN[0]
+    if main is not None and torch.cuda.current_stream() != main:
+      # A capture failed INSIDE a forked branch (ops.auto_branch entered it because a captured view was planned).  Eager
+      # launches do not run on the side stream (their gradient accumulation would cross the two streams): leave it --
+      # the caller's stream waits for what this view has queued so far, the eager forward runs there with the
+      # parameters themselves, and the fork stays pending, so the pair's second forward does not fork in its place.
+      sys.stderr.write("[iic_amd.graphed] eager forward of %r runs on the caller's stream\n" % (key,))
+      main.wait_stream(torch.cuda.current_stream())
+      with torch.cuda.stream(main):
+        return eager_here()
+    return eager_here()
+
+  def eager_here():
     if res == ops.BRANCH[0]:
       return fwd(mod, x, *args, **kwargs)
     prev = ops.BRANCH[0]

@@ -46,52 +46,18 @@ _BRANCH_MAIN = [None]     # inside `with branch():` the stream the caller was on
 
 
 # IIC_BRANCH_PROXIES=0 (debugging only): side branches use the parameters themselves and autograd accumulates both
-# views' gradients into p.grad ACROSS the two streams.  Not safe with torch 2.10 once the GPU is the bottleneck (see
-# _AUTO_FOLD below: the accumulation races the other view's producer) -- auto_branch does not use this mode any more.
+# views' gradients into p.grad ACROSS the two streams.
 USE_PROXIES = [os.environ.get("IIC_BRANCH_PROXIES", "1") != "0"]
 
 
+# Branch indices that see the parameters themselves (no leaf aliases): the side stream of ops.auto_branch -- only
+# captured / replayed views run there, and those hand their gradients over explicitly (iic_amd/graphed.py) -- and the
+# resource namespaces iic_amd.graphed gives to positions that share a real branch.
+# (Rounds 3-4 also had an EAGER two-stream mode for unchanged scripts -- leaf aliases plus an end-of-backward fold of the
+# alias gradients into .grad.  It was demoted to opt-in in round 4 because about 1 run in 13 differed from the one-stream
+# run; round 5 found the cause -- the loss stacked the forked view's outputs before joining it, iic_amd/losses.py -- and
+# removed the mode rather than carry a second gradient hand-over for launches that are host-bound anyway.)
 _NO_PROXY_BRANCHES = set()
-# Branches whose alias gradients are folded into the parameters' .grad by an end-of-backward callback (auto_branch: an
-# UNCHANGED script, any optimiser).  Until round 4 auto_branch ran its side view WITHOUT aliases and let autograd
-# accumulate both views into p.grad across the two streams; with torch 2.10's AccumulateGrad stream handling that is a
-# race as soon as the GPU, not the host, is the bottleneck (300 images of 96 x 96: garbage losses from the third step
-# on, correct under AMD_SERIALIZE_KERNEL=3; found by tools/race_check.py -- the 24-image tests are host-bound and never
-# showed it).  With aliases each view accumulates on its own stream into its own leaves, and ONE multi-tensor add on the
-# caller's stream, after it has waited for the side stream, produces p.grad.
-_AUTO_FOLD = set()
-_FOLD_STATE = {"queued": False, "main": None}
-
-
-def use_aliases_in_current_branch():
-  """(iic_amd.graphed: an eager forward inside a branch that was entered without aliases -- a failed capture)"""
-  b = BRANCH[0]
-  if 0 < b < 100:
-    _NO_PROXY_BRANCHES.discard(b)
-    _AUTO_FOLD.add(b)
-
-
-def _fold_after_backward():
-  """Engine callback, end of the backward pass: the caller's stream waits for the side streams, then
-  p.grad (+)= the alias gradients."""
-  _FOLD_STATE["queued"] = False
-  main = _FOLD_STATE["main"] or torch.cuda.current_stream()
-  with torch.cuda.stream(main):
-    for (_, idx), st in list(_BRANCH_STREAM.items()):
-      if idx in _AUTO_FOLD:
-        main.wait_stream(st)
-    tgt, src = [], []
-    for p, d in list(_PROXIES.values()):
-      for idx, q in d.items():
-        if idx in _AUTO_FOLD and q.grad is not None:
-          if p.grad is None:
-            p.grad = q.grad
-          else:
-            tgt.append(p.grad)
-            src.append(q.grad)
-          q.grad = None
-    if tgt:
-      torch._foreach_add_(tgt, src)
 
 
 _CAPTURE_PROXIES = [None]   # iic_amd.graphed: {id(param): leaf alias} while a view's graphs are captured
@@ -160,17 +126,14 @@ def clear_branch_grads():
 class branch(object):
   """Fork the enclosed forward onto a side stream / graph branch (see above).  Not re-entrant."""
 
-  def __init__(self, index=1, proxies=True, auto_fold=False):
+  def __init__(self, index=1, proxies=True):
     assert index >= 1
     self.index = index
     self.proxies = proxies
-    self.auto_fold = auto_fold and proxies
 
   def __enter__(self):
     assert BRANCH[0] == 0, "branches do not nest"
     (_NO_PROXY_BRANCHES.discard if self.proxies else _NO_PROXY_BRANCHES.add)(self.index)
-    (_AUTO_FOLD.add if self.auto_fold else _AUTO_FOLD.discard)(self.index)
-    _FOLD_STATE["queued"] = False
     dev = torch.cuda.current_device()
     key = (dev, self.index)
     st = _BRANCH_STREAM.get(key)
@@ -188,7 +151,6 @@ class branch(object):
     self.ctx.__enter__()
     BRANCH[0] = self.index
     _BRANCH_MAIN[0] = self.main
-    _FOLD_STATE["main"] = self.main
     return self
 
   def __exit__(self, *exc):
@@ -213,7 +175,6 @@ class on_branch(object):
     # (this view sees the parameters through leaf aliases whatever an earlier auto_branch run left behind: with the
     #  index still marked alias-free, its gradients would be accumulated into .grad across the two streams)
     _NO_PROXY_BRANCHES.discard(self.index)
-    _AUTO_FOLD.discard(self.index)
     self.ctx = torch.cuda.stream(self.stream)
     self.ctx.__enter__()
     BRANCH[0] = self.index
@@ -234,14 +195,10 @@ class on_branch(object):
 # the outputs of the first forward must not be consumed by anything but this library's losses
 # before the join (true of every reference script); evaluation / no_grad forwards never branch.
 AUTO_BRANCH = [os.environ.get("IIC_AUTO_BRANCH", "0") == "1"]
-# EAGER launches of the pair on two streams (leaf aliases + end-of-backward fold, _AUTO_FOLD above): opt-in since the end
-# of round 4.  The mode is correct at GPU-bound sizes (tests/test_gpu_graphed.py, tools/race_check.py) but the
-# 24-image bit-identity tests differed from the one-stream run in about 1 of 13 runs on the MI355X boxes and the cause
-# was not found before the round's GPU budget ran out.  Default: a forward of the pair that
-# runs EAGERLY -- graph replay off, a warm-up occurrence, a shape that was not captured -- stays on the caller's stream;
-# the two streams are used for captured / replayed views, whose gradient hand-over is explicit (iic_amd/graphed.py).
-AUTO_BRANCH_EAGER = [os.environ.get("IIC_AUTO_BRANCH_EAGER", "0") == "1"]
-_SOLO_FIRST = [False]     # the first forward of a pair ran on the caller's stream: the second one must not fork either
+# A forward of the pair that runs EAGERLY -- graph replay off, a warm-up occurrence, a shape that was not captured --
+# stays on the caller's stream; the two streams are for captured / replayed views, whose gradient hand-over is explicit
+# (iic_amd/graphed.py).
+_SOLO_FIRST = [0]         # 1: the first forward of a pair ran on the caller's stream (the second one must not fork either); 2: so did the second
 # forwards that hand back FEATURES (semisup heads: sup_head5.py:34-35, net6c_two_head.py:78-94,
 # k-means feature extraction) are consumed by modules outside this library, which know nothing about
 # the side stream: they never branch
@@ -290,6 +247,10 @@ def auto_branch(fwd):
     if BRANCH[0] == 0 and (_PENDING_JOIN or _DEFERRED_RUNNING) and (
         not self.training or not torch.is_grad_enabled() or len(_DEFERRED_RUNNING) > _DEFERRED_LIMIT):
       join()      # evaluation must see up-to-date running statistics; bound the postponed list
+    if _SOLO_FIRST[0] == 2:
+      # the pair that ran on the caller's stream is over and nothing of ours joined it (a foreign loss AND a foreign
+      # optimiser): apply its postponed running-statistic updates now, in call order, and start a new pair
+      join()
     run = fwd
     will_branch = (AUTO_BRANCH[0] and self.training and torch.is_grad_enabled() and BRANCH[0] == 0
                    and not _PENDING_JOIN and not _SOLO_FIRST[0] and torch.is_tensor(x) and x.is_cuda
@@ -303,21 +264,30 @@ def auto_branch(fwd):
         def run(self_, x_, *a_, **k_):      # captured-graph replay once this (shape, head, position) is warm
           return graphed.forward(fwd, self_, x_, a_, k_, pl)
     if will_branch:
-      # a replayed / captured view accumulates its gradients itself; an eager side view (opt-in) sees the parameters
-      # through leaf aliases whose gradients are folded into .grad at the end of backward (_AUTO_FOLD)
-      aliases = pl is None or pl.mode == "eager"
-      if aliases and not AUTO_BRANCH_EAGER[0]:
+      if pl is None or pl.mode == "eager":
         # eager launches stay on the caller's stream.  A planned position keeps its resource namespace (so that its
         # buffers exist before the capture) but sees the parameters themselves; the pair's second forward must not
         # fork in its place, and the running-statistic updates of both are applied at the join, in call order.
-        _SOLO_FIRST[0] = True
+        _SOLO_FIRST[0] = 1
         if pl is not None:
           _NO_PROXY_BRANCHES.add(pl.res)
-          _AUTO_FOLD.discard(pl.res)
-        return run(self, x, *a, **k)
-      with branch(proxies=aliases, auto_fold=aliases) as br:
+        try:
+          return run(self, x, *a, **k)
+        except BaseException:
+          _SOLO_FIRST[0] = 0              # the forward raised: there will be no second view to wait for
+          raise
+      # a replayed / captured view: side stream, the parameters themselves, gradients handed over by its autograd node
+      with branch(proxies=False) as br:
         x.record_stream(br.side)         # allocated on the caller's stream, consumed on the side stream
         return run(self, x, *a, **k)
+    if _SOLO_FIRST[0] == 1 and self.training and torch.is_grad_enabled() and BRANCH[0] == 0:
+      # the second view of a pair whose first view stayed on the caller's stream: its running-statistic updates are
+      # postponed like the first view's (bn_finalize), the pair ends with it -- whoever joins next (our losses, our
+      # optimiser, the next pair's first forward, an evaluation forward) applies them
+      try:
+        return run(self, x, *a, **k)
+      finally:
+        _SOLO_FIRST[0] = 2
     if not torch.is_grad_enabled():
       mark = POOL.mark()                 # evaluation: nothing will release the activations later
       try:
@@ -337,7 +307,7 @@ def join():
   while _PENDING_JOIN:
     main, side = _PENDING_JOIN.pop()
     main.wait_stream(side)
-  _SOLO_FIRST[0] = False
+  _SOLO_FIRST[0] = 0
   flush_deferred_running()
 
 
@@ -367,9 +337,6 @@ def branch_backward(fn):
     prev, prev_dt = BRANCH[0], PT_DTYPE[0]
     BRANCH[0] = getattr(ctx, "branch", 0)
     PT_DTYPE[0] = getattr(ctx, "pt_dtype", prev_dt)     # (fp32_mode() forwards allocate fp32 in backward too)
-    if BRANCH[0] in _AUTO_FOLD and not _FOLD_STATE["queued"]:
-      _FOLD_STATE["queued"] = True
-      torch.autograd.Variable._execution_engine.queue_callback(_fold_after_backward)
     try:
       return fn(ctx, *grads)
     finally:
@@ -418,8 +385,6 @@ class PTPool(object):
     self.live = {}            # data_ptr -> serial of the alloc() that handed it out
     self.serial = 0
     self.allocated_bytes = 0
-    self.pinned = set()       # data_ptr of buffers a deferred launch still reads (deferring_wgrads)
-    self.held = []            # pinned buffers whose release was requested meanwhile
 
   def alloc(self, shape, device, P=1):
     dt = PT_DTYPE[0]
@@ -443,25 +408,10 @@ class PTPool(object):
     ent = self.owned.get(t.data_ptr())
     if ent is None or ent[0].shape != t.shape:
       return                  # not one of ours (a user tensor, a view): never recycle it
-    if t.data_ptr() in self.pinned:
-      if t.data_ptr() in self.live and not any(h is ent[0] for h in self.held):
-        self.held.append(ent[0])
-      return                  # a recorded launch on another stream still reads it: unpin_all() releases it
     if self.live.pop(t.data_ptr(), None) is None:
       return                  # already back in the pool
     key = (tuple(t.shape), ent[1], str(t.device), ent[2], t.dtype)
     self.free.setdefault(key, []).append(ent[0])
-
-  def pin(self, t):
-    if t is not None and t.data_ptr() in self.owned:
-      self.pinned.add(t.data_ptr())
-
-  def unpin_all(self):
-    """The streams that ran the recorded launches have been joined: hand back what was released meanwhile."""
-    self.pinned.clear()
-    held, self.held = self.held, []
-    for t in held:
-      self.release(t)
 
   def mark(self):
     return self.serial
@@ -476,8 +426,6 @@ class PTPool(object):
     self.free.clear()
     self.owned.clear()
     self.live.clear()
-    self.pinned.clear()
-    del self.held[:]
 
 
 POOL = PTPool()
@@ -709,84 +657,21 @@ def conv_igemm(g, x_pt, w_t, out_pt, stats=None, res_grad=None, res_act=None, ac
 _WG_PART = {}
 
 
-# conv(relu(bn(y))) without the activation tensor (include/iic_hip.h iic_conv_igemm_frag_apply / iic_conv_wgrad_apply):
-# built and bit-identical, but OFF by default (IIC_FUSE_APPLY=1 switches it on): measured on the north-star step
-# (profiles/r04_bn_ablation.txt) the in-LDS transform costs conv2's forward +25...30 us and its weight gradient +33 us
-# per launch (1.6 ms per step) to save 26 bn_apply launches of ~26 us each (0.7 ms) -- the layer 2-4 applies are cheap,
-# the expensive BatchNorm passes are layer 1's (64 channels at 49 x 49), whose convolutions this kernel does not serve.
-FUSE_APPLY = [os.environ.get("IIC_FUSE_APPLY", "0") == "1"]
-
-
-def apply_supported(gf, w_t):
-  """Can this forward conv AND its weight gradient take their input as (raw tensor, BatchNorm coefficients)?"""
-  if not (FUSE_APPLY[0] and PT_DTYPE[0] is BF16 and isinstance(w_t, WOperand) and USE_FRAG[0]):
-    return False
-  ok = getattr(gf, "_apply_ok", None)
-  if ok is None:
-    ok = bool(lib().iic_conv_igemm_apply_supported(ctypes.byref(gf))) and \
-        bool(lib().iic_conv_wgrad_apply_supported(ctypes.byref(gf)))
-    gf._apply_ok = ok
-  return ok
-
-
-def conv_igemm_apply(g, y_pt, coef, pad, w_t, out_pt, stats=None):
-  """out = conv(relu(coef[0] * y + coef[1])) on the interior of y (border of width `pad` stays zero)."""
-  check(lib().iic_conv_igemm_frag_apply(ctypes.byref(g), ptr(y_pt), ptr(coef), pad, ptr(w_t.pw.frag(w_t.bwd)),
-                                        ptr(out_pt), ptr(stats), stream_ptr()), "iic_conv_igemm_frag_apply")
-  return out_pt
-
-
-# Deferred weight gradients (iic_amd.graph.CapturedPairStep, side_wgrad): a weight gradient depends on its layer's
-# (input, output gradient) pair and on nothing downstream, while the data-gradient / BatchNorm chain of the backward
-# pass is strictly serial and alternates matrix-bound and HBM-bound kernels.  While `deferring_wgrads()` is active,
-# conv_wgrad only RECORDS its launch (and hands back the still unwritten gradient tensor); the caller runs the recorded
-# launches later on another stream (run_deferred_wgrads) so that they fill the chain's HBM-bound phases.  The PT buffers
-# a recorded launch reads are pinned: PTPool.release() keeps them out of circulation until unpin_all().
-_WGRAD_DEFER = [None]
-
-
-class deferring_wgrads(object):
-  def __init__(self):
-    self.items = []
-
-  def __enter__(self):
-    assert _WGRAD_DEFER[0] is None, "deferring_wgrads does not nest"
-    _WGRAD_DEFER[0] = self.items
-    return self
-
-  def __exit__(self, *exc):
-    _WGRAD_DEFER[0] = None
-    return False
-
-
-def run_deferred_wgrads(items, branch):
-  """Enqueue the recorded weight-gradient launches (and their split-K reduces) on the current stream, with the
-  split-K scratch of (branch, "side") -- the recording stream may be running its own weight gradients meanwhile."""
-  for (g, x_pt, dy_pt, wtaps, use_tr, out, accumulate, ns, x_coef, x_pad) in items:
-    _conv_wgrad_launch(g, x_pt, dy_pt, wtaps, use_tr, out, accumulate, ns, x_coef, x_pad, (str(x_pt.device), branch, "side"))
-  del items[:]
-
-
-def _conv_wgrad_launch(g, x_pt, dy_pt, wtaps, use_tr, out, accumulate, ns, x_coef, x_pad, key):
+def _conv_wgrad_launch(g, x_pt, dy_pt, wtaps, use_tr, out, accumulate, ns, key):
   need = ns * g.ntaps * g.Cout * g.Cin
   part = _WG_PART.get(key)
   if part is None or part.numel() < need:
     part = torch.empty(max(need, 1 << 22), dtype=F32, device=x_pt.device)
     _WG_PART[key] = part
-  if x_coef is not None:
-    check(lib().iic_conv_wgrad_apply(ctypes.byref(g), ptr(x_pt), ptr(x_coef), x_pad, ptr(dy_pt), ptr(part), ns,
-                                     stream_ptr()), "iic_conv_wgrad_apply")
-  else:
-    check(lib().iic_conv_wgrad(ctypes.byref(g), ptr(x_pt), ptr(dy_pt), ptr(part), ns,
-                               1 if use_tr else 0, stream_ptr()), "iic_conv_wgrad")
+  check(lib().iic_conv_wgrad(ctypes.byref(g), ptr(x_pt), ptr(dy_pt), ptr(part), ns,
+                             1 if use_tr else 0, stream_ptr()), "iic_conv_wgrad")
   check(lib().iic_conv_wgrad_reduce(ptr(part), ns, wtaps, g.Cout, g.Cin, ptr(out),
                                     1 if accumulate else 0, stream_ptr()), "iic_conv_wgrad_reduce")
 
 
-def conv_wgrad(g, x_pt, dy_pt, wtaps, use_tr=True, out=None, accumulate=False, nsplit=None, x_coef=None, x_pad=1):
+def conv_wgrad(g, x_pt, dy_pt, wtaps, use_tr=True, out=None, accumulate=False, nsplit=None):
   """Returns dW fp32 [Co][Ci][kh][kw] flattened as [Co, Ci, wtaps].  nsplit: override of the
-  split-K factor (tests: few splits = many K-tiles per workgroup).  x_coef: the X operand is
-  relu(x_coef[0] * x + x_coef[1]) of the raw tensor x (iic_conv_wgrad_apply)."""
+  split-K factor (tests: few splits = many K-tiles per workgroup)."""
   if x_pt.dtype == F32:
     if out is None:
       out = torch.empty((g.Cout, g.Cin, wtaps), dtype=F32, device=x_pt.device)
@@ -797,13 +682,7 @@ def conv_wgrad(g, x_pt, dy_pt, wtaps, use_tr=True, out=None, accumulate=False, n
   if out is None:
     out = torch.empty((g.Cout, g.Cin, wtaps), dtype=F32, device=x_pt.device)
   assert g.ntaps == wtaps, "wgrad geometry must list every weight tap once"
-  pending = _WGRAD_DEFER[0]
-  if pending is not None:
-    POOL.pin(x_pt)
-    POOL.pin(dy_pt)
-    pending.append((g, x_pt, dy_pt, wtaps, use_tr, out, accumulate, ns, x_coef, x_pad))
-    return out
-  _conv_wgrad_launch(g, x_pt, dy_pt, wtaps, use_tr, out, accumulate, ns, x_coef, x_pad, (str(x_pt.device), BRANCH[0]))
+  _conv_wgrad_launch(g, x_pt, dy_pt, wtaps, use_tr, out, accumulate, ns, (str(x_pt.device), BRANCH[0]))
   return out
 
 
@@ -894,37 +773,6 @@ def sobel(imgs, include_rgb, using_IR=False):
 def stem_stats(x, w, stats):
   n, c, h, wd = x.shape
   check(lib().iic_stem_stats(ptr(x), ptr(w), ptr(stats), n, c, h, wd, stream_ptr()), "iic_stem_stats")
-
-
-# The stem's batch statistics from the Gram matrix of the input patches instead of a convolution pass
-# (csrc/stem_gram.hip).  Built and parity-tested at the end of round 4, measured NEUTRAL on the step (the 210 us pass it
-# removes runs beside the other view's stem kernels either way: 37.33 / 37.43 ms without, 37.48 / 37.36 with), so it is
-# opt-in: IIC_STEM_GRAM=1.
-STEM_GRAM = [os.environ.get("IIC_STEM_GRAM", "0") == "1"]
-
-
-def stem_gram_supported(x):
-  n, c, h, wd = x.shape
-  return STEM_GRAM[0] and x.dtype == F32 and bool(lib().iic_stem_gram_supported(c, h, wd))
-
-
-def new_gram_stats(cin, device):
-  return torch.zeros(lib().iic_stem_gram_bytes(cin) // 8, dtype=torch.int64, device=device)
-
-
-def stem_gram_finalize(x, w, gstats, gamma, beta, running_mean, running_var, nbt, count):
-  """stem_stats + bn_finalize(training=True) of the 5g stem in two small launches (same deferral of the running
-  statistics inside a branch as bn_finalize)."""
-  n, c, h, wd = x.shape
-  check(lib().iic_stem_gram(ptr(x), ptr(gstats), n, c, h, wd, stream_ptr()), "iic_stem_gram")
-  coef = torch.empty((5, 64), dtype=F32, device=gamma.device)
-  if running_mean is not None and (BRANCH[0] != 0 or _PENDING_JOIN or _SOLO_FIRST[0]):
-    _DEFERRED_RUNNING.append((coef, running_mean, running_var, nbt, 64))
-    running_mean = running_var = nbt = None
-  check(lib().iic_stem_gram_finalize(ptr(gstats), ptr(w), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
-                                     ptr(nbt), ptr(coef), c, count, count * BN_REPLICAS[0], BN_EPS, BN_MOMENTUM,
-                                     stream_ptr()), "iic_stem_gram_finalize")
-  return coef
 
 
 def stem_apply_pool(x, w, coef, out_pt):

@@ -1,5 +1,5 @@
-"""The C-ABI library loads and exports every symbol include/iic_hip.h declares (no compute
-calls -- runs without a GPU)."""
+"""The C-ABI library loads and exports exactly the symbols include/iic_hip.h declares -- no more (no measurement
+switches, no kernel stubs), no less (no compute calls: runs without a GPU)."""
 import ctypes
 import os
 import re
@@ -27,6 +27,46 @@ def test_header_symbols_exported_and_bound():
   assert L.iic_version() >= 1
   assert L.iic_iid_nsplit(660) >= 1
   assert L.iic_iid_workspace_bytes(5, 70) >= 5 * 70 * 70 * 8      # [H][k][k] float64 + the multi-block stage's scratch
+
+
+def _dynamic_symbols(path):
+  import subprocess
+  out = subprocess.check_output(["nm", "-D", "--defined-only", path], universal_newlines=True)
+  return sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+
+
+def test_product_library_exports_exactly_the_header():
+  """-fvisibility=hidden + the version script (iic_amd/csrc/exports.map): `nm -D` of libiic_hip.so == the prototypes
+  of include/iic_hip.h.  The measurement switches (iic_debug_*) exist only in the instrumented flavour."""
+  from iic_amd import _lib
+  here = os.path.dirname(_lib.LIB_PATH)
+  product = os.path.join(here, "libiic_hip.so")
+  assert os.path.exists(product)
+  syms = _dynamic_symbols(product)
+  assert syms == _declared(), (sorted(set(syms) - set(_declared())), sorted(set(_declared()) - set(syms)))
+  assert not any(s.startswith("iic_debug_") for s in syms)
+  dbg = os.path.join(here, "libiic_hip_dbg.so")
+  assert os.path.exists(dbg), "build it: make -C iic_amd/csrc dbg"
+  dsyms = _dynamic_symbols(dbg)
+  extra = sorted(set(dsyms) - set(_declared()))
+  assert set(_declared()) <= set(dsyms) and extra and all(s.startswith("iic_debug_") for s in extra), extra
+
+
+def test_product_python_path_has_no_measurement_switches():
+  """No environment variable changes which kernel the product path launches, except the documented feature switches
+  of iic_amd.ops / archs (graph replay, two streams, replica de-duplication, fp32 parity mode, ...): the round-4
+  experiments (CU-masked streams, side-stream weight gradients, the fused BatchNorm input, Gram statistics, the eager
+  two-stream mode, BN-apply ablation) are gone from the package."""
+  pkg = os.path.join(ROOT, "iic_amd")
+  gone = ("IIC_PAIR_CUMASK", "IIC_PAIR_PRIO", "IIC_WGRAD_SIDE", "IIC_STEM_GRAM", "IIC_FUSE_APPLY", "IIC_ABLATE",
+          "IIC_AUTO_BRANCH_EAGER", "IIC_DUAL_STREAM", "iic_debug_stream_create_cumask")
+  for dp, _, files in os.walk(pkg):
+    for f in files:
+      if f.endswith(".py"):
+        src = open(os.path.join(dp, f)).read()
+        for g in gone:
+          assert g not in src, (f, g)
+  assert "IIC_WGRAD_SIDE" not in open(os.path.join(ROOT, "bench.py")).read()
 
 
 def test_geom_struct_matches_header_size():

@@ -139,16 +139,13 @@ def test_captured_and_branched_steps_track_the_eager_step(mode):
     assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("mode", ["pair", "staged", "staged-side"])
+@pytest.mark.parametrize("mode", ["pair", "staged"])
 def test_two_stream_graph_modes_with_k_split_head_gemm_are_bit_identical_to_eager(mode):
   """Batch large enough (96 x 512 features) for the heads' backward GEMM to take the LDS-tiled kernel with
   its K split over a workspace: the workspace is per branch, so the two views' backward graphs -- replayed
   concurrently on two streams -- must not share it (a shared one made view A's gradients differ from
   replay to replay).  `staged`: the backward captured per layer group (the data-parallel replay order,
-  forced here without a process group); `staged-side`: in addition every group's weight gradients are captured as
-  graphs of their own and replayed on per-view side streams beside the next group's data-gradient / BatchNorm chain
-  (CapturedPairStep side_wgrad: recorded launches, pinned PT buffers).  Six steps enqueued back to back, no host
-  synchronisation."""
+  forced here without a process group).  Six steps enqueued back to back, no host synchronisation."""
   from iic_amd.graph import CapturedPairStep
   from iic_amd.losses import IID_loss_heads
   from iic_amd.optim import Adam
@@ -171,13 +168,8 @@ def test_two_stream_graph_modes_with_k_split_head_gemm_are_bit_identical_to_eage
       run = CapturedPairStep(lambda: net.forward_packed_taps(sobel_process(imgs, False)),
                              lambda: net.forward_packed_taps(sobel_process(imgs_tf, False)),
                              loss_fn, opt.step, lambda: net.zero_grad(set_to_none=True), warmup=2,
-                             grad_groups=net.grad_groups(), opt_step=opt.step, events=events, force_staged=True,
-                             side_wgrad=mode == "staged-side")
+                             grad_groups=net.grad_groups(), opt_step=opt.step, events=events, force_staged=True)
       assert run.staged and len(run.g_ba) == 4 and len(run.buckets) == 4
-      if mode == "staged-side":
-        assert len(run.g_w[0]) == 4 and len(run.g_w[1]) == 4
-        from iic_amd import ops
-        assert not ops.POOL.pinned and not ops.POOL.held
     losses = [run().clone() for _ in range(6)]       # (a replay returns the same static tensor every time)
     torch.cuda.synchronize()
     runs[name] = ([float(l) for l in losses], [p.detach().clone() for p in net.parameters()])
@@ -270,15 +262,9 @@ def test_training_is_bit_reproducible_run_to_run():
 def test_auto_branch_reference_call_sequence_is_bit_identical():
   """iic_amd.ops.auto_branch (what `python -m iic_amd.run` switches on) with EAGER launches: the unchanged scripts'
   call sequence -- net(x), net(x_tf), IID_loss per sub-head, stock torch.optim.Adam -- against the same sequence with
-  the switch off: identical bits.  By default eager forwards of the pair stay on the caller's stream (the side stream
-  is for captured / replayed views: tests/test_gpu_graphed.py); IIC_TEST_EAGER_TWO_STREAMS=1 runs this test with the
-  opt-in eager two-stream mode (ops.AUTO_BRANCH_EAGER: leaf aliases + end-of-backward fold), which differed from the
-  one-stream run in about 1 of 13 runs at this size in round 4 -- cause not found, hence opt-in."""
-  import os
+  the switch off: identical bits.  Eager forwards of the pair stay on the caller's stream (the side stream is for
+  captured / replayed views: tests/test_gpu_graphed.py)."""
   from iic_amd import ops
-  eager_two = os.environ.get("IIC_TEST_EAGER_TWO_STREAMS", "0") == "1"
-  prev_eager = ops.AUTO_BRANCH_EAGER[0]
-  ops.AUTO_BRANCH_EAGER[0] = eager_two
   from iic_amd.losses import IID_loss
   from iic_amd.transforms import sobel_process
   imgs, imgs_tf = _batch()
@@ -292,8 +278,8 @@ def test_auto_branch_reference_call_sequence_is_bit_identical():
       for _ in range(4):
         net.zero_grad()
         xo = net(sobel_process(imgs, False))
-        assert (len(ops._PENDING_JOIN) == 1) == (auto and eager_two)
-        assert ops._SOLO_FIRST[0] == (auto and not eager_two)
+        assert not ops._PENDING_JOIN
+        assert ops._SOLO_FIRST[0] == (1 if auto else 0)
         xt = net(sobel_process(imgs_tf, False))
         tot = None
         for i in range(2):
@@ -310,8 +296,6 @@ def test_auto_branch_reference_call_sequence_is_bit_identical():
       assert not ops._PENDING_JOIN
     finally:
       ops.AUTO_BRANCH[0] = False
-      if auto:
-        ops.AUTO_BRANCH_EAGER[0] = prev_eager
     torch.cuda.synchronize()
     res.append((losses, ev, [p.detach().clone() for p in net.parameters()],
                 net.trunk.bn1.running_mean.clone(), int(net.trunk.bn1.num_batches_tracked)))

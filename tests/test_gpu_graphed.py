@@ -79,7 +79,7 @@ def test_graphed_two_streams_are_ordered_before_the_optimiser_when_the_gpu_is_th
   300 images of 96 x 96 the optimiser is enqueued while both views' backward graphs still run, so this is the case
   that shows whether the second view's gradients (side stream) are ordered before the optimiser's reads (caller's
   stream).  Two streams must equal one stream bit for bit, graph replay must equal eager launches (which, with
-  auto_branch, stay on the caller's stream by default: ops.AUTO_BRANCH_EAGER)."""
+  auto_branch, stay on the caller's stream)."""
   l1, s1, _ = _run(True, False, steps=5, n_base=100, sz=96)
   l2, s2, n2 = _run(True, True, steps=5, n_base=100, sz=96)
   l3, s3, _ = _run(False, True, steps=5, n_base=100, sz=96)

@@ -229,19 +229,23 @@ def _conv_inputs(cin, cout, K, N, H, seed=0):
   return bf16_round(x), w
 
 
+# Measurement switches (iic_debug_*) exist in the instrumented library only (make dbg; IIC_HIP_LIB=dbg): parameters that
+# set one to a non-default value carry the `hooks` marker (tests/conftest.py deselects them in the product library and
+# test_switch_dependent_tests_pass_in_the_instrumented_library runs them in a sub-process); hook() is a no-op otherwise.
+from tests.conftest import hook      # noqa: E402
+
+HOOKS = pytest.mark.hooks
+
+
 def _force_bm(bm):
-  import ctypes
-  from iic_amd import _lib
-  ctypes.CDLL(_lib.LIB_PATH).iic_debug_force_bm(bm)
+  hook("iic_debug_force_bm", bm)
 
 
 def _p64_grid(n):
-  import ctypes
-  from iic_amd import _lib
-  ctypes.CDLL(_lib.LIB_PATH).iic_debug_p64_grid(n)
+  hook("iic_debug_p64_grid", n)
 
 
-@pytest.mark.parametrize("grid", [1, 3, 0])
+@pytest.mark.parametrize("grid", [pytest.param(1, marks=HOOKS), pytest.param(3, marks=HOOKS), 0])
 def test_conv_p64_persistent_tiles(grid):
   """64 -> 64 3x3 layers run on the persistent DMA-fed kernel (conv_igemm_p64.hip); a forced
   small grid makes every workgroup walk many tiles (double-buffered patches, deferred stores,
@@ -255,7 +259,7 @@ def test_conv_p64_persistent_tiles(grid):
     _p64_grid(0)
 
 
-@pytest.mark.parametrize("bm", [0, 256, "frag"])
+@pytest.mark.parametrize("bm", [0, pytest.param(256, marks=HOOKS), "frag"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_forward_and_stats(case, bm):
   """bm: 0 / 256 = first-generation kernel with 128- / 256-row tiles (row-major weights);
@@ -358,7 +362,7 @@ def test_conv_large_images_padded_row_numbering(cin, cout, d, frag):
   assert (gw - wt.grad).abs().max().item() <= 3e-3 * wt.grad.abs().max().item()
 
 
-@pytest.mark.parametrize("bm", [0, 256, "frag"])
+@pytest.mark.parametrize("bm", [0, pytest.param(256, marks=HOOKS), "frag"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_backward_data(case, bm):
   if bm == "frag":
@@ -443,14 +447,11 @@ def test_conv_backward_weight(case, use_tr):
 
 def _wgrad_dma(mode):
   """mode 1 / 3 / 0 as iic_debug_enable_wgrad_dma; 11: mode 1 with the inline-asm transposing reads."""
-  import ctypes
-  from iic_amd import _lib
-  L = ctypes.CDLL(_lib.LIB_PATH)
-  L.iic_debug_wgrad_asm(1 if int(mode) == 11 else 0)
-  L.iic_debug_enable_wgrad_dma(1 if int(mode) == 11 else int(mode))
+  hook("iic_debug_wgrad_asm", 1 if int(mode) == 11 else 0)
+  hook("iic_debug_enable_wgrad_dma", 1 if int(mode) == 11 else int(mode))
 
 
-@pytest.mark.parametrize("dma", [1, 11, 3, 0])
+@pytest.mark.parametrize("dma", [1, pytest.param(11, marks=HOOKS), pytest.param(3, marks=HOOKS), pytest.param(0, marks=HOOKS)])
 @pytest.mark.parametrize("case,nsplit", [((64, 64, 3, 1, 1, 2, 49), 2), ((128, 128, 3, 1, 1, 20, 25), 3),
                                          ((512, 512, 3, 1, 1, 6, 7), 1), ((64, 64, 3, 1, 1, 5, 13), 1)])
 def test_conv_backward_weight_long_k_ranges(case, nsplit, dma):
@@ -464,7 +465,7 @@ def test_conv_backward_weight_long_k_ranges(case, nsplit, dma):
     _wgrad_dma(1)
 
 
-@pytest.mark.parametrize("dma", [3, 0])
+@pytest.mark.parametrize("dma", [pytest.param(3, marks=HOOKS), pytest.param(0, marks=HOOKS), 1])
 @pytest.mark.parametrize("cin,cout,H,dil", [(64, 128, 200, 1), (128, 128, 100, 2)])
 def test_conv_backward_weight_padded_row_numbering(cin, cout, H, dil, dma):
   """Large images (SegmentationNet10a at 200 x 200, PT border 3): iic_amd.geom pads the per-image GEMM row
@@ -599,6 +600,7 @@ def test_bn_forward_backward_kernels():
 @pytest.mark.parametrize("N,H,W,P,C", [(5, 49, 49, 1, 64), (7, 25, 25, 1, 128), (9, 13, 13, 1, 256),
                                        (11, 7, 7, 1, 512), (3, 3, 5, 2, 512), (2, 20, 36, 2, 64),
                                        (1, 1, 1, 1, 64)])
+@pytest.mark.hooks
 def test_bn_backward_kernel_generations_agree(N, H, W, P, C):
   """Second-generation backward passes (pixel walkers, coefficients in registers) against the first:
   bn_bwd_apply is the same expression per element => bit-identical; bn_bwd_reduce sums in another
@@ -658,52 +660,6 @@ def test_sobel_matches_reference_golden():
   assert np.abs(o.cpu().numpy() - g["sobel_out1"]).max() <= 1e-6
   o = sobel_process(torch.from_numpy(g["sobel_in4"]).to(dev()), True)
   assert np.abs(o.cpu().numpy() - g["sobel_out4"]).max() <= 1e-6
-
-
-@pytest.mark.parametrize("cin,N,H,W", [(2, 24, 96, 96), (2, 5, 33, 29), (1, 7, 20, 64), (2, 3, 8, 8), (2, 2, 3, 5)])
-def test_stem_gram_statistics_match_the_convolution_pass(cin, N, H, W):
-  """conv1 is linear in a pixel's 3x3 patch, so the stem's BatchNorm batch statistics follow from the patch sums and
-  the patch Gram matrix (csrc/stem_gram.hip) -- no convolution pass.  Against float64 statistics of F.conv2d on the
-  CPU (the reference's conv1 -> bn1, net5g.py:21-24) and against the recompute pass it replaces: mean, biased and
-  unbiased variance, the BatchNorm coefficients and the running-statistic update; partial row bands, a width that
-  is no multiple of anything, images smaller than one band; the accumulator is left zeroed for the next call."""
-  from iic_amd import ops
-  rng = np.random.default_rng(5)
-  x = torch.from_numpy((rng.standard_normal((N, cin, H, W)) * 0.7 + 0.3).astype(np.float32))     # a non-zero mean
-  w = torch.from_numpy((rng.standard_normal((64, cin, 3, 3)) * 0.3).astype(np.float32))
-  gamma = torch.from_numpy((1 + 0.2 * rng.standard_normal(64)).astype(np.float32))
-  beta = torch.from_numpy((0.1 * rng.standard_normal(64)).astype(np.float32))
-  y = F.conv2d(x.double(), w.double(), padding=1)
-  cnt = N * H * W
-  mean64, var64 = y.mean((0, 2, 3)), y.var((0, 2, 3), unbiased=False)
-  d = dev()
-  xd, wd, gd, bd = x.to(d), w.to(d), gamma.to(d), beta.to(d)
-  assert ops.lib().iic_stem_gram_supported(cin, H, W) == 1      # (ops.STEM_GRAM, the opt-in switch, is not consulted here)
-  gst = ops.new_gram_stats(cin, d)
-  rm, rv = torch.zeros(64, device=d), torch.ones(64, device=d)
-  nbt = torch.zeros((), dtype=torch.int64, device=d)
-  for rep in range(2):           # twice: the finaliser must have re-zeroed the accumulator
-    coef = ops.stem_gram_finalize(xd, wd, gst, gd, bd, rm if rep == 0 else None, rv if rep == 0 else None,
-                                  nbt if rep == 0 else None, cnt)
-    torch.cuda.synchronize()
-    c = coef.double().cpu()
-    scale = 5e-6 * (mean64.abs().max() + var64.sqrt().max())
-    assert (c[2] - mean64).abs().max() <= 2 * scale + 1e-6 * mean64.abs().max(), (c[2] - mean64).abs().max()
-    assert torch.allclose(c[3], 1.0 / torch.sqrt(var64 + 1e-5), rtol=5e-5)
-    assert torch.allclose(c[4], var64 * cnt / (cnt - 1), rtol=5e-5, atol=1e-7)
-    assert torch.allclose(c[0], gamma.double() / torch.sqrt(var64 + 1e-5), rtol=5e-5)
-    assert torch.allclose(c[1], beta.double() - mean64 * gamma.double() / torch.sqrt(var64 + 1e-5), rtol=5e-5, atol=2e-6)
-  assert int(nbt) == 1
-  assert torch.allclose(rm.double().cpu(), 0.1 * mean64, rtol=5e-5, atol=1e-7)
-  assert torch.allclose(rv.double().cpu(), 0.9 + 0.1 * var64 * cnt / (cnt - 1), rtol=5e-5)
-  assert int(gst.abs().sum()) == 0
-  # the recompute pass it replaces (which, like the rest of the stem, takes even image sizes only)
-  if H % 2 or W % 2:
-    return
-  st = ops.new_stats(64, d)
-  ops.stem_stats(xd, wd, st)
-  old = ops.bn_finalize(st, gd, bd, None, None, None, 64, cnt, True).double().cpu()
-  assert torch.allclose(c[0], old[0], rtol=5e-5) and torch.allclose(c[1], old[1], rtol=5e-5, atol=2e-6)
 
 
 @pytest.mark.parametrize("cin,S", [(2, 32), (2, 96), (1, 24)])
@@ -864,6 +820,7 @@ def test_adam_per_parameter_step_counts():
 
 
 @pytest.mark.parametrize("cin,cout,H", [(64, 64, 49), (128, 128, 25), (256, 256, 13), (512, 512, 7)])
+@pytest.mark.hooks
 def test_full_size_kernel_generations_agree(cin, cout, H):
   """North-star shapes at the FULL batch (660 images): the second-generation kernels
   (weights-direct / persistent DMA conv, DMA weight gradient) against the first-generation ones,
@@ -1044,8 +1001,8 @@ def test_eval_matching_against_reference_golden():
 
 
 @pytest.mark.parametrize("cin,cout,H,N,has2,masked", [
-  (64, 64, 19, 24, False, True),      # persistent 64->64 kernel, mask from y
-  (64, 64, 19, 24, True, False),      # ... with the downsample branch's second sum
+  pytest.param(64, 64, 19, 24, False, True, marks=HOOKS),      # persistent 64->64 kernel (fuses only behind iic_debug_p64_red), mask from y
+  pytest.param(64, 64, 19, 24, True, False, marks=HOOKS),      # ... with the downsample branch's second sum
   (128, 128, 13, 40, False, True), (256, 128, 9, 33, True, False), (512, 512, 7, 16, False, False)])
 def test_fused_bn_backward_reduction_in_conv_epilogue(cin, cout, H, N, has2, masked, request):
   """iic_conv_igemm_frag_red: the sums a BatchNorm backward needs (sum g, sum g*y [, sum g*y2]),
@@ -1066,11 +1023,8 @@ def test_fused_bn_backward_reduction_in_conv_epilogue(cin, cout, H, N, has2, mas
   spec = geom.ConvSpec(cin, cout, 3, 1, 1)
   (gb,) = geom.bwd_data_geoms(spec, N, H, H, 1, 1)
   pw = ops.PreppedWeights(w)
-  import ctypes
-  from iic_amd import _lib
-  L = ctypes.CDLL(_lib.LIB_PATH)
-  L.iic_debug_p64_red(1)          # (the persistent 64->64 kernel does not fuse by default: slower)
-  request.addfinalizer(lambda: L.iic_debug_p64_red(0))
+  hook("iic_debug_p64_red", 1)    # (the persistent 64->64 kernel does not fuse by default: slower)
+  request.addfinalizer(lambda: hook("iic_debug_p64_red", 0))
   gb._red_ok = None
   assert ops.red_supported(gb, pw[1])
   dx0 = torch.zeros(N, H + 2, H + 2, cin, dtype=torch.bfloat16, device=dev())
@@ -1098,53 +1052,24 @@ def test_fused_bn_backward_reduction_in_conv_epilogue(cin, cout, H, N, has2, mas
     assert float((f - s_).abs().max()) <= 2e-5 * scale + 1e-6
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("cin,cout,H,N", [(128, 128, 25, 40), (256, 256, 13, 96), (512, 512, 7, 300), (128, 256, 12, 33)])
-def test_conv_with_fused_batchnorm_relu_input_is_bit_identical(cin, cout, H, N):
-  """include/iic_hip.h iic_conv_igemm_frag_apply / iic_conv_wgrad_apply (residual.py:19-23: conv1 -> bn1 -> relu -> conv2
-  without the activation tensor): forward output, BatchNorm statistics and weight gradient must equal, bit for bit, what
-  the two-step path gives (iic_bn_apply writes relu(scale * y + shift), then the plain convolution / weight gradient) --
-  including the zero border of the activation (relu(shift) there would be wrong) and a ragged last tile."""
-  from iic_amd import geom, ops
-  dev = torch.device("cuda:0")
-  torch.manual_seed(cin + H)
-  spec = geom.ConvSpec(cin, cout, 3, 1, 1)
-  gf = geom.fwd_geom(spec, N, H, H, 1, 1)
-  pw = ops.PreppedWeights(torch.randn(cout, cin, 3, 3, device=dev) * 0.05)
-  prev = ops.FUSE_APPLY[0]
-  ops.FUSE_APPLY[0] = True          # (off by default: see iic_amd/ops.py)
-  try:
-    ok = ops.apply_supported(gf, pw[0])
-  finally:
-    ops.FUSE_APPLY[0] = prev
-  if not ok:
-    pytest.skip("geometry not taken by the fused-input kernels")
-  y = torch.zeros(N, H + 2, H + 2, cin, device=dev, dtype=torch.bfloat16)
-  y[:, 1:-1, 1:-1] = torch.randn(N, H, H, cin, device=dev).to(torch.bfloat16)
-  coef = torch.zeros(5, cin, device=dev)
-  coef[0] = torch.rand(cin, device=dev) * 1.5 + 0.25
-  coef[1] = torch.randn(cin, device=dev) * 0.7            # positive shifts: relu(shift) != 0 on the border
-  dy = torch.zeros(N, H + 2, H + 2, cout, device=dev, dtype=torch.bfloat16)
-  dy[:, 1:-1, 1:-1] = torch.randn(N, H, H, cout, device=dev).to(torch.bfloat16)
-  # two-step reference
-  a = torch.zeros_like(y)
-  ops.bn_apply(y, coef, a, N, H, H, 1, cin, relu=True)
-  assert float(a[:, 0].abs().max()) == 0.0 and float(a[:, :, 0].abs().max()) == 0.0
-  o_ref = torch.zeros(N, H + 2, H + 2, cout, device=dev, dtype=torch.bfloat16)
-  st_ref = ops.new_stats(cout, dev)
-  ops.conv_igemm(gf, a, pw[0], o_ref, stats=st_ref)
-  dw_ref = ops.conv_wgrad(gf, a, dy, 9, True)
-  # fused
-  o = torch.zeros_like(o_ref)
-  st = ops.new_stats(cout, dev)
-  ops.conv_igemm_apply(gf, y, coef, 1, pw[0], o, stats=st)
-  dw = ops.conv_wgrad(gf, y, dy, 9, True, x_coef=coef, x_pad=1)
-  torch.cuda.synchronize()
-  assert torch.equal(o, o_ref)
-  assert torch.equal(dw, dw_ref)
-  c_ref = ops.bn_finalize(st_ref, torch.ones(cout, device=dev), torch.zeros(cout, device=dev), None, None, None, cout,
-                          N * H * H, True)
-  c = ops.bn_finalize(st, torch.ones(cout, device=dev), torch.zeros(cout, device=dev), None, None, None, cout,
-                      N * H * H, True)
-  torch.cuda.synchronize()
-  assert torch.allclose(c, c_ref, rtol=1e-5, atol=1e-6)
+def test_switch_dependent_tests_pass_in_the_instrumented_library():
+  """The kernel-generation cross-checks and forced-variant parametrisations toggle iic_debug_* switches, which the product
+  library does not have (include/iic_hip.h is its whole surface; csrc/common.h IIC_SWITCH).  They run here, in a
+  sub-process that loads libiic_hip_dbg.so -- the same sources built with the switches compiled in."""
+  import subprocess
+  import sys
+  from iic_amd import _lib
+  if _lib.HAS_HOOKS:
+    pytest.skip("this process already runs the instrumented library")
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  dbg = os.path.join(root, "iic_amd", "libiic_hip_dbg.so")
+  assert os.path.exists(dbg), "build it: make -C iic_amd/csrc dbg (python -c 'import __graft_entry__ as g; g.build()' does)"
+  env = dict(os.environ, IIC_HIP_LIB="dbg")
+  r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests"), "-m", "gpu and hooks", "-x", "-q",
+                      "-p", "no:cacheprovider"], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                     universal_newlines=True, timeout=1500)
+  tail = "\n".join(r.stdout.splitlines()[-15:])
+  assert r.returncode == 0, tail
+  import re as _re
+  m = _re.search(r"(\d+) passed", r.stdout)
+  assert m and int(m.group(1)) >= 40, tail

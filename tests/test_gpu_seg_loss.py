@@ -140,6 +140,7 @@ def test_affine_warp_matches_grid_sample():
                                         (2, 9, 11, 64, 3), (1, 32, 7, 40, 2), (2, 16, 6, 8, 1),
                                         (2, 5, 6, 8, 0), (3, 24, 1, 12, 2), (1, 1, 5, 256, 10), (2, 17, 3, 132, 4)])
 @pytest.mark.parametrize("collapsed", [False, True])
+@pytest.mark.hooks
 def test_stream_kernels_match_generic_kernels_bitwise(bn, k, h, w, T, collapsed):
   """The float4 / prefetching kernels (default when w % 4 == 0, k <= 32) against the element-wise
   generic ones, same inputs incl. per-image x/y flips and a blob mask, at the BASELINE row widths

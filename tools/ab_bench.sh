@@ -5,7 +5,7 @@
 mkdir -p gpurun_out
 for rep in 1 2; do
   for dbg in "$@"; do
-    IIC_DEBUG="$dbg" python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-roofline --no-reference-api --no-secondary $AB_BENCH_ARGS 2>/dev/null \
+    IIC_HIP_LIB=dbg IIC_DEBUG="$dbg" python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-roofline --no-reference-api --no-secondary $AB_BENCH_ARGS 2>/dev/null \
       | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('IIC_DEBUG=%-40r ms/step %.3f  value %.0f' % ('$dbg', d['ms_per_step'], d['value']))"
   done
 done | tee -a gpurun_out/ab_bench.txt

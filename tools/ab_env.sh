@@ -1,8 +1,8 @@
 #!/bin/bash
 # A/B of environment switches on the default bench step (pair graphs): each argument is one set of assignments
-# ("" = defaults, "IIC_PAIR_CUMASK=half", "IIC_DEBUG=iic_debug_wgrad_target_wgs=128 IIC_PAIR_PRIO=1", ...); prints ms_per_step
+# ("" = defaults, "IIC_HIP_LIB=dbg IIC_DEBUG=iic_debug_wgrad_target_wgs=128", ...); prints ms_per_step
 # for each, interleaved twice to expose box drift.
-#   gpurun -- bash tools/ab_env.sh "" "IIC_PAIR_CUMASK=half"
+#   gpurun -- bash tools/ab_env.sh "" "IIC_HIP_LIB=dbg IIC_DEBUG=iic_debug_bd_ms=4"
 mkdir -p gpurun_out
 for rep in 1 2; do
   for e in "$@"; do

@@ -12,7 +12,7 @@ from iic_amd.transforms import sobel_process
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--no-item", action="store_true")
-ap.add_argument("--modes", default="eager2,graphed2,graphed1")
+ap.add_argument("--modes", default="eager1,graphed2,graphed1")
 ap.add_argument("--profile", action="store_true", help="cProfile of the timed steps (host side), top 30 by cumulative time")
 ap.add_argument("--user-stream", action="store_true", help="run the whole script-side sequence on a non-default stream")
 a = ap.parse_args()
@@ -27,7 +27,6 @@ for mode in a.modes.split(","):
   opt = Adam(net.parameters(), lr=1e-4)
   ops.AUTO_BRANCH[0] = mode.endswith("2")
   ops.GRAPH_FORWARD[0] = mode.startswith("graphed")
-  ops.AUTO_BRANCH_EAGER[0] = mode == "eager2"       # (eager launches on two streams are opt-in: ops.AUTO_BRANCH_EAGER)
   t_host = [0.0]
 
   def step():

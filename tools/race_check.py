@@ -1,5 +1,5 @@
 """Eager / graphed x one / two streams of the drop-in call sequence at a GPU-bound batch: losses of 5 steps per mode.
-(Eager launches on two streams are opt-in: run with IIC_AUTO_BRANCH_EAGER=1 to include that mode.)"""
+(Eager forwards of the pair stay on the caller's stream; tools/race_hunt.py is the round-5 tool that names differing tensors.)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))

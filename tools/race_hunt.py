@@ -1,11 +1,16 @@
-"""Which tensors differ when the eager two-stream pair (ops.auto_branch with leaf aliases + end-of-backward fold) disagrees
-with the one-stream run?  ("find the 1-in-13".)
+"""Which tensors differ when a two-stream mode of the drop-in path (ops.auto_branch) disagrees with the one-stream run?
+("find the 1-in-13" -- found with this tool in round 5: profiles/r05_race_hunt.txt.)
 
-One gradient computation per run from IDENTICAL state (parameters, BatchNorm buffers, inputs), no optimiser: the reference
-is the one-stream run; every two-stream run is compared with it bit for bit -- the two views' outputs, the loss, every
-parameter gradient, the running statistics -- and the first tensors that differ are named.
+Every run starts from IDENTICAL state (parameters, BatchNorm buffers, inputs); the reference is the one-stream eager run;
+each run of the mode under test is compared with it bit for bit -- the views' outputs, the losses, parameter gradients,
+parameters, running statistics -- and the first tensors that differ are named.
 
-  python tools/race_hunt.py [runs=200] [n=48] [mode=eager2|graph2]    (IIC_HIP_LIB does not matter)
+  python tools/race_hunt.py [runs=200] [n=48] [mode=graph2|graph1|eager2]
+    graph2: graph replay + two streams (what `python -m iic_amd.run` does), graph1: graph replay on one stream,
+    eager2: auto_branch with eager launches (they stay on the caller's stream since round 5)
+  HUNT_STEPS=4      several steps per run with an optimiser (HUNT_OPT=torch|ours), no synchronisation but the loss's .item()
+  HUNT_SYNC=1       torch.cuda.synchronize() after every step;  HUNT_SYNC_AT=D|d|m|e: one synchronisation point only
+  HUNT_TRACE=1      asynchronous clones of outputs / gradients / parameters per step: WHICH step goes wrong first
 """
 import os
 import sys
@@ -138,8 +143,6 @@ def main():
   same = all((ref[k_] is None and ref2[k_] is None) or torch.equal(ref[k_], ref2[k_]) for k_ in ref)
   print("one-stream run reproduces itself: %s" % same)
   ops.AUTO_BRANCH[0] = mode != "graph1"
-  if hasattr(ops, "AUTO_BRANCH_EAGER"):
-    ops.AUTO_BRANCH_EAGER[0] = mode == "eager2"
   ops.GRAPH_FORWARD[0] = mode in ("graph1", "graph2")
   bad = 0
   hist = {}
