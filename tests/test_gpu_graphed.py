@@ -159,3 +159,64 @@ def test_per_sub_head_loss_calls_are_batched_and_bit_identical():
   assert out[True][0] == out[False][0], (out[True][0], out[False][0])
   for a, b in zip(out[True][1], out[False][1]):
     assert torch.equal(a, b)
+
+
+def test_default_drop_in_path_is_one_bit_pattern_over_fifty_runs():
+  """What `python -m iic_amd.run` does by default -- graph replay, the pair's two forwards on two streams -- run 50
+  times over 4 optimiser steps from identical state, stock torch.optim.Adam, no synchronisation but the loss's .item():
+  every run must equal the one-stream eager run bit for bit (losses, parameters, running statistics).  Before round 5
+  about HALF of such runs differed at this size: IID_loss's batched sub-head evaluation stacked the forked view's
+  outputs on the caller's stream before joining the side stream (iic_amd/losses.py; found with tools/race_hunt.py,
+  profiles/r05_race_hunt.txt).  The single-shot bit-identity tests above could not see a 1-in-2 event reliably at 24
+  images and never saw it at all sizes; this one repeats."""
+  from iic_amd import archs, ops
+  from iic_amd.archs.cluster import bump_weights_epoch
+  from iic_amd.losses import IID_loss
+  from iic_amd.transforms import sobel_process
+  dev = torch.device("cuda:0")
+  torch.manual_seed(0)
+  cfg = types.SimpleNamespace(in_channels=2, input_sz=32, batchnorm_track=True, num_sub_heads=2, output_k=10)
+  net = archs.ClusterNet5g(cfg).to(dev).train()
+  state = {k: v.detach().clone() for k, v in net.state_dict().items()}
+  g = torch.Generator().manual_seed(1)
+  base = torch.rand(16, 1, 32, 32, generator=g)
+  imgs = base.repeat(3, 1, 1, 1).to(dev)
+  imgs_tf = (torch.flip(imgs, dims=[3]) * 0.9 + 0.03).clamp(0, 1)
+
+  def run():
+    net.load_state_dict(state, strict=True)
+    bump_weights_epoch()             # (load_state_dict wrote the parameters in place)
+    opt = torch.optim.Adam(net.parameters(), lr=2e-4)
+    losses = []
+    for _ in range(4):
+      net.zero_grad()
+      xo = net(sobel_process(imgs, False))
+      xt = net(sobel_process(imgs_tf, False))
+      tot = None
+      for i in range(2):
+        l, _ = IID_loss(xo[i], xt[i], lamb=1.0)
+        tot = l if tot is None else tot + l
+      tot = tot / 2
+      losses.append(tot.item())
+      tot.backward()
+      opt.step()
+    torch.cuda.synchronize()
+    return losses, torch.cat([p.detach().reshape(-1) for p in net.parameters()]).clone(), \
+        net.trunk.bn1.running_mean.clone(), net.trunk.layer4[2].bn2.running_var.clone()
+
+  prev = ops.AUTO_BRANCH[0], ops.GRAPH_FORWARD[0]
+  try:
+    ops.AUTO_BRANCH[0], ops.GRAPH_FORWARD[0] = False, False
+    ref = run()
+    ops.AUTO_BRANCH[0], ops.GRAPH_FORWARD[0] = True, True
+    bad = []
+    for r in range(50):
+      got = run()
+      if got[0] != ref[0] or not all(torch.equal(a, b) for a, b in zip(got[1:], ref[1:])):
+        bad.append((r, got[0]))
+    graphs = net.__dict__.get("_iic_graphed", {"graphs": {}})["graphs"]
+    assert len(graphs) == 2, "the two positions of the step must have been captured (else this ran eagerly)"
+    assert not bad, "%d of 50 runs differ from the one-stream run; reference losses %s, first: %s" % (len(bad), ref[0], bad[:2])
+  finally:
+    ops.AUTO_BRANCH[0], ops.GRAPH_FORWARD[0] = prev
+    ops.join()

@@ -108,9 +108,13 @@ def test_net5g_small_vs_reference_golden(use_tr):
     f.write("%s\n" % report)
   assert mean_emu <= 3.0 * mean_inherent + 2e-3, report
   assert (out.argmax(-1) == eout.argmax(-1)).mean() >= 0.9, report
-  # The statistics are accumulated exactly (round 2), so the run is bit-reproducible: the loss is
-  # -0.014923 on every run -- 2.3 % from the bf16 emulation, 1.8 % from the fp32 reference (MI ~ 0 on
-  # this 24-image fixture: the loss itself is a difference of nearly equal terms); 5 % gates.
+  # The statistics are accumulated exactly (round 2), so a given build is bit-reproducible run to run; the VALUE depends
+  # on how the launches group their statistic partials: -0.014923 in rounds 2-3, -0.014511 since round 4's 128-row tiles
+  # for launches that fill less than half of the chip's workgroup slots (csrc/conv_igemm_bd.hip bd_pick_ms; with
+  # iic_debug_bd_ms=4 the instrumented library gives -0.014923 again: profiles/r05_smoke_bisect.txt) -- 4.5 % / 1.8 %
+  # from the fp32 reference.  MI ~ 0 on this 24-image fixture: the loss is a difference of nearly equal terms and a
+  # one-ulp change in a partial sum moves it by percents, which is why the 5 % gates below are all this fixture can carry
+  # and why smoke() and the tight gates use the 96-image fixture (loss -0.40) instead.
   assert abs(report["loss"] - report["loss_bf16emu"]) < 5e-2 * abs(report["loss_bf16emu"]), report
   assert abs(report["loss"] - report["loss_fp32_reference"]) < 5e-2 * abs(report["loss_fp32_reference"]), report
   # gradients vs the bf16-emulating oracle (straight-through rounding)
@@ -416,6 +420,82 @@ def test_net5g_bf16_large_batch_vs_reference_golden():
   # exist; gradient NORMS (median ratio 1.000), the loss (0.14 %) and the probabilities (4e-3) are the
   # quantities bf16 storage preserves.  Exact gradient parity is the fp32-mode test (1e-3, every parameter).
   assert np.median(ce) >= 0.88 and ce.min() >= 0.75, (float(np.median(ce)), float(ce.min()))
+
+
+def test_net5g_fp32_mode_large_batch_gradients_vs_reference_golden():
+  """The exact-fp32 kernels (`ops.fp32_mode()`) on the fixture OUTSIDE the chaotic regime (tests/golden/net5g_large.npz:
+  the reference's own ClusterNet5g + IID_loss, fp32, CPU; 96 images of 64 x 64, loss -0.40), gradients element by
+  element.  What the gate can be was MEASURED (oracle/gen_golden_large_f64.py): the reference's own
+  float32 gradients sit 3.4e-3 (median relative L2 per parameter, worst 9.1e-3) from the float64 evaluation of the
+  same graph -- 33 batch-statistics BatchNorm layers amplify float32 rounding in backward although loss and
+  probabilities agree to 2e-6 / 1.5e-5 -- so no float32 implementation with another summation order can meet the
+  float32 golden to 2e-4.  The gate that exists: against FLOAT64 (tests/golden/net5g_large_f64.npz) the HIP fp32 path
+  must be in the class of the reference's own float32 run -- measured: median error 3.8e-3 against the reference's
+  3.4e-3 (ratio of the medians 1.11), worst 9.8e-3 against 9.1e-3; per parameter the ratio has median 1.45 and
+  exceeds 3 for three BatchNorm parameters of the LAST block (layer4.2.bn2.weight: 1.2e-3 against 1.6e-5), where
+  both runs are far below everyone else's error and one ReLU-mask decision at a pre-activation of ~0 moves a
+  ~900-term sum by 1e-3.  Gates: per parameter <= 2.5 x the reference's error + 2.5e-3, median <= 1.3 x the
+  reference's median; outputs to 2e-5 and loss to 1e-5 of the float32 golden."""
+  from iic_amd import archs, ops
+  from iic_amd.losses import IID_loss
+  from iic_amd.transforms import sobel_process
+  from oracle import net_oracle
+  from oracle.gen_golden_large import HEADS, INPUT_SZ, K, N_PAIRS, sample_stride
+  from oracle.gen_golden_large_f64 import SUB
+  g = np.load(os.path.join(G, "net5g_large.npz"))
+  g64 = np.load(os.path.join(G, "net5g_large_f64.npz"))
+  params = net_oracle.make_net5g_params(2, K, HEADS, True, seed=13, randomize_bn=True, head_std=0.03)
+  for k in g.files:
+    if k.startswith("param/"):
+      params[k[6:]] = torch.from_numpy(g[k])
+  net = archs.ClusterNet5g(_cfg(input_sz=INPUT_SZ, num_sub_heads=HEADS, output_k=K))
+  net.load_state_dict(params, strict=True)
+  net.to(dev()).train()
+  imgs, imgs_tf = net_oracle.make_mild_pair(N_PAIRS, INPUT_SZ, 3, seed=21)
+  with ops.fp32_mode():
+    xo = net(sobel_process(imgs.to(dev()), False))
+    xt = net(sobel_process(imgs_tf.to(dev()), False))
+  tot = None
+  for i in range(HEADS):
+    l, _ = IID_loss(xo[i], xt[i], lamb=1.0)
+    tot = l if tot is None else tot + l
+  tot = tot / HEADS
+  tot.backward()
+  torch.cuda.synchronize()
+  out = np.stack([o.detach().cpu().numpy() for o in xo])
+  out_tf = np.stack([o.detach().cpu().numpy() for o in xt])
+  d_out = max(np.abs(out - g["out"]).max(), np.abs(out_tf - g["out_tf"]).max())
+  lref = float(g["loss"][0])
+  d_loss = abs(float(tot.detach()) - lref) / abs(lref)
+  rows = []
+  for n, p in net.named_parameters():
+    if "grad64/" + n not in g64.files:
+      continue
+    gd = p.grad.detach().flatten()
+    ours = gd[::sample_stride(gd.numel())][::SUB].double().cpu().numpy()
+    exact = g64["grad64/" + n].astype(np.float64)
+    assert ours.shape == exact.shape, (n, ours.shape, exact.shape)
+    e_ours = float(np.linalg.norm(ours - exact) / max(np.linalg.norm(exact), 1e-30))
+    rows.append((e_ours, float(g64["ref_err/" + n][0]), n))
+  e_o = np.array([r[0] for r in rows])
+  e_r = np.array([r[1] for r in rows])
+  os.makedirs("gpurun_out", exist_ok=True)
+  with open("gpurun_out/net5g_large_fp32_mode.txt", "w") as f:
+    f.write("max|dprob| %.3e, loss %.9f vs float32 golden %.9f (rel %.2e), float64 %.9f\n" % (
+      d_out, float(tot.detach()), lref, d_loss, float(g64["loss64"][0])))
+    f.write("gradient relative L2 error vs FLOAT64 per parameter (%d parameters): HIP fp32 mode median %.3e worst %.3e | "
+            "the reference's own float32 run median %.3e worst %.3e | worst ratio ours / reference's %.2f\n" % (
+              len(rows), np.median(e_o), e_o.max(), np.median(e_r), e_r.max(), float((e_o / np.maximum(e_r, 1e-12)).max())))
+    for e1, e2, n in sorted(rows, reverse=True):
+      f.write("%.3e (reference float32: %.3e)  %s\n" % (e1, e2, n))
+  assert d_out <= 2e-5, d_out
+  assert d_loss <= 1e-5, (float(tot.detach()), lref)
+  assert np.all(e_o <= 2.5 * e_r + 2.5e-3), sorted(rows, reverse=True)[:5]
+  assert np.median(e_o) <= 1.3 * np.median(e_r), (float(np.median(e_o)), float(np.median(e_r)))
+  sd = net.state_dict()
+  assert np.allclose(sd["trunk.bn1.running_mean"].cpu().numpy(), g["state/trunk.bn1.running_mean"], atol=1e-5)
+  assert np.allclose(sd["trunk.bn1.running_var"].cpu().numpy(), g["state/trunk.bn1.running_var"], rtol=1e-4, atol=1e-7)
+  assert np.allclose(sd["trunk.layer4.2.bn2.running_var"].cpu().numpy(), g["state/trunk.layer4.2.bn2.running_var"], rtol=1e-3, atol=1e-7)
 
 
 def test_replica_dedup_fp32_mode_vs_reference_golden():
