@@ -141,9 +141,14 @@ def counting_net(cls):
   return CountingNet
 
 
+LOSS_VALUES = []       # every IID_loss call's value, in call order (IIC_DRIVER_FULL: stored in the fixture)
+
+
 def counting_loss(x_out, x_tf_out, lamb=1.0, EPS=sys.float_info.epsilon):
   calls["loss"] += 1
-  return iid_oracle.IID_loss(x_out, x_tf_out, lamb=lamb, EPS=EPS)
+  r = iid_oracle.IID_loss(x_out, x_tf_out, lamb=lamb, EPS=EPS)
+  LOSS_VALUES.append(float(r[0].detach()))
+  return r
 
 
 def counting_seg_loss(name):
@@ -202,7 +207,11 @@ torch.Tensor.cuda = lambda self, *a, **k: self
 torch.nn.Module.cuda = lambda self, *a, **k: self
 
 # ---- synthetic stand-ins for the data layer ---------------------------------------------------
-NUM_IMGS = 24
+# IIC_DRIVER_FULL=<epochs> (oracle/gen_golden_script.py): whole epochs on the data / arguments / seeds of the GPU driver
+# (tests/ref_script_gpu_driver.py: 44 images per loader = 5 full batches + a ragged one, batch 24), no --test_code --
+# the reference's own modules on the CPU produce the epoch losses the HIP path is held to (tests/golden/script_*.json)
+FULL = int(os.environ.get("IIC_DRIVER_FULL", "0"))
+NUM_IMGS = 44 if FULL else 24
 
 
 def _cluster_loaders(config, seed0):
@@ -273,6 +282,15 @@ sys.modules["code.utils.segmentation.data"] = sdata
 name = spec["module"].rsplit(".", 1)[1]
 sys.argv = [name, "--model_ind", str(spec["model_ind"]), "--dataset_root", "/nonexistent", "--gt_k", str(gt_k),
             "--lr", "0.001", "--num_epochs", "3", "--batch_sz", "12", "--out_root", out_root, "--test_code"] + spec["argv"]
+if FULL:
+  import random
+  import numpy as np
+  random.seed(0)
+  np.random.seed(0)
+  torch.manual_seed(0)
+  sys.argv = [name, "--model_ind", str(spec["model_ind"]), "--dataset_root", "/nonexistent", "--gt_k", str(gt_k),
+              "--lr", "0.001", "--num_epochs", str(FULL), "--batch_sz", "24", "--out_root", out_root, "--save_freq", "1"] + \
+      [a for a in spec["argv"]] + (["--lr_schedule", "2"] if SCRIPT.startswith("cluster_sobel") else [])
 rc, err = None, None
 try:
   py2compat.run_script(spec["module"])
@@ -283,5 +301,17 @@ except Exception as e:       # noqa: BLE001  (reported to the test, with the tra
   traceback.print_exc()
   err = "%s: %s" % (type(e).__name__, e)
 odir = os.path.join(out_root, str(spec["model_ind"]))
-print("IIC_DRIVER_RESULT " + json.dumps({"script": SCRIPT, "bound": bound, "calls": calls, "exit": rc, "error": err,
-                                           "files": sorted(os.listdir(odir)) if os.path.isdir(odir) else []}))
+res = {"script": SCRIPT, "bound": bound, "calls": calls, "exit": rc, "error": err,
+       "files": sorted(os.listdir(odir)) if os.path.isdir(odir) else []}
+cp = os.path.join(odir, "config.pickle")
+if FULL and os.path.exists(cp):
+  import pickle
+  with open(cp, "rb") as f:
+    cfg = pickle.load(f)
+  for k in ("epoch_loss", "epoch_loss_no_lamb", "epoch_acc", "epoch_loss_head_A", "epoch_loss_head_B", "last_epoch"):
+    if hasattr(cfg, k):
+      v = getattr(cfg, k)
+      res[k] = [float(x) for x in v] if isinstance(v, (list, tuple)) else v
+  res["argv"] = sys.argv[1:]
+  res["loss_calls"] = LOSS_VALUES
+print("IIC_DRIVER_RESULT " + json.dumps(res))
