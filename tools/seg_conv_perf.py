@@ -37,10 +37,21 @@ def main():
     t_f = timeit(lambda: ops.conv_igemm(gf, x, pw[0], y, stats=st), iters)
     t_b = timeit(lambda: [ops.conv_igemm(g, dy, pw[1], dx) for g in gb], iters)
     t_w = timeit(lambda: ops.conv_wgrad(gf, x, dy, 9, True), iters)
+    # backward-data with the BatchNorm-backward reduction fused into its epilogue (what the step runs for c3..c6)
+    # against the plain launch + the separate reduction pass it replaces
+    extra = ""
+    if len(gb) == 1 and ops.red_supported(gb[0], pw[1]):
+      yin = torch.randn(N, H + 2 * P, H + 2 * P, cin, device=dev).to(torch.bfloat16)
+      coef = torch.stack([torch.rand(cin, device=dev) + 0.5, torch.randn(cin, device=dev) * 0.3, torch.zeros(cin, device=dev),
+                          torch.ones(cin, device=dev), torch.zeros(cin, device=dev)])
+      s1 = ops.new_stats(cin, dev)
+      t_br = timeit(lambda: ops.conv_igemm(gb[0], dy, pw[1], dx, red=(yin, coef, s1, None, None)), iters)
+      t_r = timeit(lambda: ops.bn_bwd_reduce(dx, None, yin, s1, N, H, H, P, cin, mask_coef=coef), iters)
+      extra = " | bwdD+red %8.1f us vs plain + separate reduce %8.1f + %6.1f = %8.1f us" % (t_br, t_b, t_r, t_b + t_r)
     tf += t_f; tb += t_b; tw += t_w
     print("%-20s %5d | %9.1f %7.1f | %9.1f %7.1f | %9.1f %7.1f | %d %d %d  %s %s" % (
       name, H, t_f, flops / t_f / 1e6, t_b, flops / t_b / 1e6, t_w, flops / t_w / 1e6, gf.NP, gf.NP64, gf.NP256,
-      ops.frag_supported(gf), [ops.frag_supported(g) for g in gb]))
+      ops.frag_supported(gf), [ops.frag_supported(g) for g in gb]) + extra)
   print("sum per pass: fwd %.2f ms, bwd-data %.2f ms, wgrad %.2f ms" % (tf / 1e3, tb / 1e3, tw / 1e3))
 
 
