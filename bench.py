@@ -210,7 +210,9 @@ def cpu_baseline(n_pairs=96, budget_s=45.0):
           "threads_sweep_pairs_per_s": {str(k): round(v, 2) for k, v in sweep.items()},
           "sample": "%d pairs/step, 1 warm-up + up to 2 timed steps per thread count, fp32 torch-CPU %s of the "
                     "ClusterNet5g+IID_loss+Adam step, 96x96, k=70, 5 sub-heads"
-                    % (n_pairs, "run of the reference's own modules" if kind == "reference" else "restatement (oracle/)")}
+                    "%s" % (n_pairs, "run of the reference's own modules" if kind == "reference" else "restatement (oracle/)",
+                            "" if kind == "reference" else "; the restatement runs at 0.9-1.3 x the rate of the reference's own "
+                            "modules on the same host (profiles/r05_cpu_reference_vs_port.txt: 18.5 vs 19.7 pairs/s on 8 cores)")}
 
 
 def cpu_baseline_mnist(batch=700, budget_s=40.0):
