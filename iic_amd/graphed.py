@@ -25,6 +25,13 @@ capture time and re-queued at every replay; both positions re-lay their own bf16
 their forward graph (one operand set per branch, ops / archs.cluster._ConvHolder.weights).
 
 Switch: ops.GRAPH_FORWARD[0] (env IIC_GRAPH_FORWARD; `python -m iic_amd.run` turns it on).
+
+Gradient hand-over: a replayed view installs / adds its static parameter gradients into `.grad` itself and returns
+nothing for the parameters to autograd (one multi-tensor add instead of 118 AccumulateGrad launches per view) -- which is
+what `loss.backward()` followed by `optimiser.step()` wants, the only pattern the reference's scripts use.  Parameters
+with hooks keep the autograd route.  `torch.autograd.grad(loss, parameters)` therefore sees no gradient for them while
+`.grad` is written as a side effect: callers that need that API switch the fused hand-over off
+(IIC_GRAPH_FUSED_ACC=0 / FUSED_ACCUMULATE[0] = False) or graph replay itself.
 """
 import gc
 import os
