@@ -166,6 +166,9 @@ sys.argv = [name, "--model_ind", str(spec["model_ind"]), "--dataset_root", "/non
             "--lr", "0.001", "--num_epochs", str(NUM_EPOCHS), "--batch_sz", str(BATCH), "--num_dataloaders", "3",
             "--out_root", out_root, "--save_freq", "1"] + spec["argv"] + (["--restart"] if RESTART else [])
 rc, err = None, None
+_fp32 = ops.fp32_mode() if os.environ.get("IIC_FP32_MODE", "0") == "1" else None      # the exact-fp32 parity kernels
+if _fp32 is not None:
+  _fp32.__enter__()
 try:
   py2compat.run_script(spec["module"])
 except SystemExit as e:
@@ -174,6 +177,8 @@ except Exception as e:       # noqa: BLE001  (reported to the test, with the tra
   import traceback
   traceback.print_exc()
   err = "%s: %s" % (type(e).__name__, e)
+if _fp32 is not None:
+  _fp32.__exit__(None, None, None)
 torch.cuda.synchronize()
 odir = os.path.join(out_root, str(spec["model_ind"]))
 res = {"script": SCRIPT, "bound": bound, "exit": rc, "error": err,

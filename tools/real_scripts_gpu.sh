@@ -7,5 +7,5 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 test -f .refstage/code/scripts/cluster/cluster_sobel.py || { echo "stage the reference first (see header)"; exit 2; }
 mkdir -p gpurun_out
-rm -f gpurun_out/r04_real_scripts_gpu.txt
-IIC_REFERENCE="$GRAFT_REPO_ROOT/.refstage" timeout 1500 python -m pytest tests/test_gpu_script.py -q -m gpu -k "real_reference${1:+ and $1}" 2>&1 | tail -25 | tee gpurun_out/r04_real_scripts_pytest.txt
+rm -f gpurun_out/real_scripts_gpu.txt gpurun_out/script_real_fp32.txt
+IIC_REFERENCE="$GRAFT_REPO_ROOT/.refstage" timeout 1500 python -m pytest tests/test_gpu_script.py -q -m gpu -k "real_${1:-}" 2>&1 | tail -25 | tee gpurun_out/real_scripts_pytest.txt
