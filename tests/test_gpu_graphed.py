@@ -220,3 +220,30 @@ def test_default_drop_in_path_is_one_bit_pattern_over_fifty_runs():
   finally:
     ops.AUTO_BRANCH[0], ops.GRAPH_FORWARD[0] = prev
     ops.join()
+
+
+def test_capture_failure_inside_the_forked_branch_runs_eager_on_the_callers_stream(monkeypatch, capfd):
+  """A capture that fails for the view that was forked onto the side stream (ops.auto_branch forks only captured /
+  replayed views): the eager fallback must NOT run on the side stream -- it leaves the branch (the caller's stream waits
+  for what the view queued, the forward runs there with the parameters themselves), the pair's other view does not
+  fork in its place, later steps run that position eagerly on one stream, and everything stays bit-identical to the
+  plain eager run (the old fallback switched to the then-unverified leaf-alias mode)."""
+  from iic_amd import graphed
+  real_init = graphed._ViewGraph.__init__
+  fails = []
+
+  def flaky_init(self, fwd, mod, x, args, kwargs, res_branch):
+    if res_branch == 1:                       # the side view's capture always fails
+      fails.append(res_branch)
+      raise RuntimeError("injected capture failure")
+    real_init(self, fwd, mod, x, args, kwargs, res_branch)
+  l0, s0, _ = _run(False, False)
+  monkeypatch.setattr(graphed._ViewGraph, "__init__", flaky_init)
+  l1, s1, n1 = _run(True, True)
+  err = capfd.readouterr().err
+  assert len(fails) == 1, "one capture attempt for the failing position, then eager for good"
+  assert "capture failed" in err and "runs on the caller's stream" in err
+  assert l0 == l1, (l0, l1)
+  for k in s0:
+    assert torch.equal(s0[k], s1[k]), k
+  assert n1 == 2                               # both positions are in the table: one captured, one marked failed
