@@ -22,6 +22,19 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
                     pack_bf16x2(f[6], f[7]));
 }
 
+// Streaming loads of the BatchNorm passes carry the non-temporal hint (`global_load ... nt`: evict-first in L2).
+// Every tensor here is 50-400 MB and read once per pass; without the hint the stream pushes the weight fragments
+// that the other view's convolution keeps re-reading out of the 4 MB L2s.  Measured on the two-stream step
+// (profiles/r05_cache_policy_ab.txt): loads nt -0.5 ms per step, stores nt neutral, both = loads alone; the same
+// hint on the convolutions' epilogues / patch DMA and on the weight gradient's DMA is neutral to worse.
+template <bool NT>
+__device__ __forceinline__ uint4 ld16(const bf16_t* p) {
+  if (NT) {
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    return make_uint4(v[0], v[1], v[2], v[3]);
+  }
+  return *reinterpret_cast<const uint4*>(p);
+}
 // coef layout: [0]=scale [1]=shift [2]=mean [3]=invstd [4]=unbiased batch variance, each [C]
 __global__ __launch_bounds__(256) void bn_finalize_kernel(
     float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -86,6 +99,7 @@ __global__ __launch_bounds__(256) void bn_running_update_kernel(const BnRunTable
 }
 
 // out = act( scale*y + shift [+ res] [+ scale2*y2 + shift2] ), grid = (N*H, ceil(W*C/8/256))
+template <bool NTL>
 __global__ __launch_bounds__(256) void bn_apply_kernel(
     const bf16_t* __restrict__ y, const float* __restrict__ coef, const bf16_t* __restrict__ res,
     const bf16_t* __restrict__ y2, const float* __restrict__ coef2, bf16_t* __restrict__ out,
@@ -98,7 +112,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
   const int Hp = H + 2 * P, Wp = W + 2 * P;
   const long off = (((long)n * Hp + yy + P) * Wp + xq + P) * C + c8 * 8;
   float v[8], sc[8], sh[8];
-  unpack8(*reinterpret_cast<const uint4*>(y + off), v);
+  unpack8(ld16<NTL>(y + off), v);
   *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(coef + c8 * 8);
   *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(coef + c8 * 8 + 4);
   *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(coef + C + c8 * 8);
@@ -107,13 +121,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
   for (int i = 0; i < 8; ++i) v[i] = v[i] * sc[i] + sh[i];
   if (res) {
     float r[8];
-    unpack8(*reinterpret_cast<const uint4*>(res + off), r);
+    unpack8(ld16<NTL>(res + off), r);
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] += r[i];
   }
   if (y2) {
     float r[8];
-    unpack8(*reinterpret_cast<const uint4*>(y2 + off), r);
+    unpack8(ld16<NTL>(y2 + off), r);
     *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(coef2 + c8 * 8);
     *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(coef2 + c8 * 8 + 4);
     *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(coef2 + C + c8 * 8);
@@ -316,7 +330,7 @@ __device__ __forceinline__ void px_advance(PxWalk& w, int step, int H, int W, in
   }
 }
 
-template <int MASK, bool HAS2>
+template <int MASK, bool HAS2, bool NTL>
 __global__ __launch_bounds__(256) void bn_bwd_reduce2_kernel(
     const bf16_t* __restrict__ dout, const bf16_t* __restrict__ act, const bf16_t* __restrict__ y,
     const bf16_t* __restrict__ y2, float* __restrict__ sums, float* __restrict__ sums2,
@@ -371,14 +385,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce2_kernel(
       PxWalk wb = wa;
       px_advance(wb, PL, H, W, P, C);
       const uint4 z = make_uint4(0, 0, 0, 0);
-      const uint4 g0 = *reinterpret_cast<const uint4*>(dout + wa.off);
-      const uint4 g1 = *reinterpret_cast<const uint4*>(dout + wb.off);
-      const uint4 y0 = *reinterpret_cast<const uint4*>(y + wa.off);
-      const uint4 y1 = *reinterpret_cast<const uint4*>(y + wb.off);
-      const uint4 a0 = MASK == 1 ? *reinterpret_cast<const uint4*>(act + wa.off) : z;
-      const uint4 a1 = MASK == 1 ? *reinterpret_cast<const uint4*>(act + wb.off) : z;
-      const uint4 t0 = HAS2 ? *reinterpret_cast<const uint4*>(y2 + wa.off) : z;
-      const uint4 t1 = HAS2 ? *reinterpret_cast<const uint4*>(y2 + wb.off) : z;
+      const uint4 g0 = ld16<NTL>(dout + wa.off);
+      const uint4 g1 = ld16<NTL>(dout + wb.off);
+      const uint4 y0 = ld16<NTL>(y + wa.off);
+      const uint4 y1 = ld16<NTL>(y + wb.off);
+      const uint4 a0 = MASK == 1 ? ld16<NTL>(act + wa.off) : z;
+      const uint4 a1 = MASK == 1 ? ld16<NTL>(act + wb.off) : z;
+      const uint4 t0 = HAS2 ? ld16<NTL>(y2 + wa.off) : z;
+      const uint4 t1 = HAS2 ? ld16<NTL>(y2 + wb.off) : z;
       accumulate(g0, a0, y0, t0);
       accumulate(g1, a1, y1, t1);
       wa = wb;
@@ -386,10 +400,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce2_kernel(
     }
     if (q < q1) {
       const uint4 z = make_uint4(0, 0, 0, 0);
-      accumulate(*reinterpret_cast<const uint4*>(dout + wa.off),
-                 MASK == 1 ? *reinterpret_cast<const uint4*>(act + wa.off) : z,
-                 *reinterpret_cast<const uint4*>(y + wa.off),
-                 HAS2 ? *reinterpret_cast<const uint4*>(y2 + wa.off) : z);
+      accumulate(ld16<NTL>(dout + wa.off),
+                 MASK == 1 ? ld16<NTL>(act + wa.off) : z,
+                 ld16<NTL>(y + wa.off),
+                 HAS2 ? ld16<NTL>(y2 + wa.off) : z);
     }
   }
   const int stripe = blockIdx.x % IIC_STAT_STRIPES;
@@ -414,7 +428,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce2_kernel(
   }
 }
 
-template <int MASK, bool HAS2>
+template <int MASK, bool HAS2, bool NTL>
 __global__ __launch_bounds__(256) void bn_bwd_apply2_kernel(
     const bf16_t* __restrict__ dout, const bf16_t* __restrict__ act, const bf16_t* __restrict__ y,
     const float* __restrict__ bcoef, bf16_t* __restrict__ dy, const bf16_t* __restrict__ y2,
@@ -474,24 +488,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply2_kernel(
   for (; q + PL < q1; q += 2 * PL) {
     PxWalk wb = wa;
     px_advance(wb, PL, H, W, P, C);
-    const uint4 g0 = *reinterpret_cast<const uint4*>(dout + wa.off);
-    const uint4 g1 = *reinterpret_cast<const uint4*>(dout + wb.off);
-    const uint4 y0 = *reinterpret_cast<const uint4*>(y + wa.off);
-    const uint4 y1 = *reinterpret_cast<const uint4*>(y + wb.off);
-    const uint4 a0 = MASK == 1 ? *reinterpret_cast<const uint4*>(act + wa.off) : z;
-    const uint4 a1 = MASK == 1 ? *reinterpret_cast<const uint4*>(act + wb.off) : z;
-    const uint4 t0 = HAS2 ? *reinterpret_cast<const uint4*>(y2 + wa.off) : z;
-    const uint4 t1 = HAS2 ? *reinterpret_cast<const uint4*>(y2 + wb.off) : z;
+    const uint4 g0 = ld16<NTL>(dout + wa.off);
+    const uint4 g1 = ld16<NTL>(dout + wb.off);
+    const uint4 y0 = ld16<NTL>(y + wa.off);
+    const uint4 y1 = ld16<NTL>(y + wb.off);
+    const uint4 a0 = MASK == 1 ? ld16<NTL>(act + wa.off) : z;
+    const uint4 a1 = MASK == 1 ? ld16<NTL>(act + wb.off) : z;
+    const uint4 t0 = HAS2 ? ld16<NTL>(y2 + wa.off) : z;
+    const uint4 t1 = HAS2 ? ld16<NTL>(y2 + wb.off) : z;
     emit(wa.off, g0, a0, y0, t0);
     emit(wb.off, g1, a1, y1, t1);
     wa = wb;
     px_advance(wa, PL, H, W, P, C);
   }
   if (q < q1)
-    emit(wa.off, *reinterpret_cast<const uint4*>(dout + wa.off),
-         MASK == 1 ? *reinterpret_cast<const uint4*>(act + wa.off) : z,
-         *reinterpret_cast<const uint4*>(y + wa.off),
-         HAS2 ? *reinterpret_cast<const uint4*>(y2 + wa.off) : z);
+    emit(wa.off, ld16<NTL>(dout + wa.off),
+         MASK == 1 ? ld16<NTL>(act + wa.off) : z,
+         ld16<NTL>(y + wa.off),
+         HAS2 ? ld16<NTL>(y2 + wa.off) : z);
 }
 
 // 0: first-generation backward kernels; 1 (default): second generation where it measured faster
@@ -505,6 +519,8 @@ static int g_bn_v2_blocks = 1024;
 static constexpr int g_bn_v2 = 1;
 static constexpr int g_bn_v2_blocks = 1024;
 #endif
+// 1 (default): the passes' streaming loads carry the non-temporal hint (see ld16); 0: plain loads (A/B runs)
+IIC_SWITCH(g_bn_nt, 1, iic_debug_bn_nt)
 
 // chunk of pixels per block: a multiple of 2*PL so that every thread's pair loop stays aligned
 // reduce != 0: the reduction kernels end with 2C (3C) integer atomics per block into the exact
@@ -580,9 +596,10 @@ int iic_bn_apply(const void* y, const float* coef, const void* res, const void* 
   if (C % 8 != 0) return IIC_ERR_UNSUPPORTED;
   if ((y2 == nullptr) != (coef2 == nullptr)) return IIC_ERR_ARG;
   dim3 grid(N * H, (W * (C / 8) + 255) / 256);
-  hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y,
-                     coef, (const bf16_t*)res, (const bf16_t*)y2, coef2, (bf16_t*)out, H, W, P, C,
-                     relu);
+#define BN_APPLY_LAUNCH(L_)                                                                                 \
+  hipLaunchKernelGGL((bn_apply_kernel<L_>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y, coef, \
+                     (const bf16_t*)res, (const bf16_t*)y2, coef2, (bf16_t*)out, H, W, P, C, relu)
+  if (g_bn_nt) BN_APPLY_LAUNCH(true); else BN_APPLY_LAUNCH(false);
   return iic_launch_status();
 }
 
@@ -597,11 +614,16 @@ int iic_bn_bwd_reduce(const void* dout, const void* act, const void* y, const vo
     long per;
     int grid2;
     bn_v2_grid((long)N * H * W, C, per, grid2, 1);
-#define BN_RED2_LAUNCH(M_, H2_)                                                                 \
-  hipLaunchKernelGGL((bn_bwd_reduce2_kernel<M_, H2_>), dim3(grid2), dim3(256), 0,               \
+#define BN_RED2_LAUNCH_(M_, H2_, L_)                                                            \
+  hipLaunchKernelGGL((bn_bwd_reduce2_kernel<M_, H2_, L_>), dim3(grid2), dim3(256), 0,           \
                      (hipStream_t)stream, (const bf16_t*)dout, (const bf16_t*)act,              \
                      (const bf16_t*)y, (const bf16_t*)y2, sums, sums2, mask_coef,               \
                      (long)N * H * W, per, H, W, P, C)
+#define BN_RED2_LAUNCH(M_, H2_)                                  \
+  do {                                                           \
+    if (g_bn_nt) BN_RED2_LAUNCH_(M_, H2_, true);                 \
+    else BN_RED2_LAUNCH_(M_, H2_, false);                        \
+  } while (0)
     if (y2) {
       if (mode == 1) BN_RED2_LAUNCH(1, true); else if (mode == 2) BN_RED2_LAUNCH(2, true); else BN_RED2_LAUNCH(0, true);
     } else {
@@ -643,11 +665,16 @@ int iic_bn_bwd_apply(const void* dout, const void* act, const void* y, const flo
     long per;
     int grid2;
     bn_v2_grid((long)N * H * W, C, per, grid2);
-#define BN_APP2_LAUNCH(M_, H2_)                                                                 \
-  hipLaunchKernelGGL((bn_bwd_apply2_kernel<M_, H2_>), dim3(grid2), dim3(256), 0,                \
+#define BN_APP2_LAUNCH_(M_, H2_, L_)                                                             \
+  hipLaunchKernelGGL((bn_bwd_apply2_kernel<M_, H2_, L_>), dim3(grid2), dim3(256), 0,            \
                      (hipStream_t)stream, (const bf16_t*)dout, (const bf16_t*)act,              \
                      (const bf16_t*)y, bcoef, (bf16_t*)dy, (const bf16_t*)y2, bcoef2,           \
                      (bf16_t*)dy2, mask_coef, (long)N * H * W, per, H, W, P, C)
+#define BN_APP2_LAUNCH(M_, H2_)                                  \
+  do {                                                           \
+    if (g_bn_nt) BN_APP2_LAUNCH_(M_, H2_, true);                 \
+    else BN_APP2_LAUNCH_(M_, H2_, false);                        \
+  } while (0)
     if (y2) {
       if (mode == 1) BN_APP2_LAUNCH(1, true); else if (mode == 2) BN_APP2_LAUNCH(2, true); else BN_APP2_LAUNCH(0, true);
     } else {
