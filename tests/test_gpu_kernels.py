@@ -650,6 +650,59 @@ def test_bn_backward_kernel_generations_agree(N, H, W, P, C):
     L.iic_debug_bn_v2(1, 0)
 
 
+@pytest.mark.parametrize("N,H,W,P,C", [(5, 49, 49, 1, 64), (9, 13, 13, 1, 256), (3, 3, 5, 2, 512)])
+@pytest.mark.hooks
+def test_bn_passes_with_and_without_the_non_temporal_hint_are_bit_identical(N, H, W, P, C):
+  """The BatchNorm passes read their streams with `global_load ... nt` (cache policy only, DESIGN R5.6):
+  forward apply (plain, residual, downsample branch), both backward passes in every mask mode -- the
+  hinted kernels (the product's default) against the plain loads, bit for bit, borders untouched."""
+  import ctypes
+  from iic_amd import ops, _lib
+  L = ctypes.CDLL(_lib.LIB_PATH)
+  d = dev()
+  g = torch.Generator().manual_seed(N * 77 + C)
+  shape = (N, H + 2 * P, W + 2 * P, C)
+
+  def pt(scale=1.0):
+    t = torch.zeros(shape, dtype=torch.bfloat16)
+    t[:, P:P + H, P:P + W] = (torch.randn(N, H, W, C, generator=g) * scale).to(torch.bfloat16)
+    return t.to(d)
+  dout, y, y2, res = pt(), pt(1.5), pt(), pt()
+  coef = (torch.randn(5, C, generator=g) * 0.5).to(d)
+  coef2 = (torch.randn(5, C, generator=g) * 0.5).to(d)
+  bcoef = torch.randn(3, C, generator=g).to(d)
+  bcoef2 = torch.randn(3, C, generator=g).to(d)
+  out = {}
+  try:
+    for nt in (0, 1):
+      L.iic_debug_bn_nt(nt)
+      r = []
+      for kw in ({}, {"res": res}, {"y2": y2, "coef2": coef2}):
+        o = torch.full(shape, 7.0, dtype=torch.bfloat16, device=d)
+        ops.bn_apply(y, coef, o, N, H, W, P, C, relu=True, **kw)
+        r.append(o)
+      for mc in (None, coef):
+        for has2 in (False, True):
+          s1, s2 = ops.new_stats(C, d), ops.new_stats(C, d)
+          ops.bn_bwd_reduce(dout, None, y, s1, N, H, W, P, C, y2=y2 if has2 else None,
+                            sums2=s2 if has2 else None, mask_coef=mc)
+          dy = torch.full(shape, 7.0, dtype=torch.bfloat16, device=d)
+          dy2 = torch.full(shape, 7.0, dtype=torch.bfloat16, device=d)
+          ops.bn_bwd_apply(dout, None, y, bcoef, dy, N, H, W, P, C, y2=y2 if has2 else None,
+                           bcoef2=bcoef2 if has2 else None, dy2=dy2 if has2 else None, mask_coef=mc)
+          r += [s1.clone(), s2.clone(), dy, dy2]
+      torch.cuda.synchronize()
+      out[nt] = r
+  finally:
+    L.iic_debug_bn_nt(1)
+  assert len(out[0]) == len(out[1])
+  for a, b in zip(out[0], out[1]):
+    assert torch.equal(a, b)
+  border = out[1][0].clone()
+  border[:, P:P + H, P:P + W] = 7.0
+  assert (border == 7.0).all()
+
+
 # --------------------------------------------------------------------------------------
 # sobel + stem
 # --------------------------------------------------------------------------------------
