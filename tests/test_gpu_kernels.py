@@ -715,7 +715,7 @@ def test_sobel_matches_reference_golden():
   assert np.abs(o.cpu().numpy() - g["sobel_out4"]).max() <= 1e-6
 
 
-@pytest.mark.parametrize("cin,S", [(2, 32), (2, 96), (1, 24)])
+@pytest.mark.parametrize("cin,S", [(2, 32), (2, 96), (1, 24), (3, 64), (5, 32)])
 def test_stem_forward_backward(cin, S):
   from iic_amd import ops
   N = 3

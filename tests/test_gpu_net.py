@@ -876,3 +876,56 @@ def test_net5g_fp32_mode_vs_reference_golden():
     f.write("max|dprob| %.3e / %.3e, loss %.9f vs %.9f, worst grad-norm rel err %.3e\n"
             % (np.abs(out - g["net5g_out"]).max(), np.abs(out_tf - g["net5g_out_tf"]).max(),
                float(tot.detach()), lref, worst))
+
+
+def test_net5g_five_input_channels_fp32_mode_vs_oracle():
+  """The CIFAR configuration of ClusterNet5g (examples/commands.txt:24,27: 32 x 32, `--include_rgb` => Sobel + RGB = 5 input
+  channels, cluster_sobel_twohead.py): 9 * 5 = 45 > 32 stem taps take the two-pass stem backward.  Whole train step on the
+  exact-fp32 kernels against the CPU restatement on the same parameters and batch: outputs, loss, gradient norms."""
+  from iic_amd import archs, ops
+  from iic_amd.losses import IID_loss
+  from iic_amd.transforms import sobel_process
+  from oracle import net_oracle, iid_oracle
+  params = net_oracle.make_net5g_params(5, 10, 2, True, seed=21, randomize_bn=True, head_std=0.3)
+  g = torch.Generator().manual_seed(22)
+  rgb = torch.rand(12, 3, 32, 32, generator=g)
+  rgb_tf = (rgb.flip(3) * (0.6 + 0.8 * torch.rand(12, 1, 1, 1, generator=g))).clamp(0, 1)
+  def with_grey(t):                       # sobel_process(include_rgb=True) input: [rgb, grey] -> [rgb, dx, dy]
+    return torch.cat([t, t.mean(1, keepdim=True)], dim=1)
+  a_c, b_c = net_oracle.sobel_process(with_grey(rgb), True), net_oracle.sobel_process(with_grey(rgb_tf), True)
+  assert a_c.shape[1] == 5
+  rp = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone())
+        for k, v in params.items()}
+  ro = net_oracle.net5g_forward(rp, a_c, True, 32, "head", 2)
+  rt = net_oracle.net5g_forward(rp, b_c, True, 32, "head", 2)
+  rtot = sum(iid_oracle.IID_loss(ro[i], rt[i], lamb=1.0)[0] for i in range(2)) / 2
+  rtot.backward()
+  net = archs.ClusterNet5g(_cfg(in_channels=5))
+  net.load_state_dict(params, strict=True)
+  net.to(dev()).train()
+  a = sobel_process(with_grey(rgb).to(dev()), True)
+  b = sobel_process(with_grey(rgb_tf).to(dev()), True)
+  assert (a.cpu() - a_c).abs().max().item() <= 1e-6
+  with ops.fp32_mode():
+    xo, xt = net(a), net(b)
+  tot = sum(IID_loss(xo[i], xt[i], lamb=1.0)[0] for i in range(2)) / 2
+  tot.backward()
+  torch.cuda.synchronize()
+  for i in range(2):
+    assert (xo[i].detach().cpu() - ro[i].detach()).abs().max().item() <= 2e-4
+    assert (xt[i].detach().cpu() - rt[i].detach()).abs().max().item() <= 2e-4
+  lref = float(rtot.detach())
+  assert abs(float(tot.detach()) - lref) <= 5e-4 * abs(lref) + 1e-7, (float(tot.detach()), lref)
+  for n, p in net.named_parameters():
+    gn = float(rp[n].grad.double().norm())
+    assert abs(float(p.grad.double().norm()) - gn) <= 1e-2 * max(gn, 1e-6) + 1e-9, (n, float(p.grad.double().norm()), gn)
+  # bf16 path: runs, finite, outputs inside the bf16 tier
+  net.zero_grad()
+  bo, bt = net(a), net(b)
+  (sum(IID_loss(bo[i], bt[i], lamb=1.0)[0] for i in range(2)) / 2).backward()
+  torch.cuda.synchronize()
+  for i in range(2):       # (a 33-BatchNorm net on 12 images amplifies bf16 rounding: robust aggregates, as for the 24-image fixture)
+    d = (bo[i].detach().cpu() - ro[i].detach()).abs()
+    assert d.mean().item() <= 3e-2, d.mean().item()
+    assert (bo[i].detach().cpu().argmax(1) == ro[i].detach().argmax(1)).float().mean().item() >= 0.75
+  assert all(torch.isfinite(p.grad).all() for p in net.parameters())

@@ -193,3 +193,47 @@ def test_net6c_fp32_mode_vs_reference_golden():
   for n, p in net.named_parameters():
     gn = g["net6c_grad/" + n][0]
     assert abs(float(p.grad.double().norm()) - gn) <= 1e-2 * max(gn, 1e-6) + 1e-9, (n, float(p.grad.double().norm()), gn)
+
+
+def test_net6c_input_sz_64_fp32_mode_vs_oracle():
+  """ClusterNet6c's second supported geometry (net6c.py:42-45: input_sz 64 -> 8 x 8 x 512 features into the heads):
+  whole train step on the exact-fp32 kernels against the CPU restatement of the reference on the same parameters
+  and batch -- outputs, loss, gradient norms -- and the bf16 path's outputs inside the bf16 tier."""
+  from iic_amd import archs, ops
+  from iic_amd.losses import IID_loss
+  from oracle import net_oracle, iid_oracle
+  cfg = types.SimpleNamespace(in_channels=1, input_sz=64, batchnorm_track=True, num_sub_heads=2, output_k=10)
+  params = net_oracle.make_net6c_params(1, 64, 10, 2, True, seed=9, randomize_bn=True, head_std=0.05)
+  x6, x6t = net_oracle.make_paired_batch(12, 64, 3, seed=10)
+  # oracle (CPU, fp32 autograd)
+  rp = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone())
+        for k, v in params.items()}
+  ro, rt = net_oracle.net6c_forward(rp, x6, True, "head", 2), net_oracle.net6c_forward(rp, x6t, True, "head", 2)
+  rtot = sum(iid_oracle.IID_loss(ro[i], rt[i], lamb=1.0)[0] for i in range(2)) / 2
+  rtot.backward()
+  net = archs.ClusterNet6c(cfg)
+  net.load_state_dict(params, strict=True)
+  net.to(dev()).train()
+  with ops.fp32_mode():
+    xo, xt = net(x6.to(dev())), net(x6t.to(dev()))
+  tot = sum(IID_loss(xo[i], xt[i], lamb=1.0)[0] for i in range(2)) / 2
+  tot.backward()
+  torch.cuda.synchronize()
+  for i in range(2):
+    assert (xo[i].detach().cpu() - ro[i].detach()).abs().max().item() <= 2e-4
+    assert (xt[i].detach().cpu() - rt[i].detach()).abs().max().item() <= 2e-4
+  lref = float(rtot.detach())
+  assert abs(float(tot.detach()) - lref) <= 5e-4 * abs(lref) + 1e-7, (float(tot.detach()), lref)
+  for n, p in net.named_parameters():
+    gn = float(rp[n].grad.double().norm())
+    assert abs(float(p.grad.double().norm()) - gn) <= 1e-2 * max(gn, 1e-6) + 1e-9, (n, float(p.grad.double().norm()), gn)
+  # bf16 path (the measured configuration): same batch, outputs inside the bf16 tier, backward finite
+  net.zero_grad()
+  bo = net(x6.to(dev()))
+  (sum(IID_loss(bo[i], net(x6t.to(dev()))[i], lamb=1.0)[0] for i in range(2)) / 2).backward()
+  torch.cuda.synchronize()
+  for i in range(2):
+    d = (bo[i].detach().cpu() - ro[i].detach()).abs()
+    assert d.mean().item() <= 1e-2, d.mean().item()
+    assert (bo[i].detach().cpu().argmax(1) == ro[i].detach().argmax(1)).float().mean().item() >= 0.9
+  assert all(torch.isfinite(p.grad).all() for p in net.parameters())
