@@ -39,11 +39,60 @@ def _no_gc(fn):
   return wrapped
 
 
+_PAIR_STREAMS = {}     # device index -> (stream 1, stream 2)
+
+
 def _pair_streams():
-  """The two streams of a paired step.  (Round 4 measured three alternatives -- the views on disjoint halves of the chip
+  """The two streams of a paired step: ONE pair per device, shared by every CapturedPairStep of the process.  HIP
+  multiplexes its streams onto a few hardware queues (4 by default), assigned as streams are created: a second
+  CapturedPairStep with a fresh pair of its own (the two-head configs capture one step per head; bench.py captures
+  the replica-de-duplication variant beside the headline step) can find both of its streams on ONE hardware queue --
+  its two views then run one after the other (seen in the kernel trace of the MNIST two-head step: every dispatch of
+  the head-B step on queue 4, profiles/r05_mnist6c_pair_timeline.txt).  The steps of a process run one at a time, so
+  they can share the pair.  (Round 4 measured three alternatives -- the views on disjoint halves of the chip
   through CU-masked streams, half the CUs of every XCD each, view A at high priority: neutral, worse, neutral;
   DESIGN.md section 7.7 -- and round 5 removed the switches.)"""
-  return torch.cuda.Stream(), torch.cuda.Stream()
+  dev = torch.cuda.current_device()
+  pair = _PAIR_STREAMS.get(dev)
+  if pair is None:
+    s1 = torch.cuda.Stream()
+    s2 = torch.cuda.Stream()
+    # which hardware queue a new stream lands on depends on how many streams the process has created before
+    # (a process group's initialisation creates some): keep the first candidate that really runs beside s1
+    for _ in range(6):
+      if _streams_overlap(s1, s2):
+        break
+      s2 = torch.cuda.Stream()
+    pair = _PAIR_STREAMS[dev] = (s1, s2)
+  return pair
+
+
+def _streams_overlap(s1, s2, cycles=1200000):
+  """Do two spin kernels (torch.cuda._sleep, ~0.5 ms each), one per stream, run side by side?  Two streams that share
+  a hardware queue take twice as long as one."""
+  try:
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+    with torch.cuda.stream(s1):
+      torch.cuda._sleep(1000)          # (code object load / first-launch cost outside the timed part)
+      ev[0].record()
+      torch.cuda._sleep(cycles)
+      ev[1].record()
+    torch.cuda.synchronize()
+    single = ev[0].elapsed_time(ev[1])
+    s2.wait_stream(s1)
+    with torch.cuda.stream(s1):
+      ev[2].record()
+      torch.cuda._sleep(cycles)
+      ev[3].record()
+    with torch.cuda.stream(s2):
+      torch.cuda._sleep(cycles)
+      ev[4].record()
+    torch.cuda.synchronize()
+    both = max(ev[2].elapsed_time(ev[3]), ev[2].elapsed_time(ev[4]))
+    return both < 1.5 * single
+  except Exception:      # noqa: BLE001  (a probe never takes the step down)
+    return True
 
 
 class CapturedStep(object):

@@ -136,11 +136,19 @@ class branch(object):
     (_NO_PROXY_BRANCHES.discard if self.proxies else _NO_PROXY_BRANCHES.add)(self.index)
     dev = torch.cuda.current_device()
     key = (dev, self.index)
+    self.main = torch.cuda.current_stream()
     st = _BRANCH_STREAM.get(key)
     if st is None:
       st = torch.cuda.Stream()
+      if not torch.cuda.is_current_stream_capturing():
+        # HIP multiplexes streams onto a few hardware queues: keep a side stream that really runs beside the
+        # caller's (iic_amd.graph._streams_overlap; a pair on one queue would run the two views one after the other)
+        from .graph import _streams_overlap
+        for _ in range(6):
+          if _streams_overlap(self.main, st):
+            break
+          st = torch.cuda.Stream()
       _BRANCH_STREAM[key] = st
-    self.main = torch.cuda.current_stream()
     self.side = st
     st.wait_stream(self.main)                       # fork
     for _, d in _PROXIES.values():                  # last step's branch gradients are consumed
