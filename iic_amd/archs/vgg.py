@@ -156,21 +156,26 @@ class _Stage(object):
 
 
 class _FlattenFn(torch.autograd.Function):
-  """PT [N, h+2P, w+2P, C] interior -> [N, h*w*C] fp32 in (h, w, c) order (data movement)."""
+  """PT [N, h+2P, w+2P, C] interior -> [N, C*h*w] fp32 in the reference's (c, h, w) flatten order (net6c.py:24-25):
+  one strided copy each way, and the heads use their weights as they are (the (h, w, c) order of rounds 1-4 cost a
+  permuted copy of every sub-head's weight per forward and its transpose back per backward: ~20 small launches per
+  optimiser step of a launch-bound net)."""
 
   @staticmethod
   def forward(ctx, x, P):
     N, Hp, Wp, C = x.shape
     ctx.meta = (tuple(x.shape), P)
     ctx.branch, ctx.pt_dtype = ops.BRANCH[0], x.dtype
-    return x[:, P:Hp - P, P:Wp - P, :].float().reshape(N, -1)
+    out = torch.empty((N, C, Hp - 2 * P, Wp - 2 * P), dtype=torch.float32, device=x.device)
+    out.copy_(x[:, P:Hp - P, P:Wp - P, :].permute(0, 3, 1, 2))
+    return out.view(N, -1)
 
   @ops.branch_backward
   def backward(ctx, dfeat):
     shape, P = ctx.meta
     N, Hp, Wp, C = shape
     dx = ops.POOL.alloc(shape, dfeat.device, P)
-    dx[:, P:Hp - P, P:Wp - P, :] = dfeat.contiguous().view(N, Hp - 2 * P, Wp - 2 * P, C).to(dx.dtype)
+    dx[:, P:Hp - P, P:Wp - P, :].copy_(dfeat.contiguous().view(N, C, Hp - 2 * P, Wp - 2 * P).permute(0, 2, 3, 1))
     return dx, None
 
 
@@ -230,7 +235,7 @@ class ClusterNet6cTrunk(VGGTrunkHIP):
 
   def forward(self, x):
     x = self.run_stages(x)
-    return _FlattenFn.apply(x, self.P)   # (h, w, c) order; the head permutes its weights to match
+    return _FlattenFn.apply(x, self.P)   # the reference's (c, h, w) order
 
 
 class ClusterNet6cHead(nn.Module):
@@ -251,10 +256,8 @@ class ClusterNet6cHead(nn.Module):
       nn.Softmax(dim=1)) for _ in range(self.num_sub_heads)])
 
   def forward_packed(self, feats):
-    F_, sp, k = self.num_features, self.sp, self.output_k
-    # reference flatten order is (c, h, w) (net6c.py:24-25); ours is (h, w, c)
-    Wcat = torch.cat([ops.pv(h[0].weight).view(k, F_, sp, sp).permute(0, 2, 3, 1).reshape(k, -1)
-                      for h in self.heads], dim=0)
+    k = self.output_k
+    Wcat = torch.cat([ops.pv(h[0].weight) for h in self.heads], dim=0)
     bcat = torch.cat([ops.pv(h[0].bias) for h in self.heads], dim=0)
     return _HeadsFn.apply(feats, Wcat, bcat, self.num_sub_heads, k)
 
@@ -303,9 +306,8 @@ class ClusterNet6c(_ApplyCounter, nn.Module):
 
 
 def _to_chw_order(feats, head):
-  """Trunk features in the reference's (c, h, w) flatten order (net6c.py:24-25)."""
-  N = feats.size(0)
-  return feats.view(N, head.sp, head.sp, head.num_features).permute(0, 3, 1, 2).reshape(N, -1)
+  """Trunk features in the reference's (c, h, w) flatten order (net6c.py:24-25): what the trunk emits."""
+  return feats
 
 
 class ClusterNet6cTwoHead(_ApplyCounter, nn.Module):

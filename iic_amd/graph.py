@@ -293,7 +293,12 @@ class CapturedPairStep(object):
   def _capture_staged(self, xa, xb, ga, gb, groups, opt_step, pool_a, pool_b, mode):
     from . import ops
     s1, s2 = self.s1, self.s2
-    self.s3 = s3 = torch.cuda.Stream()
+    s3 = torch.cuda.Stream()
+    for _ in range(6):           # a third stream on a hardware queue of its own (see _pair_streams)
+      if _streams_overlap(s1, s3) and _streams_overlap(s2, s3):
+        break
+      s3 = torch.cuda.Stream()
+    self.s3 = s3
     pool_c = torch.cuda.graph_pool_handle()
     n = len(groups)
     taps_a, taps_b = self._taps["a"], self._taps["b"]
