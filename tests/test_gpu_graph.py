@@ -302,3 +302,15 @@ def test_auto_branch_reference_call_sequence_is_bit_identical():
   assert res[0][0] == res[1][0], (res[0][0], res[1][0])
   assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][3], res[1][3]) and res[0][4] == res[1][4] == 8
   assert all(torch.equal(a, b) for a, b in zip(res[0][2], res[1][2]))
+
+
+def test_captured_pair_steps_share_one_stream_pair_that_really_overlaps():
+  """HIP multiplexes streams onto a few hardware queues in creation order: two streams on one queue run their work one
+  after the other (the second CapturedPairStep of a process used to end up there: DESIGN R5.6).  Every captured pair
+  step shares ONE pair per device, chosen by a concurrency probe; the probe itself can tell the difference -- a stream
+  never runs beside itself."""
+  from iic_amd.graph import _pair_streams, _streams_overlap
+  a, b = _pair_streams(), _pair_streams()
+  assert a[0] is b[0] and a[1] is b[1] and a[0] is not a[1]
+  assert _streams_overlap(a[0], a[1])
+  assert not _streams_overlap(a[0], a[0])
