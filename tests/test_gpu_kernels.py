@@ -205,6 +205,37 @@ def test_iid_loss_analytic_pins_and_no_grad():
   assert abs(l.item() - ref) <= _iid_tol(ref)
 
 
+@pytest.mark.parametrize("bn,k,lamb", [(1, 2, 1.0), (2, 3, 1.0), (3, 2, 1.5), (5, 7, 0.5), (17, 4, 1.0), (64, 10, 1.5),
+                                       (129, 33, 1.0), (700, 50, 1.0), (41, 280, 1.0)])
+def test_iid_loss_small_ragged_and_strided_inputs_vs_oracle(bn, k, lamb):
+  """Edge shapes of the drop-in boundary (IID_losses.py:6-47): a last batch of one or two rows, k = 2, lamb != 1, and
+  NON-CONTIGUOUS inputs (row slices and the column-sliced views a packed head output hands to the per-sub-head calls) --
+  loss, loss_no_lamb and both input gradients against the float64 oracle at the north-star tolerance."""
+  from iic_amd.losses import IID_loss
+  from oracle import iid_oracle
+  z, zt = iid_oracle.make_softmax_pair(bn, k, "trained", 100 + bn + k)
+  # strided views of larger buffers: every other row of a [2*bn, k] tensor, and a [bn, 3, k] pack's middle slice
+  big = torch.zeros(2 * bn, k, device=dev())
+  big[::2] = torch.from_numpy(z).to(dev())
+  a = big[::2].detach().requires_grad_(True)
+  pack = torch.zeros(bn, 3, k, device=dev())
+  pack[:, 1, :] = torch.from_numpy(zt).to(dev())
+  pack.requires_grad_(True)
+  b = pack[:, 1, :]
+  assert not b.is_contiguous() or bn == 1
+  loss, loss_nl = IID_loss(a, b, lamb=lamb)
+  (loss + 0.25 * loss_nl).backward()
+  ref, ref_nl, dz, dzt = iid_oracle.iid_loss_np(z, zt, lamb, 1.0, 0.25)
+  assert abs(loss.item() - ref) <= _iid_tol(ref), (loss.item(), ref)
+  assert abs(loss_nl.item() - ref_nl) <= _iid_tol(ref_nl), (loss_nl.item(), ref_nl)
+  ga = a.grad.cpu().numpy().astype(np.float64)
+  gb = pack.grad[:, 1, :].cpu().numpy().astype(np.float64)
+  for got, want in ((ga, dz), (gb, dzt)):
+    nrm = max(np.linalg.norm(want), 1e-30)
+    assert np.linalg.norm(got - want) / nrm <= 2e-5, np.linalg.norm(got - want) / nrm
+  assert float(pack.grad[:, 0, :].abs().max()) == 0.0 and float(pack.grad[:, 2, :].abs().max()) == 0.0
+
+
 # --------------------------------------------------------------------------------------
 # conv: implicit GEMM forward / backward-data / backward-weight
 # --------------------------------------------------------------------------------------
