@@ -929,3 +929,55 @@ def test_net5g_five_input_channels_fp32_mode_vs_oracle():
     assert d.mean().item() <= 3e-2, d.mean().item()
     assert (bo[i].detach().cpu().argmax(1) == ro[i].detach().argmax(1)).float().mean().item() >= 0.75
   assert all(torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+def test_net5g_feature_flags_vs_oracle():
+  """The three feature taps of ClusterNet5g.forward (net5g.py:95-103, used by the reference's k-means / semi-supervised
+  tooling): `trunk_features` (512-d pooled features), `penultimate_features` (layer 3's output flattened in (c, h, w) order,
+  layer 4 and the pool skipped), `kmeans_use_features` (the features repeated once per sub-head) -- on the exact-fp32
+  kernels against the CPU restatement, train and eval mode, and the gradient through the penultimate tap."""
+  from iic_amd import archs, ops
+  from iic_amd.transforms import sobel_process
+  from oracle import net_oracle
+  params = net_oracle.make_net5g_params(2, 10, 2, True, seed=31, randomize_bn=True, head_std=0.3)
+  imgs, _ = net_oracle.make_paired_batch(12, 32, 3, seed=32)
+  xc = net_oracle.sobel_process(imgs, False)
+  net = archs.ClusterNet5g(_cfg())
+  net.load_state_dict(params, strict=True)
+  net.to(dev())
+  x = sobel_process(imgs.to(dev()), False)
+  for training in (True, False):
+    net.train(training)
+    want_f = net_oracle.net5g_trunk({k: v.clone() for k, v in params.items()}, xc, training, 32)
+    want_p = net_oracle.net5g_trunk({k: v.clone() for k, v in params.items()}, xc, training, 32, penultimate_features=True)
+    with torch.no_grad(), ops.fp32_mode():
+      # (a training-mode forward updates the running statistics: reload so that both taps see the same state)
+      net.load_state_dict(params, strict=True)
+      f = net(x, trunk_features=True)
+      net.load_state_dict(params, strict=True)
+      p = net(x, trunk_features=True, penultimate_features=True)
+      net.load_state_dict(params, strict=True)
+      km = net(x, kmeans_use_features=True)
+    assert f.shape == want_f.shape == (12, 512) and p.shape == want_p.shape
+    assert (f.cpu() - want_f).abs().max().item() <= 2e-4 * max(1.0, want_f.abs().max().item())
+    assert (p.cpu() - want_p).abs().max().item() <= 2e-4 * max(1.0, want_p.abs().max().item())
+    assert len(km) == 2 and all(torch.equal(t, km[0]) for t in km) and (km[0].cpu() - want_f).abs().max().item() <= 2e-4 * max(1.0, want_f.abs().max().item())
+  # gradient through the penultimate tap (training mode)
+  net.train()
+  net.load_state_dict(params, strict=True)
+  rp = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone())
+        for k, v in params.items()}
+  wp = net_oracle.net5g_trunk(rp, xc, True, 32, penultimate_features=True)
+  g = torch.Generator().manual_seed(33)
+  up = torch.randn(wp.shape, generator=g)
+  (wp * up).sum().backward()
+  with ops.fp32_mode():
+    p = net(x, trunk_features=True, penultimate_features=True)
+  (p * up.to(dev())).sum().backward()
+  torch.cuda.synchronize()
+  for n, q in net.named_parameters():
+    if n.startswith("trunk.layer4") or n.startswith("head"):
+      assert q.grad is None or float(q.grad.abs().max()) == 0.0, n
+      continue
+    gn = float(rp[n].grad.double().norm())
+    assert abs(float(q.grad.double().norm()) - gn) <= 1e-2 * max(gn, 1e-6) + 1e-9, (n, float(q.grad.double().norm()), gn)
