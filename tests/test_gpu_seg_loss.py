@@ -2,6 +2,7 @@
 vectors and the float64 oracle.  pytest -m gpu.  Tolerance = the loss clause of the
 north star: |ours - ref| <= 1e-5*|ref64| + 2e-7; gradients ||d||/||g|| <= 1e-5, or no worse
 than the fp32 reference's own error w.r.t. float64."""
+import math
 import os
 
 import numpy as np
@@ -63,7 +64,10 @@ def test_seg_loss_golden(ci, collapsed):
     assert err <= max(1e-5, np.linalg.norm(g32 - g64) / nrm), (key, err)
 
 
-@pytest.mark.parametrize("bn,k,h,w,T", [(3, 15, 40, 64, 10), (2, 24, 24, 40, 5), (2, 45, 16, 32, 3), (2, 3, 30, 50, 1)])
+@pytest.mark.parametrize("bn,k,h,w,T", [(3, 15, 40, 64, 10), (2, 24, 24, 40, 5), (2, 45, 16, 32, 3), (2, 3, 30, 50, 1),
+                                        # edge shapes: no shift at all, one sample, k = 2, odd sizes (w % 4 != 0 and k > 32 take the
+                                        # generic kernels), a shift range almost as large as the image
+                                        (1, 2, 9, 13, 0), (2, 3, 17, 23, 2), (1, 33, 8, 12, 1), (2, 5, 8, 9, 6)])
 @pytest.mark.parametrize("collapsed", [False, True])
 def test_seg_loss_larger_vs_oracle(bn, k, h, w, T, collapsed):
   from iic_amd import seg_losses
@@ -74,6 +78,27 @@ def test_seg_loss_larger_vs_oracle(bn, k, h, w, T, collapsed):
   fh = seg_losses.IID_segmentation_loss if collapsed else seg_losses.IID_segmentation_loss_uncollapsed
   fr = iid_oracle.IID_segmentation_loss if collapsed else iid_oracle.IID_segmentation_loss_uncollapsed
   _check(fh, fr, x1, x2, aff, mask, 1.5, T)
+
+
+def test_seg_loss_shift_range_beyond_the_image_is_nan_like_the_reference():
+  """half_T_side_dense >= the image side: shifts without any overlap have an all-zero joint, the uncollapsed loss
+  normalises every shift by its own sum (IID_losses.py:130-157) => 0 / 0: the reference returns NaN, so do we (no published
+  run comes near: T = 10 on 128 / 200-pixel images).  The collapsed loss sums the shifts first and stays finite."""
+  from iic_amd import seg_losses
+  from oracle import iid_oracle
+  from oracle.gen_golden import make_seg_inputs
+  x1, x2, aff, mask = make_seg_inputs(2, 5, 6, 7, 0.5, 0.8, 7)
+  kw = dict(lamb=1.5, half_T_side_dense=6)
+  r, _ = iid_oracle.IID_segmentation_loss_uncollapsed(
+    torch.from_numpy(x1).double().requires_grad_(True), torch.from_numpy(x2).double().requires_grad_(True),
+    all_affine2_to_1=torch.from_numpy(aff).double(), all_mask_img1=torch.from_numpy(mask).double(), **kw)
+  a = torch.from_numpy(x1).float().to(dev()).requires_grad_(True)
+  b = torch.from_numpy(x2).float().to(dev()).requires_grad_(True)
+  l, _ = seg_losses.IID_segmentation_loss_uncollapsed(
+    a, b, all_affine2_to_1=torch.from_numpy(aff).float().to(dev()), all_mask_img1=torch.from_numpy(mask).float().to(dev()),
+    half_T_side_sparse_min=0, half_T_side_sparse_max=0, **kw)
+  assert math.isnan(float(r.detach())) and math.isnan(float(l.detach()))
+  _check(seg_losses.IID_segmentation_loss, iid_oracle.IID_segmentation_loss, x1, x2, aff, mask, 1.5, 6)
 
 
 @pytest.mark.parametrize("case_i", range(7))
