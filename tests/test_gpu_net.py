@@ -981,3 +981,27 @@ def test_net5g_feature_flags_vs_oracle():
       continue
     gn = float(rp[n].grad.double().norm())
     assert abs(float(q.grad.double().norm()) - gn) <= 1e-2 * max(gn, 1e-6) + 1e-9, (n, float(q.grad.double().norm()), gn)
+
+
+@pytest.mark.parametrize("n_img,track,training", [(1, True, True), (2, True, False), (3, False, False), (5, False, True)])
+def test_net5g_tiny_batches_and_batchnorm_modes_vs_oracle(n_img, track, training):
+  """Corners of the BatchNorm semantics on whole-net forwards: one image per batch (statistics over its
+  pixels only), eval mode on the running statistics, and `batchnorm_track` absent (track_running_stats=False: batch
+  statistics even in eval()) -- exact-fp32 kernels against the CPU restatement on the same parameters."""
+  from iic_amd import archs, ops
+  from iic_amd.transforms import sobel_process
+  from oracle import net_oracle
+  params = net_oracle.make_net5g_params(2, 10, 2, track, seed=41, randomize_bn=True, head_std=0.3)
+  g = torch.Generator().manual_seed(42 + n_img)
+  imgs = torch.rand(n_img, 1, 32, 32, generator=g)
+  xc = net_oracle.sobel_process(imgs, False)
+  # the oracle's _batchnorm uses batch statistics whenever training or no running statistics exist
+  want = net_oracle.net5g_forward({k: v.clone() for k, v in params.items()}, xc, training or not track, 32, "head", 2)
+  net = archs.ClusterNet5g(_cfg(batchnorm_track=track))
+  net.load_state_dict(params, strict=True)
+  net.to(dev()).train(training)
+  with torch.no_grad(), ops.fp32_mode():
+    got = net(sobel_process(imgs.to(dev()), False))
+  for a, b in zip(got, want):
+    assert a.shape == b.shape == (n_img, 10)
+    assert (a.cpu() - b).abs().max().item() <= 3e-4, (a.cpu() - b).abs().max().item()
