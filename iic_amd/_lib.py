@@ -89,6 +89,8 @@ _SIGNATURES = {
   "iic_firstconv_wgrad": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
   "iic_maxpool2_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
   "iic_maxpool2_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+  "iic_bn_relu_maxpool2_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+  "iic_bn_relu_maxpool2_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
   "iic_sobel": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
   "iic_avgpool_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
   "iic_avgpool_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),

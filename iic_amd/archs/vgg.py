@@ -18,6 +18,11 @@ from .. import ops
 from ..dist import shard_batch
 from .cluster import FUSE_RED, _ApplyCounter, _ConvHolder, _HeadsFn, _bn_buffers, _bn_training
 
+import os
+
+# IIC_FUSE_POOL=0: store the pooled stages' activation and pool it in a separate pass (cross-check of the fused kernels)
+FUSE_POOL = [os.environ.get("IIC_FUSE_POOL", "1") != "0"]
+
 __all__ = ["ClusterNet6c", "ClusterNet6cTwoHead"]
 
 
@@ -62,12 +67,20 @@ class _StageFn(torch.autograd.Function):
                              rv if upd else None, nbt if upd else None, C, cnt, True)
     else:
       coef = ops.bn_finalize(None, gamma.detach(), beta.detach(), rm, rv, None, C, cnt, False)
-    a = ops.pt_alloc(N, Ho, Wo, C, P, dev)
-    ops.bn_apply(y, coef, a, N, Ho, Wo, P, C, relu=True)
-    out = a
-    if st.pool:
+    # pooled stages (bf16 path): the activation a = relu(bn(y)) is never stored -- the pool recomputes it from (y, coef)
+    # bit for bit, forward and backward (csrc/vgg.hip maxpool2_*_kernel<true>): one full-tensor write + read less
+    fused_pool = st.pool and FUSE_POOL[0] and ops.PT_DTYPE[0] is not torch.float32
+    a = None
+    if fused_pool:
       out = ops.pt_alloc(N, Ho // 2, Wo // 2, C, P, dev)
-      ops.maxpool2_fwd(a, out, N, Ho, Wo, P, P, C)
+      ops.bn_relu_maxpool2_fwd(y, coef, out, N, Ho, Wo, P, P, C)
+    else:
+      a = ops.pt_alloc(N, Ho, Wo, C, P, dev)
+      ops.bn_apply(y, coef, a, N, Ho, Wo, P, C, relu=True)
+      out = a
+      if st.pool:
+        out = ops.pt_alloc(N, Ho // 2, Wo // 2, C, P, dev)
+        ops.maxpool2_fwd(a, out, N, Ho, Wo, P, P, C)
     need_grad = any(ctx.needs_input_grad)
     if need_grad:
       ctx.st = st
@@ -88,7 +101,7 @@ class _StageFn(torch.autograd.Function):
       ctx.save_for_backward(x, w, gamma, y, a, coef, out if st.pool else None)
     else:
       ops.POOL.release(y)
-      if st.pool:
+      if st.pool and a is not None:
         ops.POOL.release(a)
     return out
 
@@ -104,7 +117,10 @@ class _StageFn(torch.autograd.Function):
     cnt = N * Ho * Wo
     if st.pool:
       da = ops.pt_alloc(N, Ho, Wo, C, P, dev)
-      ops.maxpool2_bwd(a, dout, da, N, Ho, Wo, P, P, C)
+      if a is None:          # fused pool: the arg-max is taken on the activation recomputed from (y, coef)
+        ops.bn_relu_maxpool2_bwd(y, coef, dout, da, N, Ho, Wo, P, P, C)
+      else:
+        ops.maxpool2_bwd(a, dout, da, N, Ho, Wo, P, P, C)
       ops.POOL.release(dout)
       ops.POOL.release(pooled)
     else:

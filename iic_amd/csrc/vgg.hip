@@ -243,7 +243,21 @@ __device__ __forceinline__ void unpack8v(const uint4 v, float* f) {
   f[4] = bf16lo(v.z); f[5] = bf16hi(v.z); f[6] = bf16lo(v.w); f[7] = bf16hi(v.w);
 }
 
+// BN = true: `in` is the convolution output y of a pooled stage and the activation a = relu(scale*y + shift) is never
+// stored: every element is recomputed as bn_apply_kernel (bn.hip) would have written it -- the same expression, rounded
+// to bf16 -- before it enters the window (forward: one full-tensor write and one read less per pooled stage; the
+// backward's arg-max sees the same bits).  sc / sh: this thread's 8 channels of coef[0][C], coef[1][C].
+__device__ __forceinline__ void bn_relu_bf16_8(float* v, const float* sc, const float* sh) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i] * sc[i] + sh[i], 0.f);
+  const uint4 r = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                             pack_bf16x2(v[6], v[7]));
+  unpack8v(r, v);
+}
+
+template <bool BN>
 __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const bf16_t* __restrict__ in,
+                                                           const float* __restrict__ coef,
                                                            bf16_t* __restrict__ out, int H, int W,
                                                            int Pi, int Po, int C) {
   const int Ho = H / 2, Wo = W / 2, c8n = C >> 3;
@@ -252,7 +266,14 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const bf16_t* __restr
   const int xo = item / c8n, c8 = item - xo * c8n;
   const int n = blockIdx.x / Ho, yo = blockIdx.x - n * Ho;
   const int Hpi = H + 2 * Pi, Wpi = W + 2 * Pi, Hpo = Ho + 2 * Po, Wpo = Wo + 2 * Po;
-  float m[8];
+  float m[8], sc[BN ? 8 : 1], sh[BN ? 8 : 1];
+  if (BN) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      sc[BN ? i : 0] = coef[c8 * 8 + i];
+      sh[BN ? i : 0] = coef[C + c8 * 8 + i];
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 8; ++i) m[i] = -INFINITY;
 #pragma unroll
@@ -260,6 +281,7 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const bf16_t* __restr
     const long off = (((long)n * Hpi + 2 * yo + (q >> 1) + Pi) * Wpi + 2 * xo + (q & 1) + Pi) * C + c8 * 8;
     float v[8];
     unpack8v(*reinterpret_cast<const uint4*>(in + off), v);
+    if (BN) bn_relu_bf16_8(v, sc, sh);
 #pragma unroll
     for (int i = 0; i < 8; ++i) m[i] = fmaxf(m[i], v[i]);
   }
@@ -270,7 +292,9 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const bf16_t* __restr
 
 // din[4 window positions] = dout at the FIRST arg-max in scan order (torch), 0 elsewhere.
 // Odd trailing rows / columns of the input (not covered by any window) receive 0.
+template <bool BN>
 __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const bf16_t* __restrict__ in,
+                                                           const float* __restrict__ coef,
                                                            const bf16_t* __restrict__ dout,
                                                            bf16_t* __restrict__ din, int H, int W,
                                                            int Pi, int Po, int C) {
@@ -282,7 +306,14 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const bf16_t* __restr
   const int n = blockIdx.x / Hc, yo = blockIdx.x - n * Hc;
   const int Hpi = H + 2 * Pi, Wpi = W + 2 * Pi, Hpo = Ho + 2 * Po, Wpo = Wo + 2 * Po;
   const bool win = yo < Ho && xo < Wo;
-  float v[4][8], g[8];
+  float v[4][8], g[8], sc[BN ? 8 : 1], sh[BN ? 8 : 1];
+  if (BN) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      sc[BN ? i : 0] = coef[c8 * 8 + i];
+      sh[BN ? i : 0] = coef[C + c8 * 8 + i];
+    }
+  }
   long offs[4];
   bool ok[4];
 #pragma unroll
@@ -290,7 +321,10 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const bf16_t* __restr
     const int yy = 2 * yo + (q >> 1), xx = 2 * xo + (q & 1);
     ok[q] = yy < H && xx < W;
     offs[q] = (((long)n * Hpi + yy + Pi) * Wpi + xx + Pi) * C + c8 * 8;
-    if (ok[q] && win) unpack8v(*reinterpret_cast<const uint4*>(in + offs[q]), v[q]);
+    if (ok[q] && win) {
+      unpack8v(*reinterpret_cast<const uint4*>(in + offs[q]), v[q]);
+      if (BN) bn_relu_bf16_8(v[q], sc, sh);
+    }
   }
   if (win) {
     const long o = (((long)n * Hpo + yo + Po) * Wpo + xo + Po) * C + c8 * 8;
@@ -376,8 +410,8 @@ int iic_maxpool2_fwd(const void* in_pt, void* out_pt, int N, int H, int W, int P
                      void* stream) {
   if (!in_pt || !out_pt || N <= 0 || H < 2 || W < 2 || (C & 7)) return IIC_ERR_ARG;
   dim3 grid(N * (H / 2), ((W / 2) * (C / 8) + 255) / 256);
-  hipLaunchKernelGGL(maxpool2_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)in_pt, (bf16_t*)out_pt, H, W, Pi, Po, C);
+  hipLaunchKernelGGL(maxpool2_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)in_pt, (const float*)nullptr, (bf16_t*)out_pt, H, W, Pi, Po, C);
   return iic_launch_status();
 }
 
@@ -385,8 +419,27 @@ int iic_maxpool2_bwd(const void* in_pt, const void* dout_pt, void* din_pt, int N
                      int Pi, int Po, int C, void* stream) {
   if (!in_pt || !dout_pt || !din_pt || N <= 0 || H < 2 || W < 2 || (C & 7)) return IIC_ERR_ARG;
   dim3 grid(N * ((H + 1) / 2), (((W + 1) / 2) * (C / 8) + 255) / 256);
-  hipLaunchKernelGGL(maxpool2_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)in_pt, (const bf16_t*)dout_pt, (bf16_t*)din_pt, H, W, Pi, Po, C);
+  hipLaunchKernelGGL(maxpool2_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)in_pt, (const float*)nullptr, (const bf16_t*)dout_pt, (bf16_t*)din_pt, H, W, Pi,
+                     Po, C);
+  return iic_launch_status();
+}
+
+int iic_bn_relu_maxpool2_fwd(const void* y_pt, const float* coef, void* out_pt, int N, int H, int W, int Pi,
+                             int Po, int C, void* stream) {
+  if (!y_pt || !coef || !out_pt || N <= 0 || H < 2 || W < 2 || (C & 7)) return IIC_ERR_ARG;
+  dim3 grid(N * (H / 2), ((W / 2) * (C / 8) + 255) / 256);
+  hipLaunchKernelGGL(maxpool2_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)y_pt, coef, (bf16_t*)out_pt, H, W, Pi, Po, C);
+  return iic_launch_status();
+}
+
+int iic_bn_relu_maxpool2_bwd(const void* y_pt, const float* coef, const void* dout_pt, void* din_pt, int N,
+                             int H, int W, int Pi, int Po, int C, void* stream) {
+  if (!y_pt || !coef || !dout_pt || !din_pt || N <= 0 || H < 2 || W < 2 || (C & 7)) return IIC_ERR_ARG;
+  dim3 grid(N * ((H + 1) / 2), (((W + 1) / 2) * (C / 8) + 255) / 256);
+  hipLaunchKernelGGL(maxpool2_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)y_pt, coef, (const bf16_t*)dout_pt, (bf16_t*)din_pt, H, W, Pi, Po, C);
   return iic_launch_status();
 }
 

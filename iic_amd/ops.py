@@ -953,6 +953,22 @@ def maxpool2_fwd(x_pt, out_pt, N, H, W, Pi, Po, C):
   return out_pt
 
 
+def bn_relu_maxpool2_fwd(y_pt, coef, out_pt, N, H, W, Pi, Po, C):
+  """out = maxpool2(relu(bn(y))) without storing the activation (bf16 PT tensors only; include/iic_hip.h)."""
+  assert y_pt.dtype == BF16
+  check(lib().iic_bn_relu_maxpool2_fwd(ptr(y_pt), ptr(coef), ptr(out_pt), N, H, W, Pi, Po, C, stream_ptr()),
+        "iic_bn_relu_maxpool2_fwd")
+  return out_pt
+
+
+def bn_relu_maxpool2_bwd(y_pt, coef, dout_pt, din_pt, N, H, W, Pi, Po, C):
+  """din = gradient w.r.t. a = relu(bn(y)) of that pool: dout at the first arg-max of the recomputed a."""
+  assert y_pt.dtype == BF16
+  check(lib().iic_bn_relu_maxpool2_bwd(ptr(y_pt), ptr(coef), ptr(dout_pt), ptr(din_pt), N, H, W, Pi, Po, C,
+                                       stream_ptr()), "iic_bn_relu_maxpool2_bwd")
+  return din_pt
+
+
 def maxpool2_bwd(x_pt, dout_pt, din_pt, N, H, W, Pi, Po, C):
   if x_pt.dtype == F32:
     check(lib().iic_f32_maxpool2_bwd(ptr(x_pt), ptr(dout_pt), ptr(din_pt), N, H, W, Pi, Po, C, stream_ptr()),

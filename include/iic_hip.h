@@ -287,6 +287,15 @@ int iic_maxpool2_fwd(const void* in_pt, void* out_pt, int N, int H, int W, int P
                      void* stream);
 int iic_maxpool2_bwd(const void* in_pt, const void* dout_pt, void* din_pt, int N, int H, int W,
                      int Pi, int Po, int C, void* stream);
+/* The same pool behind a BatchNorm + ReLU whose output is never stored (the pooled stages of vgg.py:19-30): y_pt is the
+ * convolution output (PT bf16), coef the BatchNorm's forward coefficients (iic_bn_finalize); every element enters the
+ * window as a = bf16(relu(scale*y + shift)) -- bit for bit what iic_bn_apply would have written.  Forward: out = maxpool(a)
+ * (one full-tensor write and one read less per pooled stage); backward: din (gradient w.r.t. a) = dout at the first
+ * arg-max of a in scan order, 0 elsewhere.                                                                            */
+int iic_bn_relu_maxpool2_fwd(const void* y_pt, const float* coef, void* out_pt, int N, int H, int W, int Pi,
+                             int Po, int C, void* stream);
+int iic_bn_relu_maxpool2_bwd(const void* y_pt, const float* coef, const void* dout_pt, void* din_pt, int N,
+                             int H, int W, int Pi, int Po, int C, void* stream);
 /* Sobel pre-op -- replaces code/utils/cluster/transforms.py:47-96 (grey channel -> dx,dy;
  * other channels copied through in the reference's order).                              */
 int iic_sobel(const float* imgs, float* out, int N, int C, int H, int W, int include_rgb,

@@ -72,6 +72,72 @@ def test_maxpool2_forward_backward(C, S):
   assert torch.equal(ops.pt_to_nchw(din, P).cpu(), xt.grad)
 
 
+@pytest.mark.parametrize("C,H,W", [(64, 24, 24), (128, 12, 12), (256, 6, 6), (64, 7, 9), (128, 200, 10)])
+def test_fused_bn_relu_maxpool_is_bit_identical_to_the_two_pass_path(C, H, W):
+  """The pooled stages never store relu(bn(y)): the pool recomputes it from (y, coef) -- forward and backward against
+  iic_bn_apply followed by the plain pool, bit for bit, on activations full of ties (ReLU zeros) and with odd sizes
+  (rows / columns no window covers get zero gradient), borders untouched."""
+  from iic_amd import ops
+  N, P = 3, 2
+  d = dev()
+  g = torch.Generator().manual_seed(C + H)
+  y = torch.zeros((N, H + 2 * P, W + 2 * P, C), dtype=torch.bfloat16)
+  y[:, P:P + H, P:P + W] = torch.randn(N, H, W, C, generator=g).to(torch.bfloat16)
+  y = y.to(d)
+  coef = torch.zeros(5, C)
+  coef[0] = torch.randn(C, generator=g)          # scales of both signs
+  coef[1] = torch.randn(C, generator=g) * 0.5
+  coef = coef.to(d)
+  Ho, Wo = H // 2, W // 2
+  dout = torch.zeros((N, Ho + 2 * P, Wo + 2 * P, C), dtype=torch.bfloat16)
+  dout[:, P:P + Ho, P:P + Wo] = torch.randn(N, Ho, Wo, C, generator=g).to(torch.bfloat16)
+  dout = dout.to(d)
+  a = torch.zeros_like(y)
+  ops.bn_apply(y, coef, a, N, H, W, P, C, relu=True)
+  o_ref = torch.full((N, Ho + 2 * P, Wo + 2 * P, C), 7.0, dtype=torch.bfloat16, device=d)
+  o_fus = o_ref.clone()
+  ops.maxpool2_fwd(a, o_ref, N, H, W, P, P, C)
+  ops.bn_relu_maxpool2_fwd(y, coef, o_fus, N, H, W, P, P, C)
+  d_ref = torch.full_like(y, 7.0)
+  d_fus = torch.full_like(y, 7.0)
+  ops.maxpool2_bwd(a, dout, d_ref, N, H, W, P, P, C)
+  ops.bn_relu_maxpool2_bwd(y, coef, dout, d_fus, N, H, W, P, P, C)
+  torch.cuda.synchronize()
+  assert torch.equal(o_ref, o_fus) and torch.equal(d_ref, d_fus)
+  assert float((a == 0).float().mean()) > 0.2          # the ties are really there
+  border = d_fus.clone()
+  border[:, P:P + H, P:P + W] = 7.0
+  assert (border == 7.0).all()
+
+
+def test_net6c_step_with_and_without_the_fused_pool_is_bit_identical():
+  """Whole ClusterNet6c train step (three pooled stages): IIC_FUSE_POOL on / off -- outputs, loss and every gradient."""
+  from iic_amd import archs
+  from iic_amd.archs import vgg
+  from iic_amd.losses import IID_loss
+  from oracle import net_oracle
+  cfg = types.SimpleNamespace(in_channels=1, input_sz=24, batchnorm_track=True, num_sub_heads=2, output_k=10)
+  params = net_oracle.make_net6c_params(1, 24, 10, 2, True, seed=4, randomize_bn=True, head_std=0.05)
+  x6, x6t = net_oracle.make_paired_batch(24, 24, 3, seed=6)
+  res = {}
+  try:
+    for fused in (True, False):
+      vgg.FUSE_POOL[0] = fused
+      net = archs.ClusterNet6c(cfg)
+      net.load_state_dict(params, strict=True)
+      net.to(dev()).train()
+      xo, xt = net(x6.to(dev())), net(x6t.to(dev()))
+      tot = sum(IID_loss(xo[i], xt[i], lamb=1.0)[0] for i in range(2)) / 2
+      tot.backward()
+      torch.cuda.synchronize()
+      res[fused] = ([o.detach().clone() for o in xo + xt], tot.detach().clone(),
+                    [p.grad.detach().clone() for p in net.parameters()])
+  finally:
+    vgg.FUSE_POOL[0] = True
+  for a, b in zip(res[True][0] + [res[True][1]] + res[True][2], res[False][0] + [res[False][1]] + res[False][2]):
+    assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("idx,first,pool,cin,S", [(0, True, True, 1, 24), (4, False, True, 64, 12), (12, False, False, 256, 3)])
 def test_vgg_stage_teacher_forced(idx, first, pool, cin, S):
   """One conv-BN-ReLU(-pool) stage Function, forward + backward, vs the bf16-emulating oracle
