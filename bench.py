@@ -837,8 +837,19 @@ def main():
     if rank == 0:
       timer = ConvTimer()
       timer.install()
+    # The stream is parked in front of every instrumented step so that the host can enqueue the whole step behind it
+    # (gpu_hold).  How long that takes depends on the host (20-40 ms on most boxes, > 80 ms on slow ones -- where a
+    # fixed 80 ms hold read frac 0.25 for kernels whose rocprofv3 durations had not changed): a probe step measures it,
+    # its records are dropped, the measured steps are parked for 1.5 x that.
+    gpu_hold(80.0)
+    t_h = time.perf_counter()
+    step()
+    hold_ms = min(400.0, max(80.0, 1.5e3 * (time.perf_counter() - t_h) + 20.0))
+    fence()
+    if timer is not None:
+      del timer.records[:]
     for _ in range(min(args.steps, 3)):
-      gpu_hold(80.0)          # the host enqueues an eager step in 20-40 ms: let it get ahead of the stream
+      gpu_hold(hold_ms)
       step()
     fence()
     if timer is not None:
