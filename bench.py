@@ -32,6 +32,7 @@ OUTPUT_K = 70
 SUB_HEADS = 5
 FLOP_PER_PAIR = 36.35e9      # BASELINE.md §4 (algorithmic, fwd + bwd-data + bwd-weight, 2 images)
 BF16_PEAK_TFLOPS = 2500.0    # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0        # HBM3E (same guide; 6.3 TB/s is what a streaming kernel measures)
 
 
 def make_batch(n_pairs, sz, device, seed=0):
@@ -46,6 +47,108 @@ def make_batch(n_pairs, sz, device, seed=0):
   noise = torch.randn(imgs.shape, generator=g) * 0.05
   imgs_tf = torch.clamp(torch.flip(imgs, dims=[3]) * gain + noise, 0.0, 1.0)
   return imgs.to(device).contiguous(), imgs_tf.to(device).contiguous()
+
+
+def _free_port():
+  import socket
+  sk = socket.socket()
+  sk.bind(("127.0.0.1", 0))
+  p = sk.getsockname()[1]
+  sk.close()
+  return p
+
+
+def self_launch(args):
+  """`python bench.py --gpus N` (N > 1) outside a launcher: become N ranks -- the reference's counterpart is one line
+  that just works (torch.nn.DataParallel over the visible devices: cluster_sobel.py:146, segmentation_twohead.py:173).
+  Re-executes this command under `python -m torch.distributed.run --nproc-per-node N` (one process per GPU, RCCL); exits
+  non-zero with a message when the box has fewer than N devices -- never a silent 1-rank run."""
+  backend = os.environ.get("IIC_DIST_BACKEND", "nccl")
+  ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+  if ndev < args.gpus and backend == "nccl":
+    sys.stderr.write("bench.py: --gpus %d needs %d MI355X devices, this machine has %d (RCCL wants one device per rank; "
+                     "IIC_DIST_BACKEND=gloo runs the ranks on shared devices as a functional check only)\n"
+                     % (args.gpus, args.gpus, ndev))
+    sys.exit(2)
+  if ndev == 0:
+    sys.stderr.write("bench.py: no GPU visible\n")
+    sys.exit(2)
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+  sys.stderr.write("bench.py: --gpus %d without a launcher environment: %s\n" % (args.gpus, " ".join(cmd)))
+  sys.stderr.flush()
+  os.execv(sys.executable, cmd)
+
+
+class Ranks(object):
+  """This process's place in the job: WORLD_SIZE / RANK / LOCAL_RANK from the launcher, the device, the process group
+  (RCCL unless IIC_DIST_BACKEND says otherwise).  `on` = the collectives run: world > 1, or IIC_DIST_FORCE=1 at world
+  size 1 (a single MI355X then executes the whole N > 1 path through real RCCL calls: tests/test_gpu_rccl.py)."""
+
+  def __init__(self, args):
+    self.world = int(os.environ.get("WORLD_SIZE", "1"))
+    self.rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+      sys.stderr.write("bench.py needs an MI355X\n")
+      sys.exit(2)
+    if args.gpus != self.world:
+      sys.stderr.write("bench.py: --gpus %d but the launcher started %d rank(s) (torchrun --nproc-per-node must equal "
+                       "--gpus)\n" % (args.gpus, self.world))
+      sys.exit(2)
+    ndev = torch.cuda.device_count()
+    self.backend = os.environ.get("IIC_DIST_BACKEND", "nccl")   # "gloo": functional check of the N>1
+    if local_rank >= ndev:                                      # path on a 1-GPU box (ranks share cuda:0)
+      if self.backend == "nccl" and os.environ.get("IIC_RCCL_SHARED_DEVICE", "0") != "1":
+        sys.stderr.write("bench.py: rank %d has no device of its own (%d visible) and RCCL wants one per rank\n"
+                         % (self.rank, ndev))
+        sys.exit(2)
+      local_rank = local_rank % ndev
+    torch.cuda.set_device(local_rank)
+    self.dev = torch.device("cuda", local_rank)
+    self.on = self.world > 1 or os.environ.get("IIC_DIST_FORCE", "0") == "1"
+    if self.on:
+      import torch.distributed as dist
+      os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+      os.environ.setdefault("MASTER_PORT", str(_free_port()))
+      kw = {"device_id": self.dev} if (self.backend == "nccl" and os.environ.get("IIC_RCCL_EAGER_INIT", "0") == "1") else {}
+      dist.init_process_group(self.backend, rank=self.rank, world_size=self.world, **kw)
+      from iic_amd import dist as idist
+      idist.enable()
+
+  def broadcast(self, net):
+    if self.on:      # identical weights (and BatchNorm buffers) on every rank
+      from iic_amd import dist as idist
+      idist.broadcast_module_state(net, 0)
+
+  def fence(self):
+    torch.cuda.synchronize()
+    if self.on:
+      torch.distributed.barrier()
+    torch.cuda.synchronize()
+
+  def max_over_ranks(self, dt):
+    if not self.on:
+      return dt
+    t = torch.tensor([dt], device=self.dev, dtype=torch.float64)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    return float(t)
+
+  def report(self):
+    """What the record says about the data-parallel side of the run."""
+    if not self.on:
+      return None
+    from iic_amd import dist as idist
+    from iic_amd import graph as igraph
+    return {"backend": "%s%s" % (self.backend, " (= RCCL)" if self.backend == "nccl" else ""), "world_size": self.world,
+            "forced_at_world_size_1": self.world == 1,
+            "collectives_issued_by_rank0": dict(idist.CALLS),
+            "stream_probes": igraph.PROBE_LOG[-24:]}
+
+  def close(self):
+    if self.on:
+      torch.distributed.destroy_process_group()
+
 
 
 _HOLD = {}
@@ -69,25 +172,38 @@ def gpu_hold(ms):
 
 
 class ConvTimer(object):
-  """HIP-event timing of every implicit-GEMM conv launch on the launch stream (torch's
-  current stream == the stream handed to the C ABI)."""
+  """HIP-event timing of the three kernel families of the step, on the launch stream (torch's current stream == the
+  stream handed to the C ABI), around every call of the wrappers the architectures go through:
+    conv     ops.conv_igemm                       forward + backward-data implicit GEMM      (MFMA roof, bf16)
+    wgrad    ops.conv_wgrad                       weight gradient incl. its split-K reduce   (MFMA roof, bf16)
+    bn       ops.bn_apply / bn_bwd_reduce / bn_bwd_apply   BatchNorm / ReLU / residual passes (HBM roof)
+  Algorithmic work per call from the geometry descriptor / the tensors handed over."""
 
   def __init__(self):
-    self.records = []
-    self.pool = []
+    self.records = []          # conv family (kept under this name: summary() is the bench record's `roofline`)
+    self.fam = {"wgrad": [], "bn": []}
+    self._orig = {}
 
-  def install(self):
-    from iic_amd import ops
-    self._orig = ops.conv_igemm
-    timer = self
+  def _wrap(self, ops, name, fam, work):
+    orig = getattr(ops, name)
+    self._orig[name] = orig
+    dst = self.records if fam == "conv" else self.fam[fam]
 
-    def timed(g, x_pt, w_t, out_pt, stats=None, res_grad=None, res_act=None, accumulate=False,
-              premask=False, red=None):
+    def timed(*a, **k):
       e0 = torch.cuda.Event(enable_timing=True)
       e1 = torch.cuda.Event(enable_timing=True)
       e0.record()
-      r = timer._orig(g, x_pt, w_t, out_pt, stats, res_grad, res_act, accumulate, premask, red)
+      r = orig(*a, **k)
       e1.record()
+      fl, by = work(*a, **k)
+      dst.append((e0, e1, fl, by))
+      return r
+    setattr(ops, name, timed)
+
+  def install(self):
+    from iic_amd import ops
+
+    def conv_work(g, x_pt, w_t, out_pt, stats=None, res_grad=None, res_act=None, accumulate=False, premask=False, red=None):
       flops = 2.0 * g.N * g.MY * g.MX * g.Cout * g.Cin * g.ntaps
       # algorithmic HBM bytes: read the input rows once, write the output rows, read the weight
       # slice once, plus every tensor a fused epilogue must read once (previous contents of an
@@ -97,23 +213,81 @@ class ConvTimer(object):
       extra = sum(1 for t in (res_grad, res_act) if t is not None) + (1 if accumulate else 0)
       if red is not None:
         extra += 1 + (1 if red[3] is not None else 0)
-      abytes = 2.0 * (rows * g.Cin + rows * g.Cout * (1 + extra) + g.ntaps * g.Cout * g.Cin)
-      timer.records.append((e0, e1, flops, abytes))
-      return r
-    ops.conv_igemm = timed
+      return flops, 2.0 * (rows * g.Cin + rows * g.Cout * (1 + extra) + g.ntaps * g.Cout * g.Cin)
+
+    def wgrad_work(g, x_pt, dy_pt, wtaps, *a, **k):
+      rows = float(g.N * g.MY * g.MX)
+      # read the input rows and the gradient rows once (bf16), write the fp32 gradient once
+      return 2.0 * rows * g.Cout * g.Cin * g.ntaps, 2.0 * rows * (g.Cin + g.Cout) + 4.0 * g.ntaps * g.Cout * g.Cin
+
+    def bn_bytes(n_tensors, N, H, W, C):
+      return 0.0, 2.0 * n_tensors * float(N) * H * W * C          # interiors only, bf16
+
+    def bn_apply_work(y, coef, out, N, H, W, P, C, res=None, y2=None, coef2=None, relu=True):
+      return bn_bytes(2 + (res is not None) + (y2 is not None), N, H, W, C)
+
+    def bn_red_work(dout, act, y, sums, N, H, W, P, C, y2=None, sums2=None, mask_coef=None):
+      return bn_bytes(2 + (act is not None) + (y2 is not None), N, H, W, C)
+
+    def bn_bapply_work(dout, act, y, bcoef, dy, N, H, W, P, C, y2=None, bcoef2=None, dy2=None, mask_coef=None):
+      return bn_bytes(3 + (act is not None) + (y2 is not None) + (dy2 is not None), N, H, W, C)
+    self._wrap(ops, "conv_igemm", "conv", conv_work)
+    self._wrap(ops, "conv_wgrad", "wgrad", wgrad_work)
+    self._wrap(ops, "bn_apply", "bn", bn_apply_work)
+    self._wrap(ops, "bn_bwd_reduce", "bn", bn_red_work)
+    self._wrap(ops, "bn_bwd_apply", "bn", bn_bapply_work)
 
   def uninstall(self):
     from iic_amd import ops
-    ops.conv_igemm = self._orig
+    for name, orig in self._orig.items():
+      setattr(ops, name, orig)
+    self._orig = {}
+
+  @staticmethod
+  def _sum(recs):
+    if not recs:
+      return None
+    tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in recs)
+    n = len(recs)
+    return {"launches": n, "avg_us": 1e3 * tot_ms / n, "tflops": sum(f for _, _, f, _ in recs) / (tot_ms * 1e-3) / 1e12,
+            "total_ms": tot_ms, "alg_bytes": sum(b for _, _, _, b in recs) / n,
+            "tbytes_per_s": sum(b for _, _, _, b in recs) / (tot_ms * 1e-3) / 1e12}
 
   def summary(self):
-    if not self.records:
-      return None
-    tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in self.records)
-    tot_fl = sum(f for _, _, f, _ in self.records)
-    n = len(self.records)
-    return {"launches": n, "avg_us": 1e3 * tot_ms / n, "tflops": tot_fl / (tot_ms * 1e-3) / 1e12,
-            "total_ms": tot_ms, "alg_bytes": sum(b for _, _, _, b in self.records) / n}
+    return self._sum(self.records)
+
+  def families(self, n_steps):
+    """[{family, bound, achieved, peak, unit, frac, kernel_ms_per_step, launches_per_step}] -- SURVEY 8d: "balanced:
+    report both fractions"."""
+    out = []
+    for name, recs, bound, what in (
+        ("conv_fwd_bwd_data", self.records, "mfma", "conv_igemm_{bd,pw,p64} + conv_igemm (forward + backward-data)"),
+        ("weight_gradient", self.fam["wgrad"], "mfma", "conv_wgrad_dma / conv_wgrad + conv_wgrad_reduce"),
+        ("bn_hbm", self.fam["bn"], "hbm", "bn_apply + bn_bwd_reduce + bn_bwd_apply (BatchNorm / ReLU / residual passes)")):
+      s = self._sum(recs)
+      if not s:
+        continue
+      ach, peak, unit = (s["tflops"], BF16_PEAK_TFLOPS, "TFLOP/s") if bound == "mfma" else (s["tbytes_per_s"] * 1e3, HBM_PEAK_GBS, "GB/s")
+      out.append({"family": name, "kernels": what, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
+                  "frac": ach / peak, "kernel_ms_per_step": s["total_ms"] / n_steps,
+                  "launches_per_step": s["launches"] / float(n_steps), "algorithmic_bytes_per_launch": s["alg_bytes"]})
+    return out
+
+
+def pmc_step_hbm():
+  """(HBM bytes of one whole step, file) from the newest committed PMC passes (tools/pmc_traffic.py), or (None, None)."""
+  import glob
+  for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")), reverse=True):
+    try:
+      d = json.load(open(p))
+      if d.get("step_hbm_bytes"):
+        return float(d["step_hbm_bytes"]), os.path.relpath(p, ROOT)
+      # (records written before round 6 carry no step total: every launch of the 2-step PMC command, halved)
+      tot = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in d["kernels"].values())
+      return tot / 2.0, os.path.relpath(p, ROOT)
+    except Exception:
+      continue
+  return None, None
 
 
 def pmc_traffic():
@@ -340,14 +514,21 @@ def bench_segmentation(args):
   c = dict(SEG_CONFIGS[args.config])
   if args.T is not None:
     c["T"] = args.T
-  dev = torch.device("cuda", 0)
-  torch.cuda.set_device(0)
+  rk = Ranks(args)
+  dev, world = rk.dev, rk.world
+  from iic_amd import dist as idist
   torch.manual_seed(0)
   cfg = types.SimpleNamespace(in_channels=c["in_ch"], input_sz=c["sz"], batchnorm_track=True, num_sub_heads=1,
                               output_k_A=c["k_A"], output_k_B=c["k_B"])
   net = archs.SegmentationNet10aTwoHead(cfg).to(dev).train()
-  opt = Adam(net.parameters(), lr=1e-4)
-  g = torch.Generator().manual_seed(0)
+  rk.broadcast(net)
+  params = list(net.parameters())
+  opt = Adam(params, lr=1e-4)
+  # N > 1 (BASELINE configs[3] / [4] are 4 / 8 GPUs by name; the reference runs them under nn.DataParallel,
+  # segmentation_twohead.py:173): every rank owns `bn` pairs of its own (weak scaling), the per-shift raw joints are
+  # all-reduced inside the loss (iic_amd/seg_losses.py; additive over samples exactly like the reference's conv over
+  # the batch, segmentation/IID_losses.py:125), the parameter gradients after backward
+  g = torch.Generator().manual_seed(rk.rank)
   bn, sz, T = c["bn"], c["sz"], c["T"]
   x = torch.rand(bn, c["in_ch"], sz, sz, generator=g).to(dev)
   xt = (torch.flip(x, dims=[3]) * 0.9 + 0.05).contiguous()
@@ -383,16 +564,19 @@ def bench_segmentation(args):
       if timed and head == "A":
         ev.append(e)
       torch.autograd.backward([a, b], [a_d.grad, b_d.grad])
+      if rk.on:
+        ops.fold_branch_grads(params)              # .grad += the side view's gradients
+        idist.all_reduce_grad_groups([params])     # SUM over ranks, one flat bucket (4.5 M parameters)
       opt.step()
     return loss
   for _ in range(args.warmup):
     step()
-  torch.cuda.synchronize()
+  rk.fence()
   t0 = time.perf_counter()
   for _ in range(args.steps):
     last = step()
-  torch.cuda.synchronize()
-  dt = (time.perf_counter() - t0) / args.steps
+  rk.fence()
+  dt = rk.max_over_ranks(time.perf_counter() - t0) / args.steps
   # kernel-level rooflines: HIP events around the contraction and around every conv launch, in extra
   # ONE-stream steps after the timed region (with two streams an event pair also spans whatever the
   # other view has in flight, and the event records cost GPU bubbles)
@@ -407,11 +591,15 @@ def bench_segmentation(args):
   torch.cuda.synchronize()
   conv.uninstall()
   if n_inst == 0:
-    print(json.dumps({"metric": "paired-images/sec, %s SegmentationNet10aTwoHead + IID_segmentation_loss_uncollapsed" % args.config,
-                      "value": bn / dt, "unit": "paired-images/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-                      "ms_per_step": 1e3 * dt, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                      "dtype": "bf16", "data": "synthetic",
-                      "config": {"workload": args.config, "streams": streams_timed, "final_loss": float(last.detach())}}))
+    if rk.rank == 0:
+      print(json.dumps({"metric": "paired-images/sec, %s SegmentationNet10aTwoHead + IID_segmentation_loss_uncollapsed" % args.config,
+                        "value": bn * world / dt, "unit": "paired-images/sec", "n_gpus": world, "steps": args.steps,
+                        "warmup": args.warmup, "ms_per_step": 1e3 * dt, "higher_is_better": True, "scaling": "weak",
+                        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                        "config": {"workload": args.config, "streams": streams_timed, "final_loss": float(last.detach()),
+                                   "parallelism": "dp%d" % world, "global_batch_pairs": bn * world,
+                                   "data_parallel": rk.report()}}))
+    rk.close()
     return
   kA = c["k_A"]
   f_joint = 2.0 * kA * kA * (2 * T + 1) ** 2 * bn * sz * sz          # 2 k^2 (2T+1)^2 bn h w
@@ -424,7 +612,7 @@ def bench_segmentation(args):
   cs = conv.summary()
   out = {
     "metric": "paired-images/sec, %s SegmentationNet10aTwoHead + IID_segmentation_loss_uncollapsed" % args.config,
-    "value": bn / dt, "unit": "paired-images/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+    "value": bn * world / dt, "unit": "paired-images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
     "ms_per_step": 1e3 * dt, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
     "dtype": "bf16", "data": "synthetic",
     "config": {"workload": "%s %dx%dx%d SegmentationNet10aTwoHead k_A %d / k_B %d, batch %d, T=%d, "
@@ -432,6 +620,7 @@ def bench_segmentation(args):
                            "(segmentation_twohead.py train step), bf16 MFMA convs / fp32 head + loss"
                            % (args.config, sz, sz, c["in_ch"], kA, c["k_B"], bn, T, c["mask_p"]),
                "launch": "eager (python/ctypes)", "streams": streams_timed,
+               "parallelism": "dp%d" % world, "global_batch_pairs": bn * world, "data_parallel": rk.report(),
                "final_loss": float(last.detach())},
     "roofline": {"bound": "mfma", "kernel": "seg_joint_kernel + 2x seg_grad_kernel (P = sum x1(u+t) x2(u)^T over "
                                             "(2T+1)^2 shifts and its gradient; fp32 MFMA 16x16x4)",
@@ -448,7 +637,9 @@ def bench_segmentation(args):
                             "frac": cs["tflops"] / BF16_PEAK_TFLOPS, "launches_timed": cs["launches"],
                             "kernel_ms_per_step": cs["total_ms"] / n_inst,
                             "timed_in": "%d instrumented one-stream steps after the timed region" % n_inst}
-  print(json.dumps(out))
+  if rk.rank == 0:
+    print(json.dumps(out))
+  rk.close()
 
 
 C6_CONFIGS = {
@@ -477,9 +668,10 @@ def bench_6c(args):
   from iic_amd.losses import IID_loss_heads
   from iic_amd.optim import Adam
   from iic_amd.transforms import sobel_process
+  from iic_amd import dist as idist, ops
   c = C6_CONFIGS[args.config]
-  dev = torch.device("cuda", 0)
-  torch.cuda.set_device(0)
+  rk = Ranks(args)
+  dev, world = rk.dev, rk.world
   torch.manual_seed(0)
   two = len(c["heads"]) == 2
   if two:
@@ -490,9 +682,14 @@ def bench_6c(args):
     cfg = types.SimpleNamespace(in_channels=c["in_ch"], input_sz=c["sz"], batchnorm_track=True, num_sub_heads=SUB_HEADS,
                                 output_k=c["k"][0])
     net = archs.ClusterNet6c(cfg).to(dev).train()
+  rk.broadcast(net)
+  params = list(net.parameters())
   use_graph = not args.no_graph
-  opt = Adam(net.parameters(), lr=args.lr, capturable=use_graph)
-  g = torch.Generator().manual_seed(0)
+  opt = Adam(params, lr=args.lr, capturable=use_graph)
+  # N > 1 (BASELINE configs[2] is 8 GPUs by name; cluster_sobel.py:146 wraps the net in nn.DataParallel): every rank
+  # owns `bn` pairs of its own (weak scaling), the raw joints of all sub-heads are all-reduced inside the loss, the
+  # parameter gradients (5.5 M: one flat bucket) before the optimiser -- in the captured step both are capture cuts
+  g = torch.Generator().manual_seed(rk.rank)
   bn, sz = c["bn"], c["sz"]
   raw_ch = c["in_ch"] - 1 if c["sobel"] else c["in_ch"]          # RGB + grey as the loaders emit it
   x = torch.rand(bn, raw_ch, sz, sz, generator=g).to(dev)
@@ -507,11 +704,18 @@ def bench_6c(args):
   def loss_fn(a, b):
     return IID_loss_heads(a, b, lamb=1.0)[0].mean()
 
+  def finish():
+    if rk.on:
+      ops.fold_branch_grads(params)
+      idist.all_reduce_grad_groups([params])
+    opt.step()
+
   def eager_head(head):
     net.zero_grad(set_to_none=True)
+    ops.clear_branch_grads()
     loss = loss_fn(fwd(x, head), fwd(xt, head))
     loss.backward()
-    opt.step()
+    finish()
     return loss
 
   def eager_step():
@@ -519,7 +723,7 @@ def bench_6c(args):
       last = eager_head(h)
     return last
   if use_graph:
-    caps = [CapturedPairStep((lambda h=h: fwd(x, h)), (lambda h=h: fwd(xt, h)), loss_fn, opt.step,
+    caps = [CapturedPairStep((lambda h=h: fwd(x, h)), (lambda h=h: fwd(xt, h)), loss_fn, finish,
                              lambda: net.zero_grad(set_to_none=True), warmup=max(1, args.warmup))
             for h in c["heads"]]
 
@@ -531,13 +735,13 @@ def bench_6c(args):
     run = eager_step
     for _ in range(args.warmup):
       eager_step()
-  torch.cuda.synchronize()
+  rk.fence()
   t0 = time.perf_counter()
   for _ in range(args.steps):
     last = run()
   t_enq = time.perf_counter() - t0
-  torch.cuda.synchronize()
-  dt = (time.perf_counter() - t0) / args.steps
+  rk.fence()
+  dt = rk.max_over_ranks(time.perf_counter() - t0) / args.steps
   n_inst = 0 if args.no_roofline else min(args.steps, 3)
   conv = ConvTimer()
   conv.install()
@@ -550,13 +754,17 @@ def bench_6c(args):
   out = {
     "metric": "paired-images/sec, %s" % ("MNIST 24x24 ClusterNet6cTwoHead+IID_loss (head-A step + head-B step)"
                                          if two else "CIFAR 24x24x5 ClusterNet6c+IID_loss"),
-    "value": bn / dt, "unit": "paired-images/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+    "value": bn * world / dt, "unit": "paired-images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
     "ms_per_step": 1e3 * dt, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
     "data": "synthetic",
     "config": {"workload": "%s: %dx%dx%d, batch %d, 5 sub-heads, k %s, bf16 MFMA convs / fp32 first layer + heads + loss, "
                            "fused HIP Adam" % (args.config, sz, sz, c["in_ch"], bn, "/".join(str(k) for k in c["k"])),
-               "launch": ("hip-graph replay: %d captured pair steps (6 linear graph segments each), the two views on two "
-                          "streams" % len(c["heads"])) if use_graph else "eager (python/ctypes)",
+               "launch": ("hip-graph replay: %d captured pair steps (%d linear graph segments each%s), the two views on two "
+                          "streams" % (len(c["heads"]), 4 + sum(len(sg.items) - sg.cuts for sg in (caps[0].g_l, caps[0].g_opt)),
+                                       ", %d collectives issued eagerly between them" % (caps[0].g_l.cuts + caps[0].g_opt.cuts)
+                                       if rk.on else ""))
+                         if use_graph else "eager (python/ctypes)",
+               "parallelism": "dp%d" % world, "global_batch_pairs": bn * world, "data_parallel": rk.report(),
                "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps, "final_loss": float(last.detach())},
   }
   cs = conv.summary() if n_inst else None
@@ -568,7 +776,9 @@ def bench_6c(args):
                        "timed_in": "%d instrumented one-stream eager steps after the timed region" % n_inst,
                        "step_algorithmic_tflops": fl_step / dt / 1e12,
                        "step_frac_of_peak": fl_step / dt / 1e12 / BF16_PEAK_TFLOPS}
-  print(json.dumps(out))
+  if rk.rank == 0:
+    print(json.dumps(out))
+  rk.close()
 
 
 SECONDARY = [("mnist6c", []), ("cifar6c", []), ("potsdam3", ["--T", "1"]), ("coco3", [])]
@@ -635,6 +845,8 @@ def main():
                        "dataset, as cluster_sobel.py:205-232 does from its dataloaders; the default "
                        "(off) is the metric's own timed region, which excludes data loading")
   args = ap.parse_args()
+  if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    self_launch(args)          # (does not return)
   if args.config in C6_CONFIGS:
     return bench_6c(args)
   if args.config != "stl10_5g":
@@ -642,24 +854,8 @@ def main():
       args.steps, args.warmup = 3, 1
     return bench_segmentation(args)
 
-  world = int(os.environ.get("WORLD_SIZE", "1"))
-  rank = int(os.environ.get("RANK", "0"))
-  local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-  assert torch.cuda.is_available(), "bench.py needs an MI355X"
-  ndev = torch.cuda.device_count()
-  backend = os.environ.get("IIC_DIST_BACKEND", "nccl")   # "gloo": functional check of the N>1
-  if local_rank >= ndev:                                 # path on a 1-GPU box (ranks share cuda:0)
-    assert backend != "nccl", "one GPU per rank is required with RCCL"
-    local_rank = local_rank % ndev
-  torch.cuda.set_device(local_rank)
-  dev = torch.device("cuda", local_rank)
-  if world > 1:
-    import torch.distributed as dist
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group(backend, rank=rank, world_size=world)
-    from iic_amd import dist as idist
-    idist.enable()
-  assert args.gpus == world or world == 1, "launch with torchrun --nproc-per-node == --gpus"
+  rk = Ranks(args)
+  world, rank, dev, dist_on = rk.world, rk.rank, rk.dev, rk.on
   if args.strong and world > 1:
     assert args.pairs % world == 0, "--strong: --pairs must divide by the number of ranks"
     args.pairs //= world
@@ -673,16 +869,14 @@ def main():
   cfg = types.SimpleNamespace(in_channels=2, input_sz=INPUT_SZ, batchnorm_track=True,
                               num_sub_heads=SUB_HEADS, output_k=OUTPUT_K)
   net = archs.ClusterNet5g(cfg).to(dev).train()
-  if world > 1:   # identical weights on every rank
-    for p in net.parameters():
-      torch.distributed.broadcast(p.data, 0)
+  rk.broadcast(net)   # identical weights on every rank
   # N = 1: the whole step (sobel -> 2 forwards -> loss -> backward -> Adam) is captured once in a
   # HIP graph and replayed -- same kernels, same arithmetic, one launch call per step instead of
   # ~1100 from Python.
   # N > 1: same graphs, cut at the collectives (issued eagerly between the segments); IIC_DIST_GRAPH=0
   # or IIC_DIST_OVERLAP=1 select the eager launch modes.
-  dist_graph = world > 1 and os.environ.get("IIC_DIST_GRAPH", "1") != "0" and os.environ.get("IIC_DIST_OVERLAP", "0") != "1"
-  use_graph = (world == 1 or dist_graph) and not args.no_graph and not args.with_augment
+  dist_graph = dist_on and os.environ.get("IIC_DIST_GRAPH", "1") != "0" and os.environ.get("IIC_DIST_OVERLAP", "0") != "1"
+  use_graph = (not dist_on or dist_graph) and not args.no_graph and not args.with_augment
   opt = Adam(net.parameters(), lr=args.lr, capturable=use_graph)
   # the second view (net(all_imgs_tf)) as a parallel graph branch: same kernels and arithmetic,
   # the tail of one view's launch is filled by the other view's next launch
@@ -698,8 +892,8 @@ def main():
   # and ONE bucketed SUM all-reduce follows.  IIC_DIST_OVERLAP=1 selects the round-1 mode instead:
   # one stream, gradient all-reduce overlapped with backward through post-accumulate hooks.
   reducer = None
-  two_stream = args.eager_branch or (world > 1 and os.environ.get("IIC_DIST_OVERLAP", "0") != "1")
-  if world > 1 and not two_stream:
+  two_stream = args.eager_branch or (dist_on and os.environ.get("IIC_DIST_OVERLAP", "0") != "1")
+  if dist_on and not two_stream:
     reducer = idist.GradReducer(params)
 
   aug = None
@@ -741,20 +935,16 @@ def main():
     loss.backward()
     if reducer is not None:
       reducer.finish()
-    elif world > 1:
+    elif dist_on:
       ops.fold_branch_grads(params)          # .grad += the side view's gradients (one foreach add)
       idist.all_reduce_grad_groups(groups)   # one flat bucket per layer group, as the staged graphs do
     opt.step()
     return loss
 
-  def fence():
-    torch.cuda.synchronize()
-    if world > 1:
-      torch.distributed.barrier()
-    torch.cuda.synchronize()
+  fence = rk.fence
 
   def finish():
-    if world > 1:
+    if dist_on:
       ops.fold_branch_grads(params)          # .grad += the side view's gradients (one foreach add)
       idist.all_reduce_grad_groups(groups)
     opt.step()
@@ -766,7 +956,7 @@ def main():
     from iic_amd.graph import CapturedPairStep
     try:
       force_staged = os.environ.get("IIC_FORCE_STAGED", "0") == "1"
-      staged = (world > 1 and os.environ.get("IIC_DIST_STAGED", "1") != "0") or force_staged
+      staged = (dist_on and os.environ.get("IIC_DIST_STAGED", "1") != "0") or force_staged
       if staged:
         # backward captured per layer group: a group's gradient bucket is all-reduced (third stream, async)
         # while the groups below it still run backward
@@ -787,7 +977,7 @@ def main():
                                warmup=max(1, args.warmup))       # warm-up steps are real steps
         launch_mode = "hip-graph replay: %d linear graph segments, the two views on two streams%s" % (
           4 + len(run.g_l.items) - run.g_l.cuts + len(run.g_opt.items) - run.g_opt.cuts,
-          ", %d collectives issued eagerly between them" % (run.g_l.cuts + run.g_opt.cuts) if world > 1 else "")
+          ", %d collectives issued eagerly between them" % (run.g_l.cuts + run.g_opt.cuts) if dist_on else "")
     except Exception as e:      # (N > 1 only: every rank issues the same collectives in either mode)
       if world == 1:
         raise
@@ -860,7 +1050,7 @@ def main():
   # statistics are replication-invariant).  Same losses and gradients (tests: test_replica_dedup_fp32_mode_vs_reference_
   # golden), a third of that view's conv work.  The metric's `value` keeps the reference's redundant forward.
   dedup = None
-  if world == 1 and use_branch and use_graph and aug is None and not args.no_reference_api and args.pairs % 3 == 0:
+  if not dist_on and use_branch and use_graph and aug is None and not args.no_reference_api and args.pairs % 3 == 0:
     try:
       from iic_amd.archs import cluster as _cl
       from iic_amd.graph import CapturedPairStep
@@ -883,16 +1073,25 @@ def main():
     except Exception as e:      # noqa: BLE001  (a secondary measurement never takes the headline down)
       dedup = {"error": "%s: %s" % (type(e).__name__, e)}
   ref_api = None
-  if world == 1 and not args.no_reference_api:
+  if not dist_on and not args.no_reference_api:
     ref_api = reference_api_rate(cfg, dev, imgs, imgs_tf, args.pairs, args.steps)
     # (rounds 3-4 also measured an eager two-stream variant; round 5 removed that mode: iic_amd/ops.py)
     ref_api["graphed"] = reference_api_rate(cfg, dev, imgs, imgs_tf, args.pairs, args.steps, auto_branch=True,
                                             graph_forward=True)
   loss_val = float(last.detach())
-  if world > 1:
-    t = torch.tensor([dt], device=dev, dtype=torch.float64)
-    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    dt = float(t)
+  # the two views' streams after the process group exists and has issued collectives: do they still run side by side,
+  # and does a pending collective hold either of them up?  (HIP maps streams onto 4 hardware queues in creation order;
+  # RCCL's stream is one more tenant: iic_amd.graph._collective_blocks)
+  stream_check = None
+  if dist_on and use_branch:
+    from iic_amd import graph as igraph
+    stream_check = {"pair_overlaps": igraph._streams_overlap(run.s1, run.s2),
+                    "collective_blocks_stream_1": igraph._collective_blocks(run.s1),
+                    "collective_blocks_stream_2": igraph._collective_blocks(run.s2)}
+    if getattr(run, "s3", None) is not None:
+      stream_check["fold_stream_beside_both"] = (igraph._streams_overlap(run.s1, run.s3) and
+                                                 igraph._streams_overlap(run.s2, run.s3))
+  dt = rk.max_over_ranks(dt)
   ms_per_step = 1e3 * dt / args.steps
   value = args.pairs * world / (dt / args.steps)
 
@@ -930,21 +1129,32 @@ def main():
           "kernel_ms_per_step": s["total_ms"] / min(args.steps, 3),
           "step_algorithmic_tflops": value / world * FLOP_PER_PAIR / 1e12,
           "step_frac_of_peak": value / world * FLOP_PER_PAIR / 1e12 / BF16_PEAK_TFLOPS,
+          "families": timer.families(min(args.steps, 3)),
         }
+        hb, hsrc = pmc_step_hbm()
+        if hb:
+          # the step is balanced between the matrix pipe and HBM -- both fractions.  Bytes: PMC (every kernel
+          # of a step, separate FETCH_SIZE / WRITE_SIZE passes); time: this run's step
+          out["roofline"]["hbm"] = {"bytes_per_step": hb, "source": hsrc, "TB_per_s": hb / (ms_per_step * 1e-3) / 1e12,
+                                    "frac": hb / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "algorithmic_bytes_per_step": 0.14e9 * args.pairs,
+                                    "algorithmic_frac": 0.14e9 * args.pairs / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
     if ref_api is not None:
       out["config"]["reference_api"] = ref_api
     if dedup is not None:
       out["config"]["replica_dedup_opt_in"] = dedup
-    if world == 1 and not args.no_secondary and args.pairs == PAIRS_PER_GPU:
+    if dist_on:
+      out["config"]["data_parallel"] = rk.report()
+      out["config"]["data_parallel"]["streams_after_collectives"] = stream_check
+    if not dist_on and not args.no_secondary and args.pairs == PAIRS_PER_GPU:
       out["secondary"] = secondary_configs()
-    if world == 1 and not args.no_cpu_baseline:
+    if not dist_on and not args.no_cpu_baseline:
       out["cpu_baseline"] = cpu_baseline()
       out["cpu_baseline"]["configs0_mnist"] = cpu_baseline_mnist()
     # wall time of this whole invocation (imports, captures, the timed region, the reference-API / secondary / CPU legs)
     out["elapsed_s"] = round(time.time() - T_PROCESS_START, 1)
     print(json.dumps(out))
-  if world > 1:
-    torch.distributed.destroy_process_group()
+  rk.close()
 
 
 if __name__ == "__main__":

@@ -11,25 +11,45 @@ over xGMI.  Replaces the reference's single-process torch.nn.DataParallel
 
 Only collectives live here; `gloo` on CPU is used by the world_size-2 tests.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
-_STATE = {"enabled": False, "group": None}
+_STATE = {"enabled": False, "group": None, "force": False}
 
 
-def enable(group=None):
+def enable(group=None, force=None):
+  """Switch the collectives on for `group` (default: the world).  A group of ONE rank normally keeps them off (the sums
+  are identities); `force=True` (or IIC_DIST_FORCE=1) keeps them on so that a single MI355X executes the whole N > 1
+  path -- the capture cut at the raw-joint all-reduce, the staged backward, the third stream, the bucket all-reduces --
+  through real RCCL calls (tests/test_gpu_rccl.py; the only multi-rank evidence a one-GPU box can give)."""
   assert dist.is_initialized(), "init torch.distributed first"
   _STATE["enabled"] = True
   _STATE["group"] = group
+  _STATE["force"] = (os.environ.get("IIC_DIST_FORCE", "0") == "1") if force is None else bool(force)
 
 
 def disable():
   _STATE["enabled"] = False
   _STATE["group"] = None
+  _STATE["force"] = False
 
 
 def enabled():
-  return _STATE["enabled"] and dist.is_initialized() and dist.get_world_size(_STATE["group"]) > 1
+  return _STATE["enabled"] and dist.is_initialized() and (_STATE["force"] or dist.get_world_size(_STATE["group"]) > 1)
+
+
+def backend():
+  """Backend name of the active group ("nccl" = RCCL on ROCm), or None."""
+  return dist.get_backend(_STATE["group"]) if enabled() else None
+
+
+CALLS = {}      # collective -> number of calls issued by this process (what DESIGN.md section 5 reports as executed)
+
+
+def _count(name):
+  CALLS[name] = CALLS.get(name, 0) + 1
 
 
 def world_size():
@@ -53,8 +73,13 @@ def all_reduce_sum_(t):
   if enabled():
     if _CAPTURE_CUT[0] is not None:
       grp = _STATE["group"]
-      _CAPTURE_CUT[0](lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=grp))
+
+      def replayed():
+        _count("all_reduce")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=grp)
+      _CAPTURE_CUT[0](replayed)
     else:
+      _count("all_reduce")
       dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_STATE["group"])
   return t
 
@@ -101,6 +126,7 @@ def broadcast_module_state(module, src=0):
     return
   with torch.no_grad():
     for t in list(module.parameters()) + list(module.buffers()):
+      _count("broadcast")
       dist.broadcast(t.data, src, group=_STATE["group"])
 
 
@@ -191,6 +217,7 @@ class GradReducer(object):
     if not members:
       return
     flat = torch.cat([p.grad.reshape(-1) for p in members])
+    _count("all_reduce_async")
     work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=_STATE["group"], async_op=True)
     self.inflight[bi] = (flat, work, members)
 

@@ -17,6 +17,8 @@ keeps its step count on the device (``iic_amd.optim.Adam(capturable=True)``); no
 (``.item()``) inside.  Nothing here is specific to one architecture.
 """
 import gc
+import os
+import sys
 
 import torch
 
@@ -40,6 +42,34 @@ def _no_gc(fn):
 
 
 _PAIR_STREAMS = {}     # device index -> (stream 1, stream 2)
+PROBE_LOG = []         # one dict per concurrency probe (what was measured, what was kept); bench.py reports it
+_PROBE = [os.environ.get("IIC_STREAM_PROBE", "1") != "0"]      # IIC_STREAM_PROBE=0: take streams as they come
+
+
+def _log_probe(**kw):
+  PROBE_LOG.append(kw)
+  if os.environ.get("IIC_STREAM_PROBE_LOG", "0") == "1":
+    sys.stderr.write("iic_amd stream probe: %s\n" % ", ".join("%s=%s" % (k, kw[k]) for k in sorted(kw)))
+
+
+def pick_stream(beside=(), what="stream", collective_free=False, tries=8):
+  """A new stream that really runs beside every stream in `beside` -- and, with `collective_free`, whose hardware queue
+  is not the one the process group's collectives are issued on.  HIP multiplexes its streams onto a few hardware queues
+  (4 by default) in creation order, and which queue a new stream lands on depends on how many streams the process
+  has created before (a process group's initialisation creates some): candidates are created until one passes the
+  probes (kept: the last one, if none does -- logged either way)."""
+  st = torch.cuda.Stream()
+  if not _PROBE[0] or torch.cuda.is_current_stream_capturing():
+    return st
+  for i in range(tries):
+    ok = all(_streams_overlap(b, st) for b in beside) and not (collective_free and _collective_blocks(st))
+    if ok:
+      _log_probe(probe="pick", what=what, candidate=i, kept=True)
+      return st
+    if i + 1 < tries:
+      st = torch.cuda.Stream()
+  _log_probe(probe="pick", what=what, candidate=tries - 1, kept=False)
+  return st
 
 
 def _pair_streams():
@@ -49,20 +79,17 @@ def _pair_streams():
   the replica-de-duplication variant beside the headline step) can find both of its streams on ONE hardware queue --
   its two views then run one after the other (seen in the kernel trace of the MNIST two-head step: every dispatch of
   the head-B step on queue 4, profiles/r05_mnist6c_pair_timeline.txt).  The steps of a process run one at a time, so
-  they can share the pair.  (Round 4 measured three alternatives -- the views on disjoint halves of the chip
-  through CU-masked streams, half the CUs of every XCD each, view A at high priority: neutral, worse, neutral;
-  DESIGN.md section 7.7 -- and round 5 removed the switches.)"""
+  they can share the pair.  Data parallel (round 6): RCCL's collectives are issued on a stream torch's process group
+  owns, which sits on one of the same few hardware queues -- a view whose stream shares that queue would be held up
+  behind every bucket all-reduce (which itself waits for the fold of BOTH views): the pair is chosen among candidates
+  that a pending collective does not block (_collective_blocks).  (Round 4 measured three alternatives -- the views on
+  disjoint halves of the chip through CU-masked streams, half the CUs of every XCD each, view A at high priority:
+  neutral, worse, neutral; DESIGN.md section 7.7 -- and round 5 removed the switches.)"""
   dev = torch.cuda.current_device()
   pair = _PAIR_STREAMS.get(dev)
   if pair is None:
-    s1 = torch.cuda.Stream()
-    s2 = torch.cuda.Stream()
-    # which hardware queue a new stream lands on depends on how many streams the process has created before
-    # (a process group's initialisation creates some): keep the first candidate that really runs beside s1
-    for _ in range(6):
-      if _streams_overlap(s1, s2):
-        break
-      s2 = torch.cuda.Stream()
+    s1 = pick_stream((), "pair stream 1", collective_free=True)
+    s2 = pick_stream((s1,), "pair stream 2", collective_free=True)
     pair = _PAIR_STREAMS[dev] = (s1, s2)
   return pair
 
@@ -70,6 +97,8 @@ def _pair_streams():
 def _streams_overlap(s1, s2, cycles=1200000):
   """Do two spin kernels (torch.cuda._sleep, ~0.5 ms each), one per stream, run side by side?  Two streams that share
   a hardware queue take twice as long as one."""
+  if not _PROBE[0]:
+    return True
   try:
     torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
@@ -90,9 +119,66 @@ def _streams_overlap(s1, s2, cycles=1200000):
       ev[4].record()
     torch.cuda.synchronize()
     both = max(ev[2].elapsed_time(ev[3]), ev[2].elapsed_time(ev[4]))
+    _log_probe(probe="overlap", single_ms=round(single, 3), paired_ms=round(both, 3), overlap=bool(both < 1.5 * single))
     return both < 1.5 * single
   except Exception:      # noqa: BLE001  (a probe never takes the step down)
     return True
+
+
+def _collective_blocks(s, cycles=1200000):
+  """Does a collective of the active process group that is waiting for its input hold up work on stream `s`?  torch's
+  RCCL process group issues its collectives on a stream of its own, ordered after the issuing stream by an event; if
+  that stream and `s` share a hardware queue, the queue's in-order packet processing parks `s` behind the wait.
+  Probe: a scratch stream spins for 3 units and issues an asynchronous all-reduce (which therefore waits 3 units);
+  `s` spins for 1 unit meanwhile.  1 unit = free, 4 units = blocked.  False without a process group (or on gloo,
+  whose collectives are host-side)."""
+  from . import dist as idist
+  if not _PROBE[0] or not idist.enabled() or idist.backend() != "nccl":
+    return False
+  try:
+    import torch.distributed as tdist
+    grp = idist._STATE["group"]
+    buf = torch.zeros(1024, device="cuda")
+    idist._count("all_reduce")
+    tdist.all_reduce(buf, op=tdist.ReduceOp.SUM, group=grp)      # (communicator + its stream exist from here on)
+    if "scratch" not in _COLL_PROBE:
+      _COLL_PROBE["scratch"] = torch.cuda.Stream()
+    sc = _COLL_PROBE["scratch"]
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    with torch.cuda.stream(s):
+      torch.cuda._sleep(1000)
+      ev[0].record()
+      torch.cuda._sleep(cycles)
+      ev[1].record()
+    torch.cuda.synchronize()
+    single = ev[0].elapsed_time(ev[1])
+    if not _streams_overlap(s, sc):          # the scratch stream itself shares s's queue: nothing can be told apart
+      _log_probe(probe="collective", inconclusive=True)
+      return False
+    with torch.cuda.stream(s):
+      ev[2].record()
+    sc.wait_stream(s)
+    with torch.cuda.stream(sc):
+      torch.cuda._sleep(3 * cycles)
+      idist._count("all_reduce_async")
+      w = tdist.all_reduce(buf, op=tdist.ReduceOp.SUM, group=grp, async_op=True)
+    with torch.cuda.stream(s):
+      torch.cuda._sleep(cycles)
+      ev[3].record()
+    torch.cuda.synchronize()
+    w.wait()
+    held = ev[2].elapsed_time(ev[3])
+    _log_probe(probe="collective", single_ms=round(single, 3), beside_pending_collective_ms=round(held, 3),
+               blocked=bool(held > 2.5 * single))
+    return held > 2.5 * single
+  except Exception as e:      # noqa: BLE001  (a probe never takes the step down)
+    _log_probe(probe="collective", error="%s: %s" % (type(e).__name__, e))
+    return False
+
+
+_COLL_PROBE = {}
+_FOLD_STREAMS = {}     # device index -> the staged backward's third stream (one per device, like the pair)
 
 
 class CapturedStep(object):
@@ -293,11 +379,11 @@ class CapturedPairStep(object):
   def _capture_staged(self, xa, xb, ga, gb, groups, opt_step, pool_a, pool_b, mode):
     from . import ops
     s1, s2 = self.s1, self.s2
-    s3 = torch.cuda.Stream()
-    for _ in range(6):           # a third stream on a hardware queue of its own (see _pair_streams)
-      if _streams_overlap(s1, s3) and _streams_overlap(s2, s3):
-        break
-      s3 = torch.cuda.Stream()
+    # a third stream that runs beside both views' (see _pair_streams); sharing a hardware queue with the collectives'
+    # own stream is fine for this one: fold g -> all-reduce g is one chain
+    s3 = _FOLD_STREAMS.get(torch.cuda.current_device())
+    if s3 is None:
+      s3 = _FOLD_STREAMS[torch.cuda.current_device()] = pick_stream((s1, s2), "fold / all-reduce stream")
     self.s3 = s3
     pool_c = torch.cuda.graph_pool_handle()
     n = len(groups)
@@ -399,6 +485,7 @@ class CapturedPairStep(object):
         # asynchronous: RCCL works on its own stream, ordered after the fold; streams 1 and 2 go on
         # with the next group (gloo: a worker thread, the host does not wait here either)
         if idist.enabled():
+          idist._count("all_reduce_async")
           works.append(tdist.all_reduce(self.buckets[g], op=tdist.ReduceOp.SUM, group=idist._STATE["group"],
                                         async_op=True))
       if ev is not None:

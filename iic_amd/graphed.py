@@ -147,9 +147,19 @@ def _sig_changed(mod, st, vg):
   # nn.Module._apply (.cpu() / .cuda() / .to()) keeps the Parameter objects and REPLACES the buffer objects: the cached
   # list would pin the old device buffers and keep comparing their unchanged addresses.  The architectures count their
   # _apply calls (archs.cluster._ApplyCounter): a new count means a fresh walk.
+  # The count only sees _apply on the architecture object itself; net.trunk.cuda() / bn.to(...) on a SUBMODULE replaces
+  # its buffer objects without passing there: the buffer dictionaries are therefore compared by identity
+  # as well -- 3 entries per BatchNorm, ~20 us per forward for ClusterNet5g.
   gen = _apply_generation(mod)
-  if ts is None or n % _SIG_FULL_EVERY == 0 or st.get("sig_gen") != gen:
+  stale = ts is None or n % _SIG_FULL_EVERY == 0 or st.get("sig_gen") != gen
+  if not stale:
+    for d, name, t in st["sig_bufs"]:
+      if d.get(name) is not t:
+        stale = True
+        break
+  if stale:
     st["sig_gen"] = gen
+    st["sig_bufs"] = [(m._buffers, name, t) for m in mod.modules() for name, t in m._buffers.items() if t is not None]
     ts = st["sig_tensors"] = list(mod.parameters()) + list(mod.buffers())
   if len(ts) != len(vg.sig):
     return True

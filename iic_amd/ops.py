@@ -139,16 +139,11 @@ class branch(object):
     self.main = torch.cuda.current_stream()
     st = _BRANCH_STREAM.get(key)
     if st is None:
-      st = torch.cuda.Stream()
-      if not torch.cuda.is_current_stream_capturing():
-        # HIP multiplexes streams onto a few hardware queues: keep a side stream that really runs beside the
-        # caller's (iic_amd.graph._streams_overlap; a pair on one queue would run the two views one after the other)
-        from .graph import _streams_overlap
-        for _ in range(6):
-          if _streams_overlap(self.main, st):
-            break
-          st = torch.cuda.Stream()
-      _BRANCH_STREAM[key] = st
+      # HIP multiplexes streams onto a few hardware queues: keep a side stream that really runs beside the
+      # caller's and is not parked behind the process group's collectives (iic_amd.graph.pick_stream; a pair on
+      # one queue would run the two views one after the other)
+      from .graph import pick_stream
+      st = _BRANCH_STREAM[key] = pick_stream((self.main,), "side stream of ops.branch", collective_free=True)
     self.side = st
     st.wait_stream(self.main)                       # fork
     for _, d in _PROXIES.values():                  # last step's branch gradients are consumed
@@ -206,7 +201,7 @@ AUTO_BRANCH = [os.environ.get("IIC_AUTO_BRANCH", "0") == "1"]
 # A forward of the pair that runs EAGERLY -- graph replay off, a warm-up occurrence, a shape that was not captured --
 # stays on the caller's stream; the two streams are for captured / replayed views, whose gradient hand-over is explicit
 # (iic_amd/graphed.py).
-_SOLO_FIRST = [0]         # 1: the first forward of a pair ran on the caller's stream (the second one must not fork either); 2: so did the second
+_SOLO_FIRST = [0]         # 1: the first forward of a pair ran on the caller's stream (the second one must not fork either)
 # forwards that hand back FEATURES (semisup heads: sup_head5.py:34-35, net6c_two_head.py:78-94,
 # k-means feature extraction) are consumed by modules outside this library, which know nothing about
 # the side stream: they never branch
@@ -255,10 +250,6 @@ def auto_branch(fwd):
     if BRANCH[0] == 0 and (_PENDING_JOIN or _DEFERRED_RUNNING) and (
         not self.training or not torch.is_grad_enabled() or len(_DEFERRED_RUNNING) > _DEFERRED_LIMIT):
       join()      # evaluation must see up-to-date running statistics; bound the postponed list
-    if _SOLO_FIRST[0] == 2:
-      # the pair that ran on the caller's stream is over and nothing of ours joined it (a foreign loss AND a foreign
-      # optimiser): apply its postponed running-statistic updates now, in call order, and start a new pair
-      join()
     run = fwd
     will_branch = (AUTO_BRANCH[0] and self.training and torch.is_grad_enabled() and BRANCH[0] == 0
                    and not _PENDING_JOIN and not _SOLO_FIRST[0] and torch.is_tensor(x) and x.is_cuda
@@ -290,12 +281,13 @@ def auto_branch(fwd):
         return run(self, x, *a, **k)
     if _SOLO_FIRST[0] == 1 and self.training and torch.is_grad_enabled() and BRANCH[0] == 0:
       # the second view of a pair whose first view stayed on the caller's stream: its running-statistic updates are
-      # postponed like the first view's (bn_finalize), the pair ends with it -- whoever joins next (our losses, our
-      # optimiser, the next pair's first forward, an evaluation forward) applies them
+      # postponed like the first view's (bn_finalize) and the pair ends with it.  Both views ran on the caller's
+      # stream, so nothing is left to wait for: the postponed updates are applied right here, in call order -- a
+      # state_dict() / checkpoint taken after the step sees them whoever owns the loss and the optimiser
       try:
         return run(self, x, *a, **k)
       finally:
-        _SOLO_FIRST[0] = 2
+        join()
     if not torch.is_grad_enabled():
       mark = POOL.mark()                 # evaluation: nothing will release the activations later
       try:

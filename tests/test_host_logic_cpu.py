@@ -57,8 +57,9 @@ class _FakeDeviceTensor(torch.Tensor):
 
 def test_auto_branch_keeps_eager_pair_forwards_on_the_callers_stream(monkeypatch):
   """A forward of the pair that runs eagerly does not fork; the first one marks the pair (_SOLO_FIRST = 1) so that the
-  second one does not fork in its place, the second one ends the pair (2), both postpone their running-statistic
-  updates to the join, and the join -- or, when nothing of ours joins, the next pair's first forward -- clears the mark.
+  second one does not fork in its place; both postpone their running-statistic updates, and the second one ends the
+  pair by applying them itself (both ran on the caller's stream: nothing to wait for -- a checkpoint taken right after
+  a step with a foreign loss and a foreign optimiser sees them).
   A first forward that raises clears it too.  With graph replay on, the two warm-up occurrences of a position run the
   same way inside the position's resource namespace, without parameter aliases."""
   calls = []
@@ -84,16 +85,18 @@ def test_auto_branch_keeps_eager_pair_forwards_on_the_callers_stream(monkeypatch
     ops.AUTO_BRANCH[0], ops.GRAPH_FORWARD[0] = True, False
     net(x)
     assert ops._SOLO_FIRST[0] == 1 and not ops._PENDING_JOIN and calls[-1] == (0, 1, True)
-    net(x)
-    assert calls[-1] == (0, 1, True) and not ops._PENDING_JOIN and ops._SOLO_FIRST[0] == 2
-    ops.join()
-    assert not ops._SOLO_FIRST[0]
-    # nothing of ours joins (a foreign loss and a foreign optimiser): the next pair's first forward does
-    net(x); net(x)
-    assert ops._SOLO_FIRST[0] == 2
     n_fl = len(flushes)
     net(x)
-    assert len(flushes) == n_fl + 1 and ops._SOLO_FIRST[0] == 1 and calls[-1] == (0, 1, True)
+    # the second view ends the pair: mark cleared, postponed running-statistic updates flushed -- with no join of ours
+    assert calls[-1] == (0, 1, True) and not ops._PENDING_JOIN and ops._SOLO_FIRST[0] == 0 and len(flushes) == n_fl + 1
+    ops.join()
+    assert not ops._SOLO_FIRST[0]
+    # nothing of ours joins (a foreign loss and a foreign optimiser): every pair still flushes once, at its second view
+    n_fl = len(flushes)
+    net(x); net(x)
+    assert ops._SOLO_FIRST[0] == 0 and len(flushes) == n_fl + 1
+    net(x)
+    assert ops._SOLO_FIRST[0] == 1 and calls[-1] == (0, 1, True)
     net(x)
     ops.join()
     # a first forward that raises does not leave the mark behind
@@ -122,3 +125,21 @@ def test_auto_branch_keeps_eager_pair_forwards_on_the_callers_stream(monkeypatch
   finally:
     ops.AUTO_BRANCH[0], ops.GRAPH_FORWARD[0] = prev
     ops._SOLO_FIRST[0] = 0
+
+
+def test_sig_changed_notices_a_buffer_replaced_through_a_submodule():
+  """nn.Module._apply on a SUBMODULE (net.trunk.cuda(), bn.to(...)) replaces buffer objects without passing the
+  architecture's _apply counter: the cached tensor list would keep comparing the OLD buffers' unchanged addresses and a
+  captured graph would go on writing running statistics into them.  The buffer dictionaries are compared
+  by identity on every call."""
+  net = torch.nn.Sequential(torch.nn.Conv2d(1, 2, 3), torch.nn.BatchNorm2d(2))
+  st = {}
+  vg = types.SimpleNamespace(sig=graphed._storage_sig(net))
+  assert not graphed._sig_changed(net, st, vg)
+  assert not graphed._sig_changed(net, st, vg)
+  old = net[1].running_mean
+  net[1]._apply(lambda t: t.clone())           # what .cuda() / .to() do to a submodule: new buffer objects, new addresses
+  assert net[1].running_mean is not old
+  assert graphed._sig_changed(net, st, vg)      # (the old object is still alive in the cached list: addresses alone would say "unchanged")
+  vg2 = types.SimpleNamespace(sig=graphed._storage_sig(net))
+  assert not graphed._sig_changed(net, st, vg2)

@@ -2,6 +2,7 @@
 north-star shapes: same-process timing, outputs compared bit for bit."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("IIC_HIP_LIB", "dbg")      # the iic_debug_* switches live in libiic_hip_dbg.so only (make -C iic_amd/csrc dbg)
 import torch
 from iic_amd import _lib, geom, ops
 from tools.conv_perf import LAYERS, COUNT, timeit

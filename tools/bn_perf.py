@@ -4,6 +4,7 @@ GB/s = algorithmic bytes: reduce reads dout + y, apply reads dout + y and writes
 import argparse, ctypes, os, sys
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+os.environ.setdefault("IIC_HIP_LIB", "dbg")      # the iic_debug_* switches live in libiic_hip_dbg.so only (make -C iic_amd/csrc dbg)
 from iic_amd import ops, _lib   # noqa: E402
 
 ap = argparse.ArgumentParser()

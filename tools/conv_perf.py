@@ -4,6 +4,7 @@ python tools/conv_perf.py [--n 660] [--iters 20] -> table of us and TFLOP/s per 
 import argparse
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("IIC_HIP_LIB", "dbg")      # the iic_debug_* switches live in libiic_hip_dbg.so only (make -C iic_amd/csrc dbg)
 import torch
 from iic_amd import geom, ops
 

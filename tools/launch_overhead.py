@@ -1,5 +1,6 @@
 import sys, os, time, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("IIC_HIP_LIB", "dbg")      # the iic_debug_* switches live in libiic_hip_dbg.so only (make -C iic_amd/csrc dbg)
 import torch
 from iic_amd import geom, ops, _lib
 dev = torch.device("cuda:0")

@@ -3,6 +3,7 @@ DESIGN.md; bench.py stays the north-star config).  Synthetic resident inputs, sa
 the reference scripts' train step (forward x2, loss(es), backward, Adam)."""
 import argparse, os, sys, time, types
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("IIC_HIP_LIB", "dbg")      # the iic_debug_* switches live in libiic_hip_dbg.so only (make -C iic_amd/csrc dbg)
 import torch
 from iic_amd import archs
 from iic_amd.losses import IID_loss_heads, IID_loss

@@ -53,6 +53,9 @@ def main():
     "conv_igemm_hbm_bytes_per_launch": (sum(v["hbm_bytes_per_launch"] * v["launches"] for v in conv.values())
                                         / max(tot_l, 1)),
     "conv_igemm_launches": tot_l,
+    # every launch of the command, per step (the command runs --steps 1 --warmup 1 = 2 steps; weight preparation and
+    # the first steps' buffer zero-fills included)
+    "step_hbm_bytes": sum(v["hbm_bytes_per_launch"] * v["launches"] for v in res.values()) / float(os.environ.get("PMC_STEPS", "2")),
     "kernels": res,
   }
   json.dump(summary, open(out, "w"), indent=1)

@@ -1,6 +1,7 @@
 """Timing of the stem kernels at the north-star shape (660 x 2 x 96 x 96); --ablate codes for stem_bwd2."""
 import argparse, ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("IIC_HIP_LIB", "dbg")      # the iic_debug_* switches live in libiic_hip_dbg.so only (make -C iic_amd/csrc dbg)
 import torch
 from iic_amd import ops, _lib
 
