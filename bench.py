@@ -1036,8 +1036,10 @@ def main():
     step()
     hold_ms = min(400.0, max(80.0, 1.5e3 * (time.perf_counter() - t_h) + 20.0))
     fence()
-    if timer is not None:
+    if timer is not None:      # the probe step's records are dropped
       del timer.records[:]
+      for recs in timer.fam.values():
+        del recs[:]
     for _ in range(min(args.steps, 3)):
       gpu_hold(hold_ms)
       step()

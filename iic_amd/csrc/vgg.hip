@@ -351,6 +351,12 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const bf16_t* __restr
   }
 }
 
+// firstconv2.hip
+int fc2_fwd_launch(const float* x, const float* w, void* out_pt, float* stats, int N, int Cin, int H, int W, int K,
+                   int pad, int P, int max_blocks, void* stream);
+int fc2_wgrad_launch(const float* x, const void* dy_pt, float* partials, int N, int Cin, int H, int W, int K, int pad,
+                     int P, int max_blocks, int* grid_out, int* ld_out, void* stream);
+
 extern "C" {
 
 static int fc_check(const void* x, int N, int Cin, int H, int W, int K, int pad) {
@@ -365,6 +371,9 @@ int iic_firstconv_fwd(const float* x, const float* w, void* out_pt, float* stats
   int rc = fc_check(x, N, Cin, H, W, K, pad);
   if (rc) return rc;
   if (!w || !out_pt) return IIC_ERR_ARG;
+  // second generation (firstconv2.hip: LDS-staged bands, 16-byte accesses) wherever it applies (W % 4 == 0)
+  rc = fc2_fwd_launch(x, w, out_pt, stats, N, Cin, H, W, K, pad, P, FC_PERSIST, stream);
+  if (rc != IIC_ERR_UNSUPPORTED) return rc;
   const long tiles = (long)N * H * ((W + 31) / 32);
   int grid = (int)((tiles + 3) / 4);
   if (grid > FC_PERSIST) grid = FC_PERSIST;
@@ -381,6 +390,16 @@ int iic_firstconv_wgrad(const float* x, const void* dy_pt, float* partials, floa
   if (rc) return rc;
   if (!dy_pt || !partials || !dW) return IIC_ERR_ARG;
   const int KT = Cin * K * K, NKT = (KT + 31) / 32;
+  {
+    int g2 = 0, ld2 = 0;
+    rc = fc2_wgrad_launch(x, dy_pt, partials, N, Cin, H, W, K, pad, P, FC_PERSIST, &g2, &ld2, stream);
+    if (rc == IIC_OK) {
+      hipLaunchKernelGGL(fc_wgrad_reduce_kernel, dim3(64 * KT), dim3(256), 0, (hipStream_t)stream, partials, g2, ld2,
+                         KT, dW);
+      return iic_launch_status();
+    }
+    if (rc != IIC_ERR_UNSUPPORTED) return rc;
+  }
   const long tiles = (long)N * H * ((W + 31) / 32);
   int grid = (int)((tiles + 3) / 4);
   if (grid > FC_PERSIST) grid = FC_PERSIST;

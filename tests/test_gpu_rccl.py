@@ -83,7 +83,8 @@ def test_staged_captured_step_runs_through_rccl_in_a_one_rank_group():
 
 
 def test_unstaged_and_eager_modes_through_rccl_agree_with_the_staged_one():
-  base = _bench(["--gpus", "1"] + SMALL, IIC_DIST_FORCE="1")[1]
+  r0, base = _bench(["--gpus", "1"] + SMALL, IIC_DIST_FORCE="1")
+  assert r0.returncode == 0 and base is not None, r0.stdout[-1500:] + r0.stderr[-3000:]
   for extra in (dict(IIC_DIST_STAGED="0"), dict(IIC_DIST_GRAPH="0"), dict(IIC_DIST_OVERLAP="1")):
     r, rec = _bench(["--gpus", "1"] + SMALL, IIC_DIST_FORCE="1", **extra)
     assert r.returncode == 0 and rec is not None, (extra, r.stderr[-3000:])

@@ -152,7 +152,13 @@ def test_net6c_bf16_and_fp32_trajectories_track_the_reference():
   _gates(runs, lo, hi, w, wb, wf, bf16, fp32, first_tol_fp32=1e-3, first_tol_bf16=5e-2, gap_bf16=GAP6C_BF16, gap_fp32=GAP6C_FP32)
 
 
-# The stated gaps (relative to the reference band's centre, per 5-step window; measured on the MI355X, see
-# gpurun_out/traj_*.txt -> profiles/r06_traj_*.txt, + margin).  Set after the first GPU run.
-GAP5G_BF16, GAP5G_FP32 = 0.05, 0.02
-GAP6C_BF16, GAP6C_FP32 = 0.10, 0.05
+# The stated gaps: how far outside the reference's own band a 5-step window mean may lie, relative to the band's
+# centre.  Measured on the MI355X (profiles/r06_traj_net5g.txt, r06_traj_net6c.txt):
+#   ClusterNet5g  fp32 mode 2e-4 in every window (it IS the reference's trajectory: -2.1736 vs -2.1710 ... -2.1726 after
+#                 30 steps), bf16 2.9 % in the first window (-0.984 vs -1.013: the steps where the loss falls fastest),
+#                 0.2 % from the third window on, final-loss gap 2.0e-3 relative;
+#   ClusterNet6c  the reference's own runs spread by 4 % after 30 steps (-1.068 / -1.077 / -1.114 at 1 / 2 / 8 BLAS
+#                 threads: MI ~ 0 at the start, lr 1e-3); fp32 mode 1.1 % outside that band, bf16 5.9 % (final loss
+#                 -1.167: it trains slightly FASTER than any fp32 run, same shape).
+GAP5G_BF16, GAP5G_FP32 = 0.05, 0.005
+GAP6C_BF16, GAP6C_FP32 = 0.10, 0.03

@@ -22,17 +22,24 @@ def _cos(a, b):
   return float((a @ b) / (a.norm() * b.norm() + 1e-30))
 
 
-@pytest.mark.parametrize("cin,K,S,N", [(1, 5, 24, 5), (5, 5, 24, 3), (4, 3, 40, 2), (5, 3, 64, 2), (2, 3, 96, 2)])
+@pytest.mark.parametrize("cin,K,S,N", [(1, 5, 24, 5), (5, 5, 24, 3), (4, 3, 40, 2), (5, 3, 64, 2), (2, 3, 96, 2),
+                                       # round 6 (firstconv2.hip: bands of rows in LDS): the Potsdam / COCO widths, a band
+                                       # count that does not divide the height, rectangular images, one image row per
+                                       # 32-pixel tile boundary case (W = 32), and widths the banded kernels do not take
+                                       # (W % 4 != 0: first-generation kernels)
+                                       (4, 3, 200, 2), (5, 3, 128, 1), (3, 5, 28, 3), (1, 3, (20, 36), 2), (8, 3, (36, 32), 2),
+                                       (4, 3, 30, 2), (2, 5, (24, 26), 2)])
 def test_firstconv_forward_and_wgrad(cin, K, S, N):
   from iic_amd import ops
   pad, P = (K - 1) // 2, 2
   rng = np.random.default_rng(cin * 10 + K)
-  x = torch.from_numpy(rng.standard_normal((N, cin, S, S)).astype(np.float32))
+  SH, SW = S if isinstance(S, tuple) else (S, S)
+  x = torch.from_numpy(rng.standard_normal((N, cin, SH, SW)).astype(np.float32))
   w = torch.from_numpy((rng.standard_normal((64, cin, K, K)) * 0.2).astype(np.float32))
   wt = w.clone().requires_grad_(True)
   y = F.conv2d(x, wt, padding=pad)
   d = dev()
-  out = torch.zeros((N, S + 2 * P, S + 2 * P, 64), dtype=torch.bfloat16, device=d)
+  out = torch.zeros((N, SH + 2 * P, SW + 2 * P, 64), dtype=torch.bfloat16, device=d)
   st = ops.new_stats(64, d)
   ops.firstconv_fwd(x.to(d), w.to(d), out, st, K, pad, P)
   torch.cuda.synchronize()
@@ -40,7 +47,8 @@ def test_firstconv_forward_and_wgrad(cin, K, S, N):
   scale = float(y.abs().max())
   assert float((got - y.detach()).abs().max()) <= 1e-2 * scale
   assert out[:, :P].abs().max() == 0 and out[:, :, -P:].abs().max() == 0
-  cnt = N * S * S
+  assert out[:, -P:].abs().max() == 0 and out[:, :, :P].abs().max() == 0
+  cnt = N * SH * SW
   ssum = ops.stats_decode(st, 64).float().cpu()
   assert torch.allclose(ssum[0] / cnt, y.detach().mean((0, 2, 3)), atol=1e-4 * scale)
   assert torch.allclose(ssum[1] / cnt, (y.detach() ** 2).mean((0, 2, 3)), rtol=1e-4, atol=1e-5)
