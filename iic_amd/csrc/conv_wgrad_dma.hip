@@ -137,7 +137,11 @@ __device__ __forceinline__ void wd_walk_pixels(const WdWalk& w, const iic_conv_g
   pout = valid ? (n * g.out_Hp + y * g.ty + g.py) * g.out_Wp + x * g.tx + g.px : -1;
 }
 
-template <int COT, int WD_BM, int NBUF, bool ASMRD, bool PF>
+// SWP (round 6, 12-wave form only): the fragments of k-step ks + 1 are read while the MFMAs of k-step ks run (two
+// register sets, compile-time indices) -- a wave no longer parks on lgkmcnt(0) between issuing its 10 transposing
+// reads and its 6 MFMAs eight times per K-tile (r05_pmc_stalls.txt: 35 % of the wave cycles parked, 34 % of the matrix
+// pipe busy).  Three waves per SIMD stay (<= 170 registers), unlike the 4-wave PF form.
+template <int COT, int WD_BM, int NBUF, bool ASMRD, bool PF, bool SWP = false>
 __global__ __launch_bounds__(PF ? 256 : WD_THREADS) void conv_wgrad_dma_kernel(
     const iic_conv_geom g, const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
     float* __restrict__ partials, int nsplit, int num_ktiles, int xb_bytes, int max_tap_off, int abl) {
@@ -337,6 +341,32 @@ __global__ __launch_bounds__(PF ? 256 : WD_THREADS) void conv_wgrad_dma_kernel(
                                                                          acc[3 * gq + t][c], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
+      } else if (SWP) {
+        constexpr int NKS = WD_BM / 16;
+        bf16x8 fa[2][CS], fb[2][3];
+        auto load_ks = [&](int ks) {
+#pragma unroll
+          for (int c = 0; c < CS; ++c)
+            fa[ks & 1][c] = wd_frag(db + ks * 16 * DROW + aoff[c], db + (ks * 16 + 4) * DROW + aoff[c]);
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            const int toff = __builtin_amdgcn_readlane(v_tapoff, tfirst + t);
+            const int R0 = rr0[ks] + toff, R1 = rr1[ks] + toff;
+            fb[ks & 1][t] = wd_frag(xb + (R0 << 7) + (R0 & 2) * xs32, xb + (R1 << 7) + (R1 & 2) * xs32);
+          }
+        };
+        load_ks(0);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          if (ks + 1 < NKS) load_ks(ks + 1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int c = 0; c < CS; ++c)
+              acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][c], fb[ks & 1][t], acc[t][c], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       } else {
   #pragma unroll
         for (int ks = 0; ks < WD_BM / 16; ++ks) {
@@ -422,6 +452,11 @@ IIC_SWITCH(g_wd_asm, 0, iic_debug_wgrad_asm)
 // timing ablation (WRONG results): 1 = no DMA after the prologue (compute-only time of the K loop)
 IIC_SWITCH(g_wd_ablate, 0, iic_debug_wgrad_ablate)
 IIC_SWITCH(g_wd_prefetch, 0, iic_debug_wgrad_prefetch)
+// 1: 12-wave kernel with the next k-step's fragments read under the current k-step's MFMAs (template SWP).  Measured
+// (tools/wgrad_swp_ab.py, profiles/r06_wgrad_swp_ab.txt): bit-identical, 1.01-1.03 x per launch in isolation (layer 1
+// 215.5 -> 209.1 us, layer 3 159.1 -> 155.4), and 36.31 / 36.26 -> 36.38 / 36.34 ms per step interleaved on one box: the
+// wave-level lgkmcnt park was not what sets the step.  Default 0; instantiated in the instrumented library only.
+IIC_SWITCH(g_wd_swp, 0, iic_debug_wgrad_swp)
 IIC_SWITCH(g_wd_enabled, 1, iic_debug_enable_wgrad_dma)     // 0: register-staged kernel, 1: DMA kernel, 3: force 64-pixel K-tiles
 
 // K-tile size / ring depth.  Measured at the ClusterNet5g shapes (tools/conv_perf.py): 128-pixel
@@ -474,16 +509,16 @@ int iic_wgrad_dma_launch(const iic_conv_geom* g, const void* x, const void* dy, 
   for (int i = 0; i < g->ntaps; ++i) mto = g->tap_off[i] > mto ? g->tap_off[i] : mto;
   dim3 grid((g->Cout / cot) * (g->Cin / 64), nsplit);
   hipStream_t s = (hipStream_t)stream;
-#define WD_LAUNCH2(COT_, BMK_, NBUF_, ASM_, PF_)                                                 \
+#define WD_LAUNCH2(COT_, BMK_, NBUF_, ASM_, PF_, SWP_)                                           \
   do {                                                                                          \
     static bool attr = false;                                                                   \
     if (!attr) {                                                                                \
       (void)hipFuncSetAttribute(                                                                \
-          reinterpret_cast<const void*>(&conv_wgrad_dma_kernel<COT_, BMK_, NBUF_, ASM_, PF_>),  \
+          reinterpret_cast<const void*>(&conv_wgrad_dma_kernel<COT_, BMK_, NBUF_, ASM_, PF_, SWP_>), \
           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                              \
       attr = true;                                                                              \
     }                                                                                           \
-    hipLaunchKernelGGL((conv_wgrad_dma_kernel<COT_, BMK_, NBUF_, ASM_, PF_>), grid,             \
+    hipLaunchKernelGGL((conv_wgrad_dma_kernel<COT_, BMK_, NBUF_, ASM_, PF_, SWP_>), grid,       \
                        dim3(PF_ ? 256 : WD_THREADS), lds, s, *g, (const bf16_t*)x,              \
                        (const bf16_t*)dy,                                                       \
                        partials, nsplit, kt, xb, mto, g_wd_ablate);                             \
@@ -491,12 +526,13 @@ int iic_wgrad_dma_launch(const iic_conv_geom* g, const void* x, const void* dy, 
 #ifdef IIC_DEBUG_HOOKS
 #define WD_LAUNCH(COT_, BMK_, NBUF_)                                                             \
   do {                                                                                          \
-    if (g_wd_asm) WD_LAUNCH2(COT_, BMK_, NBUF_, true, false);                                   \
-    else if (g_wd_prefetch) WD_LAUNCH2(COT_, BMK_, NBUF_, false, true);                         \
-    else WD_LAUNCH2(COT_, BMK_, NBUF_, false, false);                                           \
+    if (g_wd_asm) WD_LAUNCH2(COT_, BMK_, NBUF_, true, false, false);                            \
+    else if (g_wd_prefetch) WD_LAUNCH2(COT_, BMK_, NBUF_, false, true, false);                  \
+    else if (g_wd_swp) WD_LAUNCH2(COT_, BMK_, NBUF_, false, false, true);                       \
+    else WD_LAUNCH2(COT_, BMK_, NBUF_, false, false, false);                                    \
   } while (0)
 #else
-#define WD_LAUNCH(COT_, BMK_, NBUF_) WD_LAUNCH2(COT_, BMK_, NBUF_, false, false)
+#define WD_LAUNCH(COT_, BMK_, NBUF_) WD_LAUNCH2(COT_, BMK_, NBUF_, false, false, (g_wd_swp != 0))
 #endif
   if (bmk == 64 && nbuf == 4) {
     if (cot == 128) WD_LAUNCH(128, 64, 4); else WD_LAUNCH(64, 64, 4);
