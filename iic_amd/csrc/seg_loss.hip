@@ -427,17 +427,198 @@ __global__ __launch_bounds__(256, 2) void seg_joint_stream_kernel(
   }
 }
 
+
+// ====================================================================================
+// The same contractions on the bf16 matrix pipe (round 6): every fp32 operand element is split
+// into three bf16 terms  x = h + m + l  (h = bf16(x), m = bf16(x - h), l = bf16(x - h - m): 24 mantissa bits, the
+// subtractions are exact in fp32) and a product is the six MFMAs  h h', h m', m h', h l', l h', m m'  accumulated in
+// fp32 -- what is dropped (m l', l m', l l') is below 2^-24 of the product, i.e. inside the rounding of the exact-fp32
+// MFMA path itself (measured on the golden fixtures: the loss moves in its 8th digit).  One v_mfma_f32_16x16x32_bf16
+// covers 32 k values in 16 cycles where v_mfma_f32_16x16x4_f32 covers 4 in 32: six of them replace eight fp32 MFMAs at
+// 3/8 of the matrix-pipe time; the split costs ~36 VALU + 8 scalar LDS reads per 8-element fragment, paid once per
+// fragment, not per product.  That cost decides where this pays (see g_seg_bf16 below): the joint at k <= 16.
+// ====================================================================================
+__device__ __forceinline__ void seg_split8(const float (&v)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
+  union { uint32_t u[4]; bf16x8 v; } H, M, L;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    float a = v[2 * p], b = v[2 * p + 1];
+    H.u[p] = pack_bf16x2(a, b);
+    a -= bf16lo(H.u[p]);
+    b -= bf16hi(H.u[p]);
+    M.u[p] = pack_bf16x2(a, b);
+    a -= bf16lo(M.u[p]);
+    b -= bf16hi(M.u[p]);
+    L.u[p] = pack_bf16x2(a, b);
+  }
+  h = H.v; m = M.v; l = L.v;
+}
+__device__ __forceinline__ f32x4 seg_mfma6(const bf16x8& ah, const bf16x8& am, const bf16x8& al, const bf16x8& bh,
+                                           const bf16x8& bm, const bf16x8& bl, f32x4 c) {
+  // (smallest terms first)
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+  return c;
+}
+// row pitch of the bf16-path joint buffers: steps of 32 pixels read up to 31 columns past the row (zeros)
+__host__ __device__ __forceinline__ int seg_w32(int w) { return (w + 31) & ~31; }
+
+// Joint.  Same staging, work split and output layout as seg_joint_stream_kernel; a step is 32 pixels: lane
+// (class row / column c, k group kg) holds pixels x0 + 8 kg .. + 7 of its row.
+template <int TK, int MTMAX, int LW>
+__global__ __launch_bounds__(256, 2) void seg_joint_bf16_kernel(
+    const float* __restrict__ x1, const float* __restrict__ x2, const float* __restrict__ mask,
+    const int* __restrict__ flips, float* __restrict__ part, int bn, int k, int h, int w, int T, int QG) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int CR = 256 / LW, NJ = (16 * TK + CR - 1) / CR;
+  const int nq = 2 * T + 1;
+  const int w32 = seg_w32(w);
+  const int P1 = seg_pitch2(w32 + 2 * T), P2 = seg_pitch2(w32);
+  float* sX1 = reinterpret_cast<float*>(smem_raw);          // [16*TK][P1]
+  float* sX2 = sX1 + 16 * TK * P1;                          // [16*TK][P2]
+  int p = blockIdx.x, grp = blockIdx.y, split = blockIdx.z;
+  const int S = gridDim.z;
+  if ((S & 7) == 0) {       // (XCD-aware slice mapping: see seg_joint_stream_kernel)
+    const int npg = gridDim.x * gridDim.y;
+    const int L = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const int xcd = L & 7, j = L >> 3;
+    const int pg = j % npg;
+    split = xcd + 8 * (j / npg);
+    p = pg % (int)gridDim.x;
+    grp = pg / (int)gridDim.x;
+  }
+  const int q0 = grp * QG;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, kg = lane >> 4;
+  const int xl = tid % LW, cr = tid / LW, wq = w >> 2;
+  const bool xact = xl < wq;
+  const long rows = (long)bn * h;
+  const long per = (rows + S - 1) / S;
+  const long r0 = split * per, r1 = min(rows, r0 + per);
+  const int qn = min(QG, nq - q0);
+  const int mrows = qn * k, mt = (mrows + 15) >> 4;
+  const int nst = w32 >> 5;
+
+  f32x4 acc[MTMAX][TK];
+  int aoff[MTMAX];
+#pragma unroll
+  for (int ti = 0; ti < MTMAX; ++ti) {
+#pragma unroll
+    for (int tj = 0; tj < TK; ++tj) acc[ti][tj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int m = ti * 16 + c, a = m / k, i = m - a * k;
+    aoff[ti] = m < mrows ? i * P1 + q0 + a : (16 * TK - 1) * P1;     // (ragged tiles read the all-zero padding channel)
+  }
+  for (int idx = tid; idx < 16 * TK * (P1 + P2); idx += 256) sX1[idx] = 0.f;
+
+  float4 pre1[NJ], pre2[NJ], m1, m2;
+  int pfx = 0;
+  auto next_valid = [&](long r) {
+    while (r < r1) {
+      const int y1 = (int)(r % h) + p - T;
+      if (y1 >= 0 && y1 < h) break;
+      ++r;
+    }
+    return r;
+  };
+  auto issue = [&](long r) {
+    const int n = (int)(r / h), y = (int)(r - (long)n * h), y1 = y + p - T;
+    const int fx = flips[2 * n], fy = flips[2 * n + 1];
+    const int sy = fy ? h - 1 - y : y, sx = fx ? wq - 1 - xl : xl;
+    pfx = fx;
+    if (xact) {
+      m2 = seg_ld4(mask + ((long)n * h + y) * w + 4 * xl);
+      m1 = seg_ld4(mask + ((long)n * h + y1) * w + 4 * xl);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int ch = cr + CR * j;
+        if (ch < k) {
+          pre2[j] = seg_ld4(x2 + (((long)n * k + ch) * h + sy) * w + 4 * sx);
+          pre1[j] = seg_ld4(x1 + (((long)n * k + ch) * h + y1) * w + 4 * xl);
+        }
+      }
+    }
+  };
+
+  long r = next_valid(r0);
+  if (r < r1) issue(r);
+  while (r < r1) {
+    __syncthreads();
+    if (xact) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int ch = cr + CR * j;
+        if (ch < k) {
+          seg_store4(sX2 + ch * P2 + 4 * xl, pfx ? seg_rev4(pre2[j]) : pre2[j], m2);
+          seg_store4(sX1 + ch * P1 + T + 4 * xl, pre1[j], m1);
+        }
+      }
+    }
+    __syncthreads();
+    const long rn = next_valid(r + 1);
+    if (rn < r1) issue(rn);
+    for (int st = wave; st < nst; st += 4) {
+      const int x0 = 32 * st + 8 * kg;
+      bf16x8 bh[TK], bm[TK], bl[TK];
+#pragma unroll
+      for (int tj = 0; tj < TK; ++tj) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = sX2[(tj * 16 + c) * P2 + x0 + e];
+        seg_split8(v, bh[tj], bm[tj], bl[tj]);
+      }
+#pragma unroll
+      for (int ti = 0; ti < MTMAX; ++ti) {
+        if (ti < mt) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = sX1[aoff[ti] + x0 + e];
+          bf16x8 ah, am, al;
+          seg_split8(v, ah, am, al);
+#pragma unroll
+          for (int tj = 0; tj < TK; ++tj) acc[ti][tj] = seg_mfma6(ah, am, al, bh[tj], bm[tj], bl[tj], acc[ti][tj]);
+        }
+      }
+    }
+    r = rn;
+  }
+  // cross-wave reduction, one row tile at a time, through LDS (reuses the row buffers)
+  float* red = reinterpret_cast<float*>(smem_raw);          // [4 waves][TK][256]
+#pragma unroll
+  for (int ti = 0; ti < MTMAX; ++ti) {
+    if (ti >= mt) continue;
+    __syncthreads();
+#pragma unroll
+    for (int tj = 0; tj < TK; ++tj)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) red[(wave * TK + tj) * 256 + lane * 4 + rr] = acc[ti][tj][rr];
+    __syncthreads();
+    for (int idx = tid; idx < TK * 256; idx += 256) {
+      const int tj = idx >> 8, e = idx & 255, ln = e >> 2, rr = e & 3;
+      const int m = ti * 16 + (ln >> 4) * 4 + rr, j = tj * 16 + (ln & 15);
+      if (m < mrows && j < k) {
+        const int a = m / k, i = m - a * k;
+        float* out = part + (((long)split * nq + p) * nq + q0 + a) * k * k;
+        out[(long)i * k + j] = red[(0 * TK + tj) * 256 + e] + red[(1 * TK + tj) * 256 + e] +
+                               red[(2 * TK + tj) * 256 + e] + red[(3 * TK + tj) * 256 + e];
+      }
+    }
+  }
+}
+
 // G of one launch, laid out as the gradient kernel's LDS image wants it:
 //   Gp[p][r = q*k4 + b][a (pitch 16*TK)] = gl*dR1[p,q][e] + gnl*dR2[p,q][e],  e = a*k+b (which 0) | b*k+a
 // k4 = roundup4(k); rows with b >= k and columns a >= k are zero.  grid = (nq, ceil(rowsP*PG/256)).
 __global__ __launch_bounds__(256) void seg_gprep_kernel(
     const float* __restrict__ dR1, const float* __restrict__ dR2, const float* __restrict__ gl,
     const float* __restrict__ gnl, float* __restrict__ Gp, int k, int nq, int PG, int rowsP,
-    int which, int shift_stride) {
+    int which, int shift_stride, int k4) {       // k4: classes per shift, padded (4 | 8)
   const int p = blockIdx.x;
   const int idx = blockIdx.y * 256 + threadIdx.x;
   if (idx >= rowsP * PG) return;
-  const int k4 = (k + 3) & ~3;
   const int r = idx / PG, a = idx - r * PG;
   const int q = r / k4, b = r - q * k4;
   float v = 0.f;
@@ -634,6 +815,160 @@ __global__ __launch_bounds__(256) void seg_grad_stream_kernel(
   }
 }
 
+
+// Gradient on the bf16 pipe.  Same staging, unit split and output as seg_grad_stream_kernel; K is ordered (column
+// shift q, class b padded to k8 = roundup8(k)) and consumed 32 at a time: lane (pixel / class column c, k group kg)
+// holds the 8 classes of ONE octet o = 4 s + kg -> (shift ql = o / K8, classes 8 (o % K8) .. + 7), so the column
+// offset is per k group (per lane), not per wave.  Octets past the slice end contribute zeros.
+template <int TK, int LW>
+__global__ __launch_bounds__(256) void seg_grad_bf16_kernel(
+    const float* __restrict__ src, const float* __restrict__ mask, const int* __restrict__ flips,
+    const float* __restrict__ Gp, float* __restrict__ out, int bn, int k, int h, int w, int T,
+    int which, int src_is_x2, int QC, int rowsP) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int CR = 256 / LW, NJ = (16 * TK + CR - 1) / CR;
+  constexpr int PG = 16 * TK;
+  constexpr int NU = 4 * TK;
+  const int nq = 2 * T + 1;
+  const int k8 = (k + 7) & ~7, K8 = k8 >> 3;
+  const int w16 = (w + 15) & ~15;
+  const int PS = seg_pitch16(w16 + 2 * T);
+  float* sS = reinterpret_cast<float*>(smem_raw);          // [k8][PS]     masked source row
+  float* sG = sS + (((long)k8 * PS + 3) & ~3L);            // [slice rows][PG]
+  const int per8 = gridDim.x >> 3;
+  const int row = (blockIdx.x & 7) * per8 + (blockIdx.x >> 3);
+  if (row >= bn * h) return;
+  const int n = row / h, y = row - n * h;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = (__builtin_amdgcn_readfirstlane(tid >> 6) + 2 * ((blockIdx.x >> 8) & 1)) & 3;
+  const int c = lane & 15, kg = lane >> 4;
+  const int xl = tid % LW, cr = tid / LW, wq = w >> 2;
+  const bool xact = xl < wq;
+  const int sgn = which == 0 ? -1 : 1;
+  const int fx = src_is_x2 ? flips[2 * n] : 0, fy = src_is_x2 ? flips[2 * n + 1] : 0;
+  const int nunit = (w16 / 16) * TK;
+  const int nch = (nq + QC - 1) / QC;
+  const int nu = nunit > wave ? (nunit - wave + 3) / 4 : 0;
+  f32x4 acc[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int idx = tid; idx < k8 * PS; idx += 256) sS[idx] = 0.f;   // halo + padded classes stay zero
+
+  float4 pres[NJ], pm, preg[SEG_NG];
+  auto next_valid = [&](int p) {
+    while (p < nq) {
+      const int ys = y + sgn * (p - T);
+      if (ys >= 0 && ys < h) break;
+      ++p;
+    }
+    return p;
+  };
+  auto issue = [&](int p, int ch_) {
+    const float* g = Gp + ((long)p * rowsP + (long)ch_ * QC * k8) * PG;
+    const int nf4 = min(QC, nq - ch_ * QC) * k8 * (PG / 4);
+#pragma unroll
+    for (int j = 0; j < SEG_NG; ++j) {
+      const int f = tid + 256 * j;
+      if (f < nf4) preg[j] = seg_ld4(g + 4 * f);
+    }
+    if (ch_ == 0 && xact) {
+      const int ys = y + sgn * (p - T);
+      const int sy = fy ? h - 1 - ys : ys, sx = fx ? wq - 1 - xl : xl;
+      pm = seg_ld4(mask + ((long)n * h + ys) * w + 4 * xl);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int ch = cr + CR * j;
+        if (ch < k) pres[j] = seg_ld4(src + (((long)n * k + ch) * h + sy) * w + 4 * sx);
+      }
+    }
+  };
+  int ubase[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) ubase[u] = ((wave + 4 * u) / TK) * 16 + c;
+  const int gc = ((wave % TK) * 16) + c;                  // (a wave's units all use one class tile: TK divides 4)
+
+  int p = next_valid(0), ch_ = 0;
+  if (p < nq) issue(p, 0);
+  while (p < nq) {
+    __syncthreads();
+    {
+      const int nf4 = min(QC, nq - ch_ * QC) * k8 * (PG / 4);
+#pragma unroll
+      for (int j = 0; j < SEG_NG; ++j) {
+        const int f = tid + 256 * j;
+        if (f < nf4) {
+          const int rr = (4 * f) / PG, a = 4 * f - rr * PG;
+          const int as = TK == 2 ? (a ^ ((rr & 1) << 4)) : a;
+          *reinterpret_cast<float4*>(sG + rr * PG + as) = preg[j];
+        }
+      }
+    }
+    if (ch_ == 0 && xact) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int ch = cr + CR * j;
+        if (ch < k) seg_store4(sS + ch * PS + T + 4 * xl, fx ? seg_rev4(pres[j]) : pres[j], pm);
+      }
+    }
+    __syncthreads();
+    int pn = p, cn = ch_ + 1;
+    if (cn == nch) { cn = 0; pn = next_valid(p + 1); }
+    if (pn < nq) issue(pn, cn);
+    {
+      const int qc0 = ch_ * QC;
+      const int qn = min(QC, nq - qc0);
+      const int xoff0 = sgn * (qc0 - T) + T;
+      const int noct = qn * K8;
+      // this lane's octet walks o = kg, kg + 4, ...: (ql, oc) kept incrementally (K8 <= 4: at most 4 wraps per step)
+      int ql = 0, oc = kg;
+      while (oc >= K8) { oc -= K8; ++ql; }
+      for (int o0 = 0; o0 < noct; o0 += 4) {
+        const bool kv = o0 + kg < noct;
+        const int b0 = 8 * oc;
+        const float* srow = sS + b0 * PS + xoff0 + sgn * ql;
+        const float* grow = sG + (ql * k8 + b0) * PG;
+        float gv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gv[e] = kv ? grow[e * PG + (TK == 2 ? (gc ^ ((e & 1) << 4)) : gc)] : 0.f;
+        bf16x8 bh, bm, bl;
+        seg_split8(gv, bh, bm, bl);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          if (u < nu) {
+            float av[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) av[e] = kv ? srow[e * PS + ubase[u]] : 0.f;
+            bf16x8 ah, am, al;
+            seg_split8(av, ah, am, al);
+            acc[u] = seg_mfma6(ah, am, al, bh, bm, bl, acc[u]);
+          }
+        }
+        oc += 4;
+        while (oc >= K8) { oc -= K8; ++ql; }
+      }
+    }
+    p = pn; ch_ = cn;
+  }
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int unit = wave + 4 * u;
+    if (unit >= nunit) continue;
+    const int tile = unit / TK, t = unit - tile * TK;
+    const int a = t * 16 + c;
+    if (a >= k) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int x = tile * 16 + kg * 4 + r;
+      if (x < w) {
+        const float v = acc[u][r] * mask[((long)n * h + y) * w + x];
+        const int oy = (src_is_x2 == 0 && which == 1 && flips[2 * n + 1]) ? h - 1 - y : y;
+        const int ox = (src_is_x2 == 0 && which == 1 && flips[2 * n]) ? w - 1 - x : x;
+        out[(((long)n * k + a) * h + oy) * w + ox] = v;
+      }
+    }
+  }
+}
+
 extern "C" {
 
 static int seg_tk(int k) { return (k + 15) / 16; }
@@ -643,6 +978,19 @@ static bool seg_stream_ok(int k, int w, const void* a, const void* b, const void
   return g_seg_stream && (w & 3) == 0 && k <= 32 &&
          ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c)) & 15) == 0;
 }
+// bf16-split kernels (three-term operands on v_mfma_f32_16x16x32_bf16).  Measured (tools/seg_bf16_ab.py,
+// profiles/r06_seg_bf16_ab.txt; results agree with the exact-fp32 MFMA kernels to 1e-6): the split is done on the
+// fly -- 8 scalar LDS reads and ~36 VALU per 8-element fragment -- and that, not the matrix pipe, then sets the time:
+//   joint     k = 15: 4.38 -> 3.70 ms (1.18x), k = 3: 1.83 -> 1.10 (1.67x), k = 24: 20.1 -> 19.9 (1.01x)
+//   gradient  k = 15: 4.01 -> 5.47 ms (0.73x), k = 24: 20.3 -> 24.2 (0.84x), k = 3: 1.7 -> 3.2 (0.5x)
+// (one shared-operand fragment per step in the joint, one per 7 MFMA units in the gradient: the gradient pays a split
+// per product group).  Splitting at staging time instead needs the three bf16 planes in LDS with 16-byte-aligned
+// fragments for every column shift, i.e. the k index across image ROWS and 8 rows of both maps resident (113 + 98 KB
+// at k = 15, w = 128): it does not fit.  Default (1): the joint at k <= 16, T >= 5 -- the only place it pays; the
+// gradient stays on the exact-fp32 MFMA.  iic_debug_seg_bf16(0): fp32 everywhere; (2): bf16 split everywhere (A/B, tests).
+IIC_SWITCH(g_seg_bf16, 1, iic_debug_seg_bf16)
+static bool seg_bf16_joint_ok(int k, int T) { return g_seg_bf16 == 2 || (g_seg_bf16 == 1 && T >= 5 && k <= 16); }
+static bool seg_bf16_grad_ok() { return g_seg_bf16 == 2; }
 static int seg_qg(int tk) { return tk == 1 ? 21 : (tk == 2 ? 7 : 3); }
 // streaming joint kernel: row tiles per workgroup (accumulators) and the column shifts per group that
 // fill them -- groups balanced over the 2T+1 shifts
@@ -702,7 +1050,26 @@ int iic_seg_joint_raw(const float* x1, const float* x2, const float* mask, const
   do {                                                                                          \
     if (w > 128) SEGJS(TK_, MT_, 64); else SEGJS(TK_, MT_, 32);                                 \
   } while (0)
-  if (seg_stream_ok(k, w, x1, x2, mask)) {
+  if (seg_stream_ok(k, w, x1, x2, mask) && seg_bf16_joint_ok(k, T)) {
+    const int w32 = seg_w32(w);
+    const size_t srows = (size_t)16 * tk * (seg_pitch2(w32 + 2 * T) + seg_pitch2(w32)) * sizeof(float);
+    const size_t sred = (size_t)4 * tk * 256 * sizeof(float);
+    const size_t lds = srows > sred ? srows : sred;
+    int sqg = 1;
+    const int sgroups = seg_stream_groups(k, nq, &sqg);
+    dim3 sgrid(nq, sgroups, nsplit);
+#define SEGJB(TK_, MT_, LW_)                                                                    \
+  do {                                                                                          \
+    if (lds > 48 * 1024)                                                                        \
+      (void)hipFuncSetAttribute(                                                                \
+          reinterpret_cast<const void*>(&seg_joint_bf16_kernel<TK_, MT_, LW_>),                 \
+          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
+    hipLaunchKernelGGL((seg_joint_bf16_kernel<TK_, MT_, LW_>), sgrid, dim3(256), lds, s, x1,    \
+                       x2, mask, flips, partials, bn, k, h, w, T, sqg);                         \
+  } while (0)
+    if (tk == 1) { if (w > 128) SEGJB(1, SEG_MT1, 64); else SEGJB(1, SEG_MT1, 32); }
+    else { if (w > 128) SEGJB(2, SEG_MT2, 64); else SEGJB(2, SEG_MT2, 32); }
+  } else if (seg_stream_ok(k, w, x1, x2, mask)) {
     const size_t srows = (size_t)16 * tk * (seg_pitch2(w + 2 * T) + seg_pitch2(w)) * sizeof(float);
     const size_t sred = (size_t)4 * tk * 256 * sizeof(float);
     const size_t lds = srows > sred ? srows : sred;
@@ -719,7 +1086,7 @@ int iic_seg_joint_raw(const float* x1, const float* x2, const float* mask, const
 long iic_seg_grad_workspace_bytes(int k, int T) {
   if (k < 1 || k > 48 || T < 0 || T > 10) return 0;
   const int nq = 2 * T + 1, tk = seg_tk(k);
-  return (long)nq * nq * ((k + 3) & ~3) * 16 * tk * (long)sizeof(float);
+  return (long)nq * nq * ((k + 7) & ~7) * 16 * tk * (long)sizeof(float);      // (classes padded to 8: the bf16 path)
 }
 
 int iic_seg_grad(const float* src, const float* mask, const int* flips, const float* dR_loss,
@@ -732,6 +1099,33 @@ int iic_seg_grad(const float* src, const float* mask, const int* flips, const fl
   const int w16 = (w + 15) & ~15;
   const int src_is_x2 = which == 0 ? 1 : 0;   // d/dx1 reads x2m ; d/dx2 reads x1m
   hipStream_t s = (hipStream_t)stream;
+  if (g_seg_stream && workspace && seg_stream_ok(k, w, src, mask, out) && ((uintptr_t)workspace & 15) == 0 &&
+      seg_bf16_grad_ok()) {
+    // bf16-split path: as the streaming path below, classes padded to 8 per shift
+    const int PG = 16 * tk, k8 = (k + 7) & ~7, rowsP = nq * k8;
+    int QC = (256 * SEG_NG * 4 / PG) / k8;
+    if (QC < 1) return IIC_ERR_UNSUPPORTED;
+    if (QC > nq) QC = nq;
+    hipLaunchKernelGGL(seg_gprep_kernel, dim3(nq, (rowsP * PG + 255) / 256), dim3(256), 0, s,
+                       dR_loss, dR_loss_no_lamb, g_loss, g_loss_no_lamb, workspace, k, nq, PG, rowsP,
+                       which, collapsed ? 0 : 1, k8);
+    const int PS = seg_pitch16(w16 + 2 * T);
+    const size_t lds = ((((size_t)k8 * PS + 3) & ~(size_t)3) + (size_t)QC * k8 * PG) * sizeof(float);
+#define SEGGB(TK_, LW_)                                                                         \
+  do {                                                                                          \
+    if (lds > 48 * 1024)                                                                        \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seg_grad_bf16_kernel<TK_, LW_>), \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
+    hipLaunchKernelGGL((seg_grad_bf16_kernel<TK_, LW_>), dim3(8 * ((bn * h + 7) / 8)), dim3(256), lds, s, src, \
+                       mask, flips, workspace, out, bn, k, h, w, T, which, src_is_x2, QC, rowsP); \
+  } while (0)
+#define SEGGB_LW(TK_)                                                                           \
+  do {                                                                                          \
+    if (w > 128) SEGGB(TK_, 64); else if (w > 64) SEGGB(TK_, 32); else SEGGB(TK_, 16);          \
+  } while (0)
+    if (tk == 1) SEGGB_LW(1); else SEGGB_LW(2);
+    return iic_launch_status();
+  }
   if (g_seg_stream && workspace && seg_stream_ok(k, w, src, mask, out) && ((uintptr_t)workspace & 15) == 0) {
     // streaming path: G laid out once per launch (workspace), then one workgroup per output row
     const int PG = 16 * tk, k4 = (k + 3) & ~3, rowsP = nq * k4;
@@ -740,7 +1134,7 @@ int iic_seg_grad(const float* src, const float* mask, const int* flips, const fl
     if (QC > nq) QC = nq;
     hipLaunchKernelGGL(seg_gprep_kernel, dim3(nq, (rowsP * PG + 255) / 256), dim3(256), 0, s,
                        dR_loss, dR_loss_no_lamb, g_loss, g_loss_no_lamb, workspace, k, nq, PG, rowsP,
-                       which, collapsed ? 0 : 1);
+                       which, collapsed ? 0 : 1, k4);
     const int PS = seg_pitch16(w16 + 2 * T);
     const size_t lds = ((((size_t)k4 * PS + 3) & ~(size_t)3) + (size_t)QC * k4 * PG) * sizeof(float);
 #define SEGGS(TK_, LW_)                                                                         \

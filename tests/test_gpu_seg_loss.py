@@ -188,6 +188,7 @@ def test_stream_kernels_match_generic_kernels_bitwise(bn, k, h, w, T, collapsed)
   ns = L.iic_seg_joint_nsplit(bn, h, k, T)
   res = {}
   try:
+    dbg.iic_debug_seg_bf16(0)       # (the bf16-split joint of round 6 agrees to rounding, not bitwise: its own test below)
     for mode in (0, 1):
       dbg.iic_debug_seg_stream(mode)
       part = torch.full((ns, nq * nq, k, k), float("nan"), device=dev())
@@ -204,6 +205,7 @@ def test_stream_kernels_match_generic_kernels_bitwise(bn, k, h, w, T, collapsed)
       res[mode] = (part, outs[0], outs[1])
   finally:
     dbg.iic_debug_seg_stream(1)
+    dbg.iic_debug_seg_bf16(1)
   for i, (a, b) in enumerate(zip(res[0], res[1])):
     assert torch.isfinite(a).all()
     if i == 0 or k % 4 == 0:
@@ -212,6 +214,56 @@ def test_stream_kernels_match_generic_kernels_bitwise(bn, k, h, w, T, collapsed)
       # gradient kernel, k % 4 != 0: the streaming kernel pads the classes of every column shift to
       # a multiple of 4, so its MFMA steps group the same products differently (rounding only)
       assert float((a - b).norm() / a.norm()) <= 2e-6
+
+
+@pytest.mark.parametrize("bn,k,h,w,T", [(3, 15, 20, 128, 10), (2, 24, 14, 200, 10), (2, 3, 9, 200, 5), (2, 9, 11, 64, 3),
+                                        (1, 32, 7, 40, 2), (2, 16, 6, 8, 1), (1, 1, 5, 256, 10), (2, 17, 3, 132, 4)])
+@pytest.mark.parametrize("collapsed", [False, True])
+@pytest.mark.hooks
+def test_bf16_split_kernels_match_the_exact_fp32_mfma_kernels(bn, k, h, w, T, collapsed):
+  """Round 6: the joint / gradient on the bf16 matrix pipe (every fp32 operand element as three bf16 terms, six
+  v_mfma_f32_16x16x32_bf16 per product; the product path uses the joint form at k <= 16, T >= 5) against the exact-fp32
+  MFMA kernels on the same inputs -- per-image flips, a blob mask, ragged class counts and widths: the dropped terms are
+  below 2^-24 of a product, so the two agree to fp32 summation noise."""
+  import ctypes
+  from iic_amd import _lib
+  from iic_amd._lib import check, lib, ptr, stream_ptr
+  L, dbg = lib(), ctypes.CDLL(_lib.LIB_PATH)
+  g = torch.Generator().manual_seed(17 + k + w)
+  x1 = torch.softmax(torch.randn(bn, k, h, w, generator=g) * 2, 1).to(dev())
+  x2 = torch.softmax(torch.randn(bn, k, h, w, generator=g) * 2, 1).to(dev())
+  mask = (torch.rand(bn, h, w, generator=g) < 0.6).float().to(dev())
+  flips = torch.tensor([[i & 1, (i >> 1) & 1] for i in range(1, bn + 1)], dtype=torch.int32).to(dev())
+  nq = 2 * T + 1
+  H = 1 if collapsed else nq * nq
+  dR1 = torch.randn(H, k, k, generator=g).to(dev())
+  dR2 = torch.randn(H, k, k, generator=g).to(dev())
+  g1 = torch.randn(H, generator=g).to(dev())
+  g2 = torch.randn(H, generator=g).to(dev())
+  ns = L.iic_seg_joint_nsplit(bn, h, k, T)
+  res = {}
+  try:
+    for mode in (0, 2):
+      dbg.iic_debug_seg_bf16(mode)
+      part = torch.full((ns, nq * nq, k, k), float("nan"), device=dev())
+      check(L.iic_seg_joint_raw(ptr(x1), ptr(x2), ptr(mask), ptr(flips), ptr(part), bn, k, h, w, T, ns,
+                                stream_ptr()), "joint")
+      ws = torch.empty(L.iic_seg_grad_workspace_bytes(k, T) // 4, device=dev())
+      outs = []
+      for which, src in ((0, x2), (1, x1)):
+        o = torch.full_like(x1, float("nan"))
+        check(L.iic_seg_grad(ptr(src), ptr(mask), ptr(flips), ptr(dR1), ptr(dR2), ptr(g1), ptr(g2), ptr(o),
+                             bn, k, h, w, T, which, 1 if collapsed else 0, ptr(ws), stream_ptr()), "grad")
+        outs.append(o)
+      torch.cuda.synchronize()
+      res[mode] = (part.double().sum(0), outs[0], outs[1])
+  finally:
+    dbg.iic_debug_seg_bf16(1)
+  a, b = res[0], res[2]
+  assert all(torch.isfinite(t).all() for t in b)
+  assert float((a[0] - b[0]).abs().max()) <= 2e-6 * float(a[0].abs().max()), float((a[0] - b[0]).abs().max() / a[0].abs().max())
+  for i in (1, 2):
+    assert float((a[i] - b[i]).norm() / a[i].norm()) <= 5e-6, float((a[i] - b[i]).norm() / a[i].norm())
 
 
 @pytest.mark.parametrize("name,bn,k,h,w,T,dens", [("potsdam3", 75, 24, 200, 200, 10, 1.0),
