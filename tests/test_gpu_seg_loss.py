@@ -65,9 +65,13 @@ def test_seg_loss_golden(ci, collapsed):
 
 
 @pytest.mark.parametrize("bn,k,h,w,T", [(3, 15, 40, 64, 10), (2, 24, 24, 40, 5), (2, 45, 16, 32, 3), (2, 3, 30, 50, 1),
-                                        # edge shapes: no shift at all, one sample, k = 2, odd sizes (w % 4 != 0 and k > 32 take the
+                                        # edge shapes: no shift at all, one sample, k = 2, odd sizes (w % 4 != 0 takes the
                                         # generic kernels), a shift range almost as large as the image
-                                        (1, 2, 9, 13, 0), (2, 3, 17, 23, 2), (1, 33, 8, 12, 1), (2, 5, 8, 9, 6)])
+                                        (1, 2, 9, 13, 0), (2, 3, 17, 23, 2), (1, 33, 8, 12, 1), (2, 5, 8, 9, 6),
+                                        # round 6: 33 <= k <= 48 on the streaming kernels (three class tiles) -- the
+                                        # overclustering heads of the reference's 15- / 6-class runs (k_A = 45 / 36,
+                                        # commands.txt:80,89) at their row widths and shift ranges, reduced heights
+                                        (1, 45, 24, 128, 10), (1, 36, 12, 200, 5), (2, 48, 6, 72, 2)])
 @pytest.mark.parametrize("collapsed", [False, True])
 def test_seg_loss_larger_vs_oracle(bn, k, h, w, T, collapsed):
   from iic_amd import seg_losses
@@ -163,7 +167,8 @@ def test_affine_warp_matches_grid_sample():
 
 @pytest.mark.parametrize("bn,k,h,w,T", [(2, 24, 14, 200, 10), (3, 15, 20, 128, 10), (2, 3, 9, 200, 1),
                                         (2, 9, 11, 64, 3), (1, 32, 7, 40, 2), (2, 16, 6, 8, 1),
-                                        (2, 5, 6, 8, 0), (3, 24, 1, 12, 2), (1, 1, 5, 256, 10), (2, 17, 3, 132, 4)])
+                                        (2, 5, 6, 8, 0), (3, 24, 1, 12, 2), (1, 1, 5, 256, 10), (2, 17, 3, 132, 4),
+                                        (1, 36, 5, 200, 5), (2, 45, 4, 128, 10), (2, 48, 3, 40, 1), (1, 33, 4, 132, 3)])
 @pytest.mark.parametrize("collapsed", [False, True])
 @pytest.mark.hooks
 def test_stream_kernels_match_generic_kernels_bitwise(bn, k, h, w, T, collapsed):
