@@ -68,20 +68,40 @@ def rank():
 _CAPTURE_CUT = [None]
 
 
+def _all_reduce_now(t, grp):
+  """SUM all-reduce of `t`, ordered on the current stream.  Issued as an ASYNCHRONOUS collective + wait(): RCCL's
+  kernel and the work's completion event then live on the process group's own stream, never on the caller's.  A
+  synchronous collective runs on the caller's stream (torch >= 2.8), and the process group's watchdog thread keeps
+  polling its completion event for a while after it finished -- if that stream starts a graph capture in the meantime
+  (the warm-up step of a CapturedPairStep runs on the very streams it then captures on), HIP refuses the query
+  (hipErrorCapturedEvent: 'operation not permitted on an event last recorded in a capturing stream') and the watchdog
+  takes the process down.  Seen in about one of ten one-rank RCCL runs (round 6, tools/r06_rccl_flaky.sh)."""
+  _count("all_reduce")
+  if dist.get_backend(grp) == "nccl":
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=grp, async_op=True).wait()
+  else:
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=grp)
+
+
 def all_reduce_sum_(t):
   """In-place SUM all-reduce (no-op when not distributed)."""
   if enabled():
+    grp = _STATE["group"]
     if _CAPTURE_CUT[0] is not None:
-      grp = _STATE["group"]
-
-      def replayed():
-        _count("all_reduce")
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=grp)
-      _CAPTURE_CUT[0](replayed)
+      _CAPTURE_CUT[0](lambda: _all_reduce_now(t, grp))
     else:
-      _count("all_reduce")
-      dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_STATE["group"])
+      _all_reduce_now(t, grp)
   return t
+
+
+def settle_before_capture():
+  """Call between the eager warm-up of a step and its graph capture: completed collectives stay in the process group's
+  watchdog list until its next poll (every 100 ms); give it two polls to retire them before any stream that carried a
+  collective's event starts capturing (see _all_reduce_now; one-time cost per captured step)."""
+  if enabled() and dist.get_backend(_STATE["group"]) == "nccl":
+    import time
+    torch.cuda.synchronize()
+    time.sleep(0.25)
 
 
 def shard_rows(n_rows, r=None, w=None):

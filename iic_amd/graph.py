@@ -139,8 +139,7 @@ def _collective_blocks(s, cycles=1200000):
     import torch.distributed as tdist
     grp = idist._STATE["group"]
     buf = torch.zeros(1024, device="cuda")
-    idist._count("all_reduce")
-    tdist.all_reduce(buf, op=tdist.ReduceOp.SUM, group=grp)      # (communicator + its stream exist from here on)
+    idist._all_reduce_now(buf, grp)      # (communicator + its stream exist from here on)
     if "scratch" not in _COLL_PROBE:
       _COLL_PROBE["scratch"] = torch.cuda.Stream()
     sc = _COLL_PROBE["scratch"]
@@ -196,6 +195,8 @@ class CapturedStep(object):
         fn()
     cur.wait_stream(side)
     torch.cuda.synchronize()
+    from . import dist as idist
+    idist.settle_before_capture()
     self.graph = torch.cuda.CUDAGraph()
     # capture on the SAME stream the warm-up ran on: autograd's AccumulateGrad nodes remember the
     # stream they were created on; with a different capture stream the engine forks every
@@ -339,6 +340,7 @@ class CapturedPairStep(object):
     for _ in range(max(1, warmup)):
       self._eager_step()
     torch.cuda.synchronize()
+    idist.settle_before_capture()
     zero_grad()
     ops.clear_branch_grads()
     pool_a, pool_b = torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle()

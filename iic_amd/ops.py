@@ -5,7 +5,7 @@ the hot path is a kernel of libiic_hip.so.  All wrappers enqueue on torch's curr
 """
 import ctypes
 import os
-
+import threading
 import weakref
 
 import torch
@@ -37,12 +37,96 @@ F32 = torch.float32
 # updates of BOTH views are postponed to the join and applied there in call order -- the order a
 # sequential run would have used (bn_finalize -> _DEFERRED_RUNNING).
 # ------------------------------------------------------------------------------------
-BRANCH = [0]
-_BRANCH_STREAM = {}
-_PROXIES = {}             # id(param) -> (param, {branch: leaf alias sharing its storage})
-_DEFERRED_RUNNING = []    # (coef, running_mean, running_var, num_batches_tracked, C) of a branch
-_PENDING_JOIN = []        # (main stream, side stream) of branches not joined yet
-_BRANCH_MAIN = [None]     # inside `with branch():` the stream the caller was on (iic_amd.graphed orders it after a view's backward)
+class BranchContext(object):
+  """Everything the two-stream execution keeps between calls, in ONE object per thread (round 6; until round 5 these
+  were nine module-level lists / dicts, which is the style that produced round 5's read-before-join race): the branch
+  the calling code is on, the side streams, the per-branch leaf aliases of the parameters, the forks not joined yet
+  and the running-statistic updates they postponed.  One process drives one device (the data-parallel design: one
+  process per GPU), so a context is per thread, and its streams are keyed by device inside.  The autograd engine runs
+  backward nodes on its own threads: every Function records its branch at forward time (ctx.branch) and
+  `branch_backward` restores it there, so a backward thread never depends on the forward thread's context.
+  The module-level names below (BRANCH[0], _PENDING_JOIN, ...) are views of the calling thread's context."""
+  __slots__ = ("branch", "streams", "proxies", "deferred_running", "pending_join", "branch_main", "no_proxy_branches",
+               "capture_proxies", "solo_first")
+
+  def __init__(self):
+    self.branch = 0                 # BRANCH[0]: 0 = the caller's stream, >= 1 = a side branch / resource namespace
+    self.streams = {}               # _BRANCH_STREAM: (device, branch index) -> side stream
+    self.proxies = {}               # _PROXIES: id(param) -> (param, {branch: leaf alias sharing its storage})
+    self.deferred_running = []      # _DEFERRED_RUNNING: (coef, running_mean, running_var, num_batches_tracked, C)
+    self.pending_join = []          # _PENDING_JOIN: (main stream, side stream) of branches not joined yet
+    self.branch_main = None         # _BRANCH_MAIN[0]: inside `with branch():` the stream the caller was on
+    self.no_proxy_branches = set()  # _NO_PROXY_BRANCHES (see below)
+    self.capture_proxies = None     # _CAPTURE_PROXIES[0]: iic_amd.graphed, {id(param): leaf alias} during a capture
+    self.solo_first = 0             # _SOLO_FIRST[0] (see auto_branch)
+
+
+_TLS = threading.local()
+
+
+def context():
+  """The calling thread's BranchContext."""
+  c = getattr(_TLS, "ctx", None)
+  if c is None:
+    c = _TLS.ctx = BranchContext()
+  return c
+
+
+class _CtxCell(object):
+  """`NAME[0]` view of a scalar field of the calling thread's context."""
+  __slots__ = ("_attr",)
+
+  def __init__(self, attr):
+    self._attr = attr
+
+  def __getitem__(self, i):
+    return getattr(context(), self._attr)
+
+  def __setitem__(self, i, v):
+    setattr(context(), self._attr, v)
+
+
+class _CtxView(object):
+  """Container view (list / dict / set) of a field of the calling thread's context."""
+  __slots__ = ("_attr",)
+
+  def __init__(self, attr):
+    self._attr = attr
+
+  def _o(self):
+    return getattr(context(), self._attr)
+
+  def __getattr__(self, name):
+    return getattr(self._o(), name)
+
+  def __len__(self):
+    return len(self._o())
+
+  def __bool__(self):
+    return bool(self._o())
+
+  def __iter__(self):
+    return iter(self._o())
+
+  def __contains__(self, x):
+    return x in self._o()
+
+  def __getitem__(self, k):
+    return self._o()[k]
+
+  def __setitem__(self, k, v):
+    self._o()[k] = v
+
+  def __delitem__(self, k):
+    del self._o()[k]
+
+
+BRANCH = _CtxCell("branch")
+_BRANCH_STREAM = _CtxView("streams")
+_PROXIES = _CtxView("proxies")                    # id(param) -> (param, {branch: leaf alias sharing its storage})
+_DEFERRED_RUNNING = _CtxView("deferred_running")  # (coef, running_mean, running_var, num_batches_tracked, C) of a branch
+_PENDING_JOIN = _CtxView("pending_join")          # (main stream, side stream) of branches not joined yet
+_BRANCH_MAIN = _CtxCell("branch_main")            # inside `with branch():` the stream the caller was on (iic_amd.graphed orders it after a view's backward)
 
 
 # IIC_BRANCH_PROXIES=0 (debugging only): side branches use the parameters themselves and autograd accumulates both
@@ -57,10 +141,10 @@ USE_PROXIES = [os.environ.get("IIC_BRANCH_PROXIES", "1") != "0"]
 # alias gradients into .grad.  It was demoted to opt-in in round 4 because about 1 run in 13 differed from the one-stream
 # run; round 5 found the cause -- the loss stacked the forked view's outputs before joining it, iic_amd/losses.py -- and
 # removed the mode rather than carry a second gradient hand-over for launches that are host-bound anyway.)
-_NO_PROXY_BRANCHES = set()
+_NO_PROXY_BRANCHES = _CtxView("no_proxy_branches")
 
 
-_CAPTURE_PROXIES = [None]   # iic_amd.graphed: {id(param): leaf alias} while a view's graphs are captured
+_CAPTURE_PROXIES = _CtxCell("capture_proxies")   # iic_amd.graphed: {id(param): leaf alias} while a view's graphs are captured
 
 
 def pv(p):
@@ -201,7 +285,7 @@ AUTO_BRANCH = [os.environ.get("IIC_AUTO_BRANCH", "0") == "1"]
 # A forward of the pair that runs EAGERLY -- graph replay off, a warm-up occurrence, a shape that was not captured --
 # stays on the caller's stream; the two streams are for captured / replayed views, whose gradient hand-over is explicit
 # (iic_amd/graphed.py).
-_SOLO_FIRST = [0]         # 1: the first forward of a pair ran on the caller's stream (the second one must not fork either)
+_SOLO_FIRST = _CtxCell("solo_first")   # 1: the first forward of a pair ran on the caller's stream (the second one must not fork either)
 # forwards that hand back FEATURES (semisup heads: sup_head5.py:34-35, net6c_two_head.py:78-94,
 # k-means feature extraction) are consumed by modules outside this library, which know nothing about
 # the side stream: they never branch

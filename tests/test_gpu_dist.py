@@ -83,7 +83,15 @@ def test_segmentation_losses_sharded_over_two_ranks_match_the_full_batch():
                       "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
                       os.path.join(ROOT, "tests", "seg_dist_driver.py")], env=env, capture_output=True, text=True,
                      timeout=600, cwd=ROOT)
-  lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+  # (the two ranks print at the same time: their lines can land on one line -- scan for objects, not for lines)
+  lines, dec, txt, pos = [], json.JSONDecoder(), r.stdout, 0
+  while True:
+    pos = txt.find('{"rank"', pos)
+    if pos < 0:
+      break
+    obj, end = dec.raw_decode(txt, pos)
+    lines.append(obj)
+    pos = end
   assert r.returncode == 0 and len(lines) == 2, r.stdout[-2000:] + r.stderr[-3000:]
   rows = sorted(tuple(l["results"][0]["rows"]) for l in lines)
   assert rows == [(0, 3), (3, 6)]

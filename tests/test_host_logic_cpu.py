@@ -143,3 +143,40 @@ def test_sig_changed_notices_a_buffer_replaced_through_a_submodule():
   assert graphed._sig_changed(net, st, vg)      # (the old object is still alive in the cached list: addresses alone would say "unchanged")
   vg2 = types.SimpleNamespace(sig=graphed._storage_sig(net))
   assert not graphed._sig_changed(net, st, vg2)
+
+
+def test_branch_state_is_one_context_per_thread():
+  """Round 6: the fork / join state of the two-stream execution -- current branch, pending joins,
+  postponed running-statistic updates, leaf aliases, the solo-pair mark -- lives in ONE BranchContext per thread; the
+  module-level names are views of the calling thread's context, so a second thread (a DataParallel-style worker, the
+  autograd engine's backward thread) starts clean and cannot disturb the first."""
+  import threading
+  main = ops.context()
+  assert ops.context() is main
+  prev = ops.BRANCH[0]
+  seen = {}
+  try:
+    ops.BRANCH[0] = 2
+    ops._PENDING_JOIN.append(("main", "side"))
+    ops._DEFERRED_RUNNING.append("update")
+    ops._NO_PROXY_BRANCHES.add(7)
+    ops._SOLO_FIRST[0] = 1
+
+    def worker():
+      seen["ctx_is_other"] = ops.context() is not main
+      seen["state"] = (ops.BRANCH[0], len(ops._PENDING_JOIN), len(ops._DEFERRED_RUNNING), 7 in ops._NO_PROXY_BRANCHES,
+                       ops._SOLO_FIRST[0], ops._BRANCH_MAIN[0], ops._CAPTURE_PROXIES[0])
+      ops.BRANCH[0] = 5
+      ops._PENDING_JOIN.append(("w", "w"))
+    t = threading.Thread(target=worker)
+    t.start()
+    t.join()
+    assert seen["ctx_is_other"] and seen["state"] == (0, 0, 0, False, 0, None, None)
+    assert ops.BRANCH[0] == 2 and list(ops._PENDING_JOIN) == [("main", "side")] and main.branch == 2
+    assert main.pending_join is ops._PENDING_JOIN._o() and main.solo_first == 1
+  finally:
+    ops.BRANCH[0] = prev
+    del ops._PENDING_JOIN[:]
+    del ops._DEFERRED_RUNNING[:]
+    ops._NO_PROXY_BRANCHES.discard(7)
+    ops._SOLO_FIRST[0] = 0
