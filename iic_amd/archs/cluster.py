@@ -324,7 +324,7 @@ class _BlockFn(torch.autograd.Function):
     coef1 = bn_coef(blk.bn1, h1, g1, b1, st1)
     # conv2 reads a1 = relu(bn1(y1)), made by a separate HBM pass.  (Round 4 built the fusion of that pass into conv2's
     # patch loader -- in LDS after the DMA -- bit-identical and 0.6-0.9 ms per step SLOWER; removed in round 5,
-    # DESIGN.md R5.3 has the arithmetic of why the register variant cannot pay either.)
+    # LAB.md section R5.3 has the arithmetic of why the register variant cannot pay either.)
     st2 = h2.stats(dev) if _bn_training(blk.bn2) else None
     y2 = ops.pt_alloc(N, Ho, Wo, planes, 1, dev)
     a1 = ops.pt_alloc(N, Ho, Wo, planes, 1, dev)

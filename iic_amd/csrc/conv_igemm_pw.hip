@@ -6,7 +6,7 @@
 // Same contract, same B-fragment weight operand (iic_weight_prep_frag), same results per output element
 // (same K order) as conv_igemm_bd_kernel; what changes is everything AROUND the MFMA loop.
 //
-// What the round-3 measurements said about conv_igemm_bd_kernel (profiles/r03_bd_timeline_*):
+// What the round-3 measurements said about conv_igemm_bd_kernel (LAB.md section 8.1, profiles/r03_bd_timeline_*):
 // inside the K loop two co-resident waves keep a SIMD's matrix pipe 0.95 busy, but a 256 x 128 tile spends
 // 29-48 % of its cycles outside it (row tables 3 k, prologue 5 k, 3.6 k per chunk boundary, epilogue 13-21 k),
 // and while ONE workgroup of a CU is in such a phase the other's waves run alone on their SIMDs at only

@@ -387,7 +387,7 @@ __global__ __launch_bounds__(B2_THREADS, 2) void conv_igemm_bd2_kernel(
   }
 }
 
-static int g_bd2_enabled = 0;   // off: measured slower than the round-2 kernel + interleaved K loop (profiles/r03_bd2_*)
+static int g_bd2_enabled = 0;   // off: measured slower than the round-2 kernel + interleaved K loop (LAB.md §8, profiles/r03_bd2_*)
 extern "C" void iic_debug_bd2(int v) { g_bd2_enabled = v; }
 static int g_bd2_mode = 0;
 extern "C" void iic_debug_bd2_mode(int v) { g_bd2_mode = v; }

@@ -57,12 +57,24 @@ def pick_stream(beside=(), what="stream", collective_free=False, tries=8):
   is not the one the process group's collectives are issued on.  HIP multiplexes its streams onto a few hardware queues
   (4 by default) in creation order, and which queue a new stream lands on depends on how many streams the process
   has created before (a process group's initialisation creates some): candidates are created until one passes the
-  probes (kept: the last one, if none does -- logged either way)."""
+  probes (kept: the last one, if none does -- logged either way).
+  Data parallel: the collective probe issues real collectives, so every rank must run the SAME sequence of them whatever
+  its own measurements say -- each candidate is probed unconditionally and the verdict is agreed on (all-reduce MIN)
+  before anyone moves on: all ranks try the same number of candidates."""
+  from . import dist as idist
   st = torch.cuda.Stream()
   if not _PROBE[0] or torch.cuda.is_current_stream_capturing():
     return st
+  agree = collective_free and idist.enabled()
   for i in range(tries):
-    ok = all(_streams_overlap(b, st) for b in beside) and not (collective_free and _collective_blocks(st))
+    ok = all([_streams_overlap(b, st) for b in beside])
+    if collective_free and _collective_blocks(st):
+      ok = False
+    if agree:
+      flag = torch.tensor([1.0 if ok else 0.0], device="cuda")
+      torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN, group=idist._STATE["group"])
+      idist._count("all_reduce")
+      ok = bool(flag.item() > 0.5)
     if ok:
       _log_probe(probe="pick", what=what, candidate=i, kept=True)
       return st
@@ -84,7 +96,7 @@ def _pair_streams():
   behind every bucket all-reduce (which itself waits for the fold of BOTH views): the pair is chosen among candidates
   that a pending collective does not block (_collective_blocks).  (Round 4 measured three alternatives -- the views on
   disjoint halves of the chip through CU-masked streams, half the CUs of every XCD each, view A at high priority:
-  neutral, worse, neutral; DESIGN.md section 7.7 -- and round 5 removed the switches.)"""
+  neutral, worse, neutral; LAB.md section 7.7 -- and round 5 removed the switches.)"""
   dev = torch.cuda.current_device()
   pair = _PAIR_STREAMS.get(dev)
   if pair is None:
@@ -152,9 +164,7 @@ def _collective_blocks(s, cycles=1200000):
       ev[1].record()
     torch.cuda.synchronize()
     single = ev[0].elapsed_time(ev[1])
-    if not _streams_overlap(s, sc):          # the scratch stream itself shares s's queue: nothing can be told apart
-      _log_probe(probe="collective", inconclusive=True)
-      return False
+    # (no early return between here and the collective below: every rank issues the same collectives whatever it measures)
     with torch.cuda.stream(s):
       ev[2].record()
     sc.wait_stream(s)
@@ -167,6 +177,9 @@ def _collective_blocks(s, cycles=1200000):
       ev[3].record()
     torch.cuda.synchronize()
     w.wait()
+    if not _streams_overlap(s, sc):          # the scratch stream itself shares s's queue: nothing can be told apart
+      _log_probe(probe="collective", inconclusive=True)
+      return False
     held = ev[2].elapsed_time(ev[3])
     _log_probe(probe="collective", single_ms=round(single, 3), beside_pending_collective_ms=round(held, 3),
                blocked=bool(held > 2.5 * single))

@@ -13,7 +13,7 @@
     Adam(lr 1e-3), 30 steps.
 
 Written at 1, 2 and 8 BLAS threads: a 30-step fp32 training run does not reproduce itself across summation orders
-(tests/golden/script_cluster_sobel.json), so the fixture carries the reference's OWN band and the
+(tests/golden/script_cluster_sobel.json, LAB.md section R5.4), so the fixture carries the reference's OWN band and the
 tests gate the HIP paths against it instead of pretending there is one trajectory.
 """
 import json

@@ -306,7 +306,7 @@ def test_auto_branch_reference_call_sequence_is_bit_identical():
 
 def test_captured_pair_steps_share_one_stream_pair_that_really_overlaps():
   """HIP multiplexes streams onto a few hardware queues in creation order: two streams on one queue run their work one
-  after the other (the second CapturedPairStep of a process used to end up there: DESIGN R5.6).  Every captured pair
+  after the other (the second CapturedPairStep of a process used to end up there: LAB.md section R5.6).  Every captured pair
   step shares ONE pair per device, chosen by a concurrency probe; the probe itself can tell the difference -- a stream
   never runs beside itself."""
   from iic_amd.graph import _pair_streams, _streams_overlap

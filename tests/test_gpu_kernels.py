@@ -684,7 +684,7 @@ def test_bn_backward_kernel_generations_agree(N, H, W, P, C):
 @pytest.mark.parametrize("N,H,W,P,C", [(5, 49, 49, 1, 64), (9, 13, 13, 1, 256), (3, 3, 5, 2, 512)])
 @pytest.mark.hooks
 def test_bn_passes_with_and_without_the_non_temporal_hint_are_bit_identical(N, H, W, P, C):
-  """The BatchNorm passes read their streams with `global_load ... nt` (cache policy only, DESIGN R5.6):
+  """The BatchNorm passes read their streams with `global_load ... nt` (cache policy only, LAB.md section R5.6):
   forward apply (plain, residual, downsample branch), both backward passes in every mask mode -- the
   hinted kernels (the product's default) against the plain loads, bit for bit, borders untouched."""
   import ctypes

@@ -1,4 +1,4 @@
-"""The Winograd F(2x2, 3x3) probe kernel (iic_amd/csrc/probes/wino_probe.hip) is not part of the
+"""The Winograd F(2x2, 3x3) probe kernel (iic_amd/csrc/probes/wino_probe.hip; LAB.md section R5.1) is not part of the
 product, but its measured no-go is only worth something if the kernel is RIGHT: forward convolution + BatchNorm
 statistics against float64 F.conv2d on the same bf16 operands, at small batches of the three layer shapes, odd sizes
 (tile quantisation: the last tile row / column runs off the image) and a ragged last workgroup tile; the transformed

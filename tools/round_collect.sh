@@ -2,7 +2,7 @@
 # (two streams, graphs) and the sequential eager launch modes, PMC traffic passes (FETCH_SIZE / WRITE_SIZE in
 # separate passes), one SQ pass, the default bench line and the 6c lines.  Results land in gpurun_out/; copy the
 # summaries into profiles/ afterwards.   usage: bash tools/round_collect.sh [tag]
-T=${1:-r05}
+T=${1:-r06}
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
 cd $R
