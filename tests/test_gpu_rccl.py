@@ -107,3 +107,16 @@ def test_other_baseline_configs_run_data_parallel_through_rccl(config, extra):
   #  path folds the joint's split partials in fp32 before the all-reduce: 1e-6 absolute measured)
   a, b = plain["config"]["final_loss"], rccl["config"]["final_loss"]
   assert a == a and abs(a - b) <= 1e-3 * abs(a) + 5e-6, (a, b)
+
+
+@pytest.mark.parametrize("config,extra,batch", [("mnist6c", [], 1400), ("coco3", [], 240)])
+def test_other_baseline_configs_start_two_ranks(config, extra, batch):
+  """`python bench.py --config X --gpus 2` outside a launcher: two ranks (gloo here, sharing the device), each with its
+  own batch (weak scaling), one record from rank 0 with the global batch."""
+  r, rec = _bench(["--config", config, "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-roofline"] + extra,
+                  IIC_DIST_BACKEND="gloo")
+  assert r.returncode == 0 and rec is not None, r.stdout[-1500:] + r.stderr[-3000:]
+  assert rec["n_gpus"] == 2 and rec["config"]["parallelism"] == "dp2" and rec["config"]["global_batch_pairs"] == batch
+  dp = rec["config"]["data_parallel"]
+  assert dp["world_size"] == 2 and dp["collectives_issued_by_rank0"].get("all_reduce", 0) >= 4, dp
+  assert rec["config"]["final_loss"] == rec["config"]["final_loss"]      # (not NaN)
