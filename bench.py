@@ -1085,7 +1085,12 @@ def main():
   # and does a pending collective hold either of them up?  (HIP maps streams onto 4 hardware queues in creation order;
   # RCCL's stream is one more tenant: iic_amd.graph._collective_blocks)
   stream_check = None
-  if dist_on and use_branch:
+  probe_all = use_branch
+  if dist_on:      # (the probes issue collectives: either every rank runs them or none does -- a rank whose capture failed has no pair)
+    flag = torch.tensor([1.0 if use_branch else 0.0], device=dev)
+    torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+    probe_all = bool(flag.item() > 0.5)
+  if dist_on and probe_all:
     from iic_amd import graph as igraph
     stream_check = {"pair_overlaps": igraph._streams_overlap(run.s1, run.s2),
                     "collective_blocks_stream_1": igraph._collective_blocks(run.s1),
