@@ -264,6 +264,243 @@ __global__ __launch_bounds__(256) void gemm_f32_tiled_kernel(const float* __rest
   }
 }
 
+// The same product on the bf16 matrix pipe (round 6): every fp32 operand element as three bf16 terms
+// x = h + m + l (24 mantissa bits; the subtractions are exact), a product as the six MFMAs h h', h m', m h', h l', l h',
+// m m' (v_mfma_f32_32x32x16_bf16, fp32 accumulate): what is dropped is below 2^-24 of a product, inside the rounding
+// of the exact-fp32 kernel above (tests: same 2e-5-of-scale gate against float64).  Unlike the segmentation
+// contractions (seg_loss.hip) the split is paid ONCE per element, at staging time -- a thread splits the 4
+// consecutive k values it loaded and writes three 8-byte units -- because a GEMM's fragments are always 16-byte
+// aligned in k: six bf16 MFMAs (6 x 32 cycles per 16 k) replace eight fp32 ones (8 x 64): 2.7 x less matrix time,
+// which is what the long-K head products of the VGG-style nets (ClusterNet6c k = 280: [700 x 1400] over K = 4608,
+// three of them per view and step) are made of.  Same tiling, K split and epilogue as gemm_f32_tiled_kernel.
+#ifdef IIC_DEBUG_HOOKS
+#define GX3_PITCH 80      // bytes per row of a 32-k bf16 tile in LDS (64 + 16: 16-byte aligned fragments)
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(256) void gemm_x3_tiled_kernel(const float* __restrict__ A, long sam, long sak,
+                                                             const float* __restrict__ B, long sbk, long sbn,
+                                                             const float* __restrict__ bias,
+                                                             float* __restrict__ Cm, long scm, int M, int Nn,
+                                                             int K, int accumulate, float* __restrict__ ws) {
+  constexpr int TK = 32, PL = 64 * GX3_PITCH;                 // plane bytes
+  __shared__ __attribute__((aligned(16))) unsigned char sA[2][3 * PL], sB[2][3 * PL];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int i = lane & 31, kg = lane >> 5;
+  const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+  const int ntiles = (K + TK - 1) / TK;
+  const int S = gridDim.z, z = blockIdx.z;
+  const int per = (ntiles + S - 1) / S;
+  const int t0 = z * per, t1 = min(ntiles, t0 + per);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // a thread stages two units per operand and K-tile: unit = (row, 4 consecutive k)
+  float ra[2][4], rb[2][4];
+  auto unit_of = [&](bool kc, int u, int& row, int& k) {
+    if (kc) { const int q = tid + 256 * u; row = q >> 3; k = (q & 7) * 4; }      // lanes walk k (unit stride)
+    else { row = tid & 63; k = ((tid >> 6) + 4 * u) * 4; }                       // lanes walk the rows (unit stride)
+  };
+  auto gload = [&](int t) {
+    const int k0 = t * TK;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      int row, k;
+      unit_of(AKC, u, row, k);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        ra[u][e] = (m0 + row < M && k0 + k + e < K) ? A[(long)(m0 + row) * sam + (long)(k0 + k + e) * sak] : 0.f;
+      unit_of(BKC, u, row, k);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        rb[u][e] = (n0 + row < Nn && k0 + k + e < K) ? B[(long)(k0 + k + e) * sbk + (long)(n0 + row) * sbn] : 0.f;
+    }
+  };
+  auto split4 = [&](const float (&v)[4], unsigned char* plane0, int row, int k) {
+    uint2 H, Mi, L;
+    float a = v[0], b = v[1], c = v[2], d = v[3];
+    H.x = pack_bf16x2(a, b); H.y = pack_bf16x2(c, d);
+    a -= bf16lo(H.x); b -= bf16hi(H.x); c -= bf16lo(H.y); d -= bf16hi(H.y);
+    Mi.x = pack_bf16x2(a, b); Mi.y = pack_bf16x2(c, d);
+    a -= bf16lo(Mi.x); b -= bf16hi(Mi.x); c -= bf16lo(Mi.y); d -= bf16hi(Mi.y);
+    L.x = pack_bf16x2(a, b); L.y = pack_bf16x2(c, d);
+    unsigned char* p = plane0 + row * GX3_PITCH + k * 2;
+    *reinterpret_cast<uint2*>(p) = H;
+    *reinterpret_cast<uint2*>(p + PL) = Mi;
+    *reinterpret_cast<uint2*>(p + 2 * PL) = L;
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      int row, k;
+      unit_of(AKC, u, row, k);
+      split4(ra[u], sA[buf], row, k);
+      unit_of(BKC, u, row, k);
+      split4(rb[u], sB[buf], row, k);
+    }
+  };
+  if (t0 < t1) {
+    gload(t0);
+    lstore(0);
+    if (t0 + 1 < t1) gload(t0 + 1);
+  }
+  for (int t = t0; t < t1; ++t) {
+    const int cur = (t - t0) & 1;
+    __syncthreads();               // buffer `cur` complete; everyone is done reading the other one
+    if (t + 1 < t1) lstore(cur ^ 1);
+    if (t + 2 < t1) gload(t + 2);
+    const unsigned char* pa = sA[cur] + (wm * 32 + i) * GX3_PITCH + kg * 16;
+    const unsigned char* pb = sB[cur] + (wn * 32 + i) * GX3_PITCH + kg * 16;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8 ah = *reinterpret_cast<const bf16x8*>(pa + ks * 32);
+      const bf16x8 am = *reinterpret_cast<const bf16x8*>(pa + ks * 32 + PL);
+      const bf16x8 al = *reinterpret_cast<const bf16x8*>(pa + ks * 32 + 2 * PL);
+      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(pb + ks * 32);
+      const bf16x8 bm = *reinterpret_cast<const bf16x8*>(pb + ks * 32 + PL);
+      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(pb + ks * 32 + 2 * PL);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);      // (smallest terms first)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+    }
+  }
+  const int col = n0 + wn * 32 + i;
+  if (S > 1) {
+    float* o = ws + (long)z * M * Nn;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm * 32 + mfma32_row(r, lane);
+      if (row < M && col < Nn) o[(long)row * Nn + col] = acc[r];
+    }
+    return;
+  }
+  const float bv = (bias && col < Nn) ? bias[col] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = m0 + wm * 32 + mfma32_row(r, lane);
+    if (row < M && col < Nn) {
+      float* o = Cm + (long)row * scm + col;
+      float v = acc[r] + bv;
+      if (accumulate) v += *o;
+      *o = v;
+    }
+  }
+}
+
+#endif   // IIC_DEBUG_HOOKS (gemm_x3_tiled_kernel)
+
+// 128 x 128 tile form of gemm_f32_tiled_kernel (round 6): four waves, each a 64 x 64 quadrant (2 x 2 MFMA tiles).
+// At 64 x 64 a K-tile of 32 is 16 KB of operands for 16 fp32 MFMAs per wave and every A element is re-read by
+// ceil(N / 64) column tiles; here a K-tile is 32 KB for 64 MFMAs per wave (half the operand bytes per FLOP, one LDS read
+// per MFMA instead of two).  Measured: 3-9 % at the long-K head products of ClusterNet6c k = 280 -- the 64-tile kernel's
+// 0.4 of the fp32 MFMA rate is NOT an L2 or matrix-pipe limit (the bf16-split kernel, with a third of the matrix work,
+// takes the same time): what is left is the staging path (16-32 bounds-checked scalar loads with 64-bit index
+// arithmetic per thread and K-tile, one tile of prefetch).  Launches with too few tiles still split K over gridDim.z
+// (fixed-order fold: bit-reproducible).
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(256) void gemm_f32_tiled128_kernel(const float* __restrict__ A, long sam, long sak,
+                                                                 const float* __restrict__ B, long sbk, long sbn,
+                                                                 const float* __restrict__ bias,
+                                                                 float* __restrict__ Cm, long scm, int M, int Nn,
+                                                                 int K, int accumulate, float* __restrict__ ws) {
+  constexpr int TK = 32, LD = 129;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* const sA = reinterpret_cast<float*>(smem_raw);            // [2][TK * LD]
+  float* const sB = sA + 2 * TK * LD;                              // [2][TK * LD]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int i = lane & 31, kk = lane >> 5;
+  const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
+  const int ntiles = (K + TK - 1) / TK;
+  const int S = gridDim.z, z = blockIdx.z;
+  const int per = (ntiles + S - 1) / S;
+  const int t0 = z * per, t1 = min(ntiles, t0 + per);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  float ra[16], rb[16];
+  // element u of this thread: k-contiguous operand: k = tid & 31, row = 8 u + (tid >> 5); row-contiguous: row = tid & 127,
+  // k = 2 u + (tid >> 7)
+  auto rk = [&](bool kc, int u, int& row, int& k) {
+    if (kc) { k = tid & 31; row = u * 8 + (tid >> 5); } else { row = tid & 127; k = u * 2 + (tid >> 7); }
+  };
+  auto gload = [&](int t) {
+    const int k0 = t * TK;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      int row, k;
+      rk(AKC, u, row, k);
+      ra[u] = (m0 + row < M && k0 + k < K) ? A[(long)(m0 + row) * sam + (long)(k0 + k) * sak] : 0.f;
+      rk(BKC, u, row, k);
+      rb[u] = (n0 + row < Nn && k0 + k < K) ? B[(long)(k0 + k) * sbk + (long)(n0 + row) * sbn] : 0.f;
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      int row, k;
+      rk(AKC, u, row, k);
+      sA[buf * TK * LD + k * LD + row] = ra[u];
+      rk(BKC, u, row, k);
+      sB[buf * TK * LD + k * LD + row] = rb[u];
+    }
+  };
+  if (t0 < t1) {
+    gload(t0);
+    lstore(0);
+    if (t0 + 1 < t1) gload(t0 + 1);
+  }
+  for (int t = t0; t < t1; ++t) {
+    const int cur = (t - t0) & 1;
+    __syncthreads();               // buffer `cur` complete; everyone is done reading the other one
+    if (t + 1 < t1) lstore(cur ^ 1);
+    if (t + 2 < t1) gload(t + 2);
+    const float* pa = sA + cur * TK * LD + wm * 64 + i;
+    const float* pb = sB + cur * TK * LD + wn * 64 + i;
+#pragma unroll
+    for (int k2 = 0; k2 < TK / 2; ++k2) {
+      const int kr = (2 * k2 + kk) * LD;
+      const float a0 = pa[kr], a1 = pa[kr + 32], b0 = pb[kr], b1 = pb[kr + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int col = n0 + wn * 64 + b * 32 + i;
+      if (S > 1) {
+        float* o = ws + (long)z * M * Nn;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * 64 + a * 32 + mfma32_row(r, lane);
+          if (row < M && col < Nn) o[(long)row * Nn + col] = acc[a][b][r];
+        }
+      } else {
+        const float bv = (bias && col < Nn) ? bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * 64 + a * 32 + mfma32_row(r, lane);
+          if (row < M && col < Nn) {
+            float* o = Cm + (long)row * scm + col;
+            float v = acc[a][b][r] + bv;
+            if (accumulate) v += *o;
+            *o = v;
+          }
+        }
+      }
+    }
+}
+
 __global__ __launch_bounds__(256) void gemm_f32_fold_kernel(const float* __restrict__ ws, int S,
                                                              const float* __restrict__ bias,
                                                              float* __restrict__ Cm, long scm, int M, int Nn,
@@ -280,16 +517,33 @@ __global__ __launch_bounds__(256) void gemm_f32_fold_kernel(const float* __restr
   *o = v;
 }
 
+// 1: long-K tiled products on the bf16 pipe through the three-term split (gemm_x3_tiled_kernel); 0: exact-fp32 MFMA.
+// Measured (tools/gemm_x3_ab.py, profiles/r06_gemm_ab.txt): same errors against float64 as the fp32 kernel (7e-7), and
+// 0.8-1.0 x its time -- at 64 x 64 tiles neither is bound by the matrix pipe: a K-tile is 16 KB of operands for 0.5 us of
+// fp32 MFMA work.  What did pay a little: one round of workgroups instead of 1.2 (gemm_tiled_split) and the 128 x 128 tile
+// below for the k = 280 products; the split kernel stays in the instrumented library as the record of the experiment.
+IIC_SWITCH(g_gemm_x3, 0, iic_debug_gemm_x3)
+IIC_SWITCH(g_gemm_t128, 1, iic_debug_gemm_t128)
 static bool gemm_tiled_ok(long sam, long sak, long sbk, long sbn, int M, int Nn, int K) {
   return (sak == 1 || sam == 1) && (sbk == 1 || sbn == 1) && K >= 128 && (long)M * Nn >= 64 * 64 * 8;
 }
 // K-split factor the tiled kernel wants for this product (1 = none): about 1024 blocks, at least 4 K-tiles each
+// 128 x 128 tiles (gemm_f32_tiled128_kernel) where both output dimensions are long (measured, profiles/r06_gemm_ab.txt:
+// 1.03-1.09 x at the ClusterNet6c k = 280 products, 0.64-0.82 x where one dimension is a short class count)
+static bool gemm_tiled_big(int M, int Nn, int K) {
+  return g_gemm_t128 && K >= 512 && M >= 512 && Nn >= 512;
+}
 static int gemm_tiled_split(int M, int Nn, int K) {
-  const long nt = (long)((M + 63) / 64) * ((Nn + 63) / 64);
+  const bool big = gemm_tiled_big(M, Nn, K);
+  const int T = big ? 128 : 64;
+  const long nt = (long)((M + T - 1) / T) * ((Nn + T - 1) / T);
   const int ktiles = (K + 31) / 32;
-  int s = (int)((1024 + nt - 1) / nt);
+  // as many K-split groups as fit ONE round of resident workgroups (two 128-tile workgroups per CU, four 64-tile ones).
+  // Round 6: this used to round UP -- [700 x 1400] over 4608 = 242 tiles x 5 groups = 1 210 workgroups on 1 024 slots:
+  // a second round for the last 18 %, i.e. twice the time (profiles/r06_gemm_ab.txt)
+  int s = (int)((big ? 512 : 1024) / nt);
   if (s > ktiles / 4) s = ktiles / 4;
-  if (s > 16) s = 16;
+  if (s > (big ? 8 : 16)) s = big ? 8 : 16;
   return s < 1 ? 1 : s;
 }
 
@@ -424,10 +678,39 @@ int iic_gemm_f32_ws(const float* A, long sam, long sak, const float* B, long sbk
     int S = ws ? gemm_tiled_split(M, Nn, K) : 1;
     if (S > 1 && (long)S * M * Nn > ws_floats) S = (int)(ws_floats / ((long)M * Nn));
     if (S < 1) S = 1;
-    dim3 tg((M + 63) / 64, (Nn + 63) / 64, S);
+    const bool big = gemm_tiled_big(M, Nn, K);
+    const int T = big ? 128 : 64;
+    dim3 tg((M + T - 1) / T, (Nn + T - 1) / T, S);
+    const size_t lds128 = (size_t)4 * 32 * 129 * sizeof(float);
+    if (big) {
+      static bool attr = false;
+      if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_tiled128_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_tiled128_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_tiled128_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_tiled128_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
+        attr = true;
+      }
+    }
+#ifdef IIC_DEBUG_HOOKS
+#define GT_X3(AK_, BK_)                                                                              \
+      if (g_gemm_x3 && K >= 512 && !big)                                                             \
+        hipLaunchKernelGGL((gemm_x3_tiled_kernel<AK_, BK_>), tg, dim3(256), 0, (hipStream_t)stream,  \
+                           A, sam, sak, B, sbk, sbn, bias, C, scm, M, Nn, K, accumulate, ws);        \
+      else
+#else
+#define GT_X3(AK_, BK_)
+#endif
 #define GT_LAUNCH(AK_, BK_)                                                                          \
-    hipLaunchKernelGGL((gemm_f32_tiled_kernel<AK_, BK_>), tg, dim3(256), 0, (hipStream_t)stream,     \
-                       A, sam, sak, B, sbk, sbn, bias, C, scm, M, Nn, K, accumulate, ws)
+    do {                                                                                             \
+      GT_X3(AK_, BK_)                                                                                \
+      if (big)                                                                                       \
+        hipLaunchKernelGGL((gemm_f32_tiled128_kernel<AK_, BK_>), tg, dim3(256), lds128, (hipStream_t)stream, \
+                           A, sam, sak, B, sbk, sbn, bias, C, scm, M, Nn, K, accumulate, ws);        \
+      else                                                                                           \
+        hipLaunchKernelGGL((gemm_f32_tiled_kernel<AK_, BK_>), tg, dim3(256), 0, (hipStream_t)stream, \
+                           A, sam, sak, B, sbk, sbn, bias, C, scm, M, Nn, K, accumulate, ws);        \
+    } while (0)
     if (sak == 1) { if (sbk == 1) GT_LAUNCH(true, true); else GT_LAUNCH(true, false); }
     else { if (sbk == 1) GT_LAUNCH(false, true); else GT_LAUNCH(false, false); }
     if (S > 1) {
