@@ -135,14 +135,19 @@ class Ranks(object):
     return float(t)
 
   def report(self):
-    """What the record says about the data-parallel side of the run."""
+    """What the record says about the data-parallel side of the run (collective: every rank calls it)."""
     if not self.on:
       return None
     from iic_amd import dist as idist
     from iic_amd import graph as igraph
+    # every rank must have issued the SAME sequence of collectives (the stream probes and the capture fall-back are
+    # the places where ranks could diverge): the per-rank totals, gathered
+    totals = [None] * self.world
+    torch.distributed.all_gather_object(totals, {k: int(v) for k, v in idist.CALLS.items()})
     return {"backend": "%s%s" % (self.backend, " (= RCCL)" if self.backend == "nccl" else ""), "world_size": self.world,
             "forced_at_world_size_1": self.world == 1,
             "collectives_issued_by_rank0": dict(idist.CALLS),
+            "collectives_issued_per_rank": totals,
             "stream_probes": igraph.PROBE_LOG[-24:]}
 
   def close(self):
@@ -590,6 +595,7 @@ def bench_segmentation(args):
     step(True)
   torch.cuda.synchronize()
   conv.uninstall()
+  dp_report = rk.report()          # (collective: every rank)
   if n_inst == 0:
     if rk.rank == 0:
       print(json.dumps({"metric": "paired-images/sec, %s SegmentationNet10aTwoHead + IID_segmentation_loss_uncollapsed" % args.config,
@@ -598,7 +604,7 @@ def bench_segmentation(args):
                         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                         "config": {"workload": args.config, "streams": streams_timed, "final_loss": float(last.detach()),
                                    "parallelism": "dp%d" % world, "global_batch_pairs": bn * world,
-                                   "data_parallel": rk.report()}}))
+                                   "data_parallel": dp_report}}))
     rk.close()
     return
   kA = c["k_A"]
@@ -620,7 +626,7 @@ def bench_segmentation(args):
                            "(segmentation_twohead.py train step), bf16 MFMA convs / fp32 head + loss"
                            % (args.config, sz, sz, c["in_ch"], kA, c["k_B"], bn, T, c["mask_p"]),
                "launch": "eager (python/ctypes)", "streams": streams_timed,
-               "parallelism": "dp%d" % world, "global_batch_pairs": bn * world, "data_parallel": rk.report(),
+               "parallelism": "dp%d" % world, "global_batch_pairs": bn * world, "data_parallel": dp_report,
                "final_loss": float(last.detach())},
     "roofline": {"bound": "mfma", "kernel": "seg_joint_kernel + 2x seg_grad_kernel (P = sum x1(u+t) x2(u)^T over "
                                             "(2T+1)^2 shifts and its gradient; fp32 MFMA 16x16x4)",
@@ -1102,6 +1108,7 @@ def main():
   ms_per_step = 1e3 * dt / args.steps
   value = args.pairs * world / (dt / args.steps)
 
+  dp_report = rk.report()          # (collective: every rank)
   if rank == 0:
     out = {
       "metric": "paired-images/sec, STL10 96x96 ClusterNet5g+IID_loss",
@@ -1151,7 +1158,7 @@ def main():
     if dedup is not None:
       out["config"]["replica_dedup_opt_in"] = dedup
     if dist_on:
-      out["config"]["data_parallel"] = rk.report()
+      out["config"]["data_parallel"] = dp_report
       out["config"]["data_parallel"]["streams_after_collectives"] = stream_check
     if not dist_on and not args.no_secondary and args.pairs == PAIRS_PER_GPU:
       out["secondary"] = secondary_configs()

@@ -44,6 +44,9 @@ def test_two_rank_bench_modes_agree():
   g, a, b = _run(False, True, staged=False), _run(False, False), _run(True, False)
   assert g["n_gpus"] == 2 and g["config"]["streams"] == 2 and "collectives issued eagerly" in g["config"]["launch"]
   assert a["n_gpus"] == 2 and a["config"]["streams"] == 2 and a["config"]["launch"].startswith("eager")
+  for rec in (g, a, b):        # every rank issued the same collectives, in every launch mode
+    per = rec["config"]["data_parallel"]["collectives_issued_per_rank"]
+    assert len(per) == 2 and per[0] == per[1], per
   assert b["config"]["streams"] == 1
   assert a["config"]["global_batch_pairs"] == 132
   lg, la, lb = g["config"]["final_loss"], a["config"]["final_loss"], b["config"]["final_loss"]

@@ -51,7 +51,10 @@ def test_gpus_2_without_a_launcher_starts_two_ranks():
   r, rec = _bench(["--gpus", "2"] + SMALL, IIC_DIST_BACKEND="gloo", IIC_DIST_GRAPH="force")
   assert r.returncode == 0 and rec is not None, r.stdout[-1500:] + r.stderr[-3000:]
   assert rec["n_gpus"] == 2 and rec["config"]["global_batch_pairs"] == 132 and rec["config"]["parallelism"] == "dp2"
-  assert rec["config"]["data_parallel"]["world_size"] == 2
+  dp = rec["config"]["data_parallel"]
+  assert dp["world_size"] == 2
+  # both ranks issued the same collectives (the stream probes agree on every candidate before anyone moves on)
+  assert len(dp["collectives_issued_per_rank"]) == 2 and dp["collectives_issued_per_rank"][0] == dp["collectives_issued_per_rank"][1], dp
   assert "torch.distributed.run" in r.stderr
 
 
@@ -119,4 +122,5 @@ def test_other_baseline_configs_start_two_ranks(config, extra, batch):
   assert rec["n_gpus"] == 2 and rec["config"]["parallelism"] == "dp2" and rec["config"]["global_batch_pairs"] == batch
   dp = rec["config"]["data_parallel"]
   assert dp["world_size"] == 2 and dp["collectives_issued_by_rank0"].get("all_reduce", 0) >= 4, dp
+  assert dp["collectives_issued_per_rank"][0] == dp["collectives_issued_per_rank"][1], dp
   assert rec["config"]["final_loss"] == rec["config"]["final_loss"]      # (not NaN)
