@@ -19,12 +19,14 @@
 //     one K-tile of prefetch the ~2-4 us HBM latency exceeded the ~1-2 us of MFMA work per tile
 //     and every tile waited for its data; each wave issues a FIXED number of DMA instructions per
 //     tile so that a counted s_waitcnt vmcnt(N) retires exactly tile kt.
+#include <type_traits>
 #include "common.h"
 #include "../../include/iic_hip.h"
 
 #define WD_THREADS 768
 #define WD_NTAB 8                               // table ring (>= NBUF + 2, power of two)
 #define WD_TAB_BYTES(BMK_) (WD_NTAB * (BMK_) * (4 + 2))
+#define WDP_TAB_BYTES(BMK_) (WD_NTAB * (BMK_) * (4 + 4))
 
 __device__ __forceinline__ void wd_wait_vmcnt(int n) {   // counted wait, n uniform
   switch (n) {
@@ -434,6 +436,268 @@ __global__ __launch_bounds__(PF ? 256 : WD_THREADS) void conv_wgrad_dma_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Round 6, second generation of the K loop ("planar patch").  The ISA of the kernel above spends 34 VALU
+// instructions per k-step on the ADDRESSES of its 10 transposing reads (5 per input-patch read: the row's XOR swizzle
+// is a function of row + tap offset, so nothing of it is loop-invariant) against 6 MFMAs, and VALU and MFMA share a
+// SIMD's issue port: 3 waves x (48 MFMA + ~500 VALU) issue slots per K-tile exceed the 3 x 48 x 8 slots the matrix
+// pipe needs (LAB.md R6.6).  Here the 64-channel input patch lives in LDS as TWO PLANES of 64-byte half rows
+// (channels 0-31 | 32-63): a wave (one channel half) reads rows R .. R+3 of its plane = 256 consecutive bytes = every
+// bank once, with NO swizzle, so a read's address is  plane + 64 * (row + tap offset)  -- the per-row part is
+// tabulated (pre-multiplied) once per K-tile and the three taps of a wave's tap row are IMMEDIATE offsets
+// (0, 64*TXS, 128*TXS bytes).  The dY fragments' addresses are a per-tile base + immediates.  The DMA applies the layout
+// on its source side (a 1-KB block = 16 half rows of one plane); its global addresses are a uniform base + a lane
+// constant (input) or + a tabulated row offset (dY).  Same work split, same k order, same MFMA sequence as above:
+// bit-identical partial sums.
+template <int OFF>
+__device__ __forceinline__ void wdp_tr_asm(uint32_t addr, s16x4& d) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <int OFF, bool ASMRD>
+__device__ __forceinline__ bf16x8 wdp_frag(uint32_t a0, uint32_t a1) {
+  union { bf16x8 v; s16x4 h[2]; } u;
+  if (ASMRD) {
+    wdp_tr_asm<OFF>(a0, u.h[0]);
+    wdp_tr_asm<OFF>(a1, u.h[1]);
+  } else {
+    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wd_lds_s16x4_ptr)(uintptr_t)(a0 + OFF));
+    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wd_lds_s16x4_ptr)(uintptr_t)(a1 + OFF));
+  }
+  return u.v;
+}
+
+
+template <int OFF0, int DOFF, bool ASMRD>
+__device__ __forceinline__ bf16x8 wdp_frag_pair(uint32_t a) {     // the two halves at a + OFF0, a + OFF0 + DOFF
+  union { bf16x8 v; s16x4 h[2]; } u;
+  if (ASMRD) {
+    wdp_tr_asm<OFF0>(a, u.h[0]);
+    wdp_tr_asm<OFF0 + DOFF>(a, u.h[1]);
+  } else {
+    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wd_lds_s16x4_ptr)(uintptr_t)(a + OFF0));
+    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wd_lds_s16x4_ptr)(uintptr_t)(a + OFF0 + DOFF));
+  }
+  return u.v;
+}
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void wdp_unroll(F& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    wdp_unroll<N, I + 1>(f);
+  }
+}
+
+template <int COT, int WD_BM, int NBUF, int TXS, bool ASMRD>
+__global__ __launch_bounds__(WD_THREADS) void conv_wgrad_pl_kernel(
+    const iic_conv_geom g, const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+    float* __restrict__ partials, int nsplit, int num_ktiles, int plane_bytes, int max_tap_off, int abl) {
+  constexpr int CS = COT / 64;
+  constexpr int NW = WD_THREADS / 64;           // 12 waves: 2 co halves x 2 ci halves x 3 tap rows
+  constexpr int DROW = COT * 2;
+  constexpr int DB = WD_BM * DROW;
+  constexpr int DBLK = DB / 1024;
+  constexpr int NKS = WD_BM / 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  typedef unsigned char __attribute__((address_space(3))) * lds_u8_ptr;
+  const int xb_bytes = 2 * plane_bytes;
+  unsigned char* const sX = smem_raw;                        // [NBUF][2 planes][plane_bytes]
+  unsigned char* const sD = smem_raw + NBUF * xb_bytes;      // [NBUF][DB]
+  uint32_t* const s_dyoff = reinterpret_cast<uint32_t*>(sD + NBUF * DB);   // [NTAB][BMK] byte offset of the dY row
+  int* const s_pin = reinterpret_cast<int*>(s_dyoff + WD_NTAB * WD_BM);    // [NTAB][BMK] input pixel of the row (tap 0)
+  const uint32_t sXo = (uint32_t)(uintptr_t)(lds_u8_ptr)sX, sDo = (uint32_t)(uintptr_t)(lds_u8_ptr)sD;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tg = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+  const int l31 = lane & 31;
+  const int q = lane >> 4, i16 = lane & 15;
+  const int ncit = g.Cin >> 6;
+  int tile = blockIdx.x, split = blockIdx.y;    // XCD-aware mapping as above
+  if ((gridDim.y & 7) == 0) {
+    const int L = blockIdx.y * gridDim.x + blockIdx.x;
+    const int xcd = L & 7, j = L >> 3;
+    tile = j % (int)gridDim.x;
+    split = xcd + 8 * (j / (int)gridDim.x);
+  }
+  const int cot = tile / ncit, cit = tile - cot * ncit;
+  const int co0 = cot * COT, ci0 = cit * 64;
+  const int per = (num_ktiles + nsplit - 1) / nsplit;
+  const int kt0 = split * per;
+  const int kt1 = min(num_ktiles, kt0 + per);
+  const int in_pixels = g.N * g.in_Hp * g.in_Wp;
+  const int tfirst = tg * 3;                     // this wave's tap row: taps tfirst .. tfirst + 2
+  const int toff0 = __builtin_amdgcn_readfirstlane(g.tap_off[tfirst]);
+
+  const int trow = 8 * (q >> 1) + (i16 >> 2);
+  const int tsub = (2 * (q & 1) + ((i16 & 3) >> 1)) * 16 + (i16 & 1) * 8;
+  uint32_t aoff[CS];
+#pragma unroll
+  for (int c = 0; c < CS; ++c) {
+    const int unit = (COT == 128) ? ((wm * 2 + c) ^ (trow & 3)) : (wm ^ ((trow >> 1) & 1));
+    aoff[c] = trow * DROW + unit * 64 + tsub;
+  }
+  // DMA lane constants: input block = 16 half rows x 4 pieces; dY block = 4 (8) rows x 16 (8) pieces, swizzled
+  const uint32_t lane_x = (uint32_t)(lane >> 2) * (uint32_t)(g.Cin * 2) + (lane & 3) * 16;
+  const int drow_l = (COT == 128) ? (lane >> 4) : (lane >> 3);
+  const uint32_t lane_d = (COT == 128) ? (uint32_t)(((lane & 15) ^ ((drow_l & 3) << 2)) * 16)
+                                       : (uint32_t)(((lane & 7) ^ (((drow_l >> 1) & 1) << 2)) * 16);
+
+  f32x16 acc[3][CS];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int c = 0; c < CS; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][c][r] = 0.f;
+
+  if (kt0 < kt1) {
+    const int d_y = WD_BM / g.MX, d_x = WD_BM - d_y * g.MX;
+    // Row tables: only the first WD_BM threads walk (one row each); the tile's first / last input pixel are rows 0 and
+    // WD_BM - 1 of the table itself, so nothing uniform is walked by every wave (first generation: three walkers in all
+    // 12 waves).  The table holds ABSOLUTE input pixels; the readers fold the tile's first pixel into their base.
+    WdWalk wr;
+    if (tid < WD_BM) wd_walk_init(wr, g, kt0 * WD_BM + tid);
+    const uint32_t dy_row_bytes = (uint32_t)g.Cout * 2u;
+    auto tabulate = [&](int kt) {
+      if (tid < WD_BM) {
+        int pin, pout;
+        wd_walk_pixels(wr, g, pin, pout);
+        s_dyoff[(kt & (WD_NTAB - 1)) * WD_BM + tid] = pout < 0 ? 0u : (uint32_t)pout * dy_row_bytes;   // 0 = zero border
+        s_pin[(kt & (WD_NTAB - 1)) * WD_BM + tid] = pin;
+        wd_walk_advance(wr, g, d_y, d_x, WD_BM);
+      }
+    };
+    const int NI = (2 * (plane_bytes >> 10) + DBLK + NW - 1) / NW;
+    const unsigned char* const xg = reinterpret_cast<const unsigned char*>(x) + (long)ci0 * 2;
+    const unsigned char* const dg = reinterpret_cast<const unsigned char*>(dy) + (long)co0 * 2;
+    auto dma_issue = [&](int buf, int kt) {
+      const int tab = kt & (WD_NTAB - 1);
+      const int plo = __builtin_amdgcn_readfirstlane(s_pin[tab * WD_BM]);
+      const int phi = __builtin_amdgcn_readfirstlane(s_pin[tab * WD_BM + WD_BM - 1]);
+      const int nbp = (phi + max_tap_off - plo + 1 + 15) >> 4;        // 16-row blocks per plane
+      unsigned char* const dX = sX + buf * xb_bytes;
+      unsigned char* const dD = sD + buf * DB;
+      for (int i = 0; i < NI; ++i) {
+        int b = wave + i * NW;
+        b = b < 2 * nbp + DBLK ? b : 2 * nbp + DBLK - 1;
+        if (b < 2 * nbp) {
+          const int pl = b >= nbp ? 1 : 0;
+          const int j = b - pl * nbp;
+          const int r0 = plo + j * 16;
+          const unsigned char* src;
+          uint32_t vo = lane_x;
+          if (r0 + 15 < in_pixels) {
+            src = xg + ((long)r0 * g.Cin) * 2 + pl * 64;
+          } else {                                  // the end of the tensor: rows past it re-read its last pixel
+            const int rb = r0 < in_pixels ? r0 : in_pixels - 1;
+            int p = r0 + (lane >> 2);
+            p = p < in_pixels ? p : in_pixels - 1;
+            src = xg + ((long)rb * g.Cin) * 2 + pl * 64;
+            vo = (uint32_t)(p - rb) * (uint32_t)(g.Cin * 2) + (lane & 3) * 16;
+          }
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)vo),
+                                           (__attribute__((address_space(3))) void*)(dX + pl * plane_bytes + j * 1024),
+                                           16, 0, 0);
+        } else {
+          const int bd = b - 2 * nbp;
+          const int row = bd * (COT == 128 ? 4 : 8) + drow_l;
+          const uint32_t vo = s_dyoff[tab * WD_BM + row] + lane_d;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dg + (size_t)vo),
+                                           (__attribute__((address_space(3))) void*)(dD + bd * 1024), 16, 0, 0);
+        }
+      }
+    };
+
+#pragma unroll
+    for (int i = 0; i < NBUF; ++i) tabulate(kt0 + i);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NBUF - 1; ++i)
+      if (kt0 + i < kt1) dma_issue(i, kt0 + i);
+
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const int b = (kt - kt0) % NBUF;
+      if (NBUF == 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        const int ahead = min(NBUF - 2, kt1 - 1 - kt);
+        wd_wait_vmcnt(ahead * NI);
+      }
+      __syncthreads();
+      if (kt + NBUF - 1 < kt1 && !(abl & 1)) dma_issue((b + NBUF - 1) % NBUF, kt + NBUF - 1);
+      tabulate(kt + NBUF);
+      const int* prow = s_pin + (kt & (WD_NTAB - 1)) * WD_BM;
+      // read addresses of the tile: input rows for tap (ty, 0) of this wave's plane; dY base per co sub-tile
+      const int plo = __builtin_amdgcn_readfirstlane(prow[0]);
+      const uint32_t xbase = sXo + b * xb_bytes + wn * plane_bytes + (toff0 - plo) * 64 + tsub;
+      uint32_t pb0[NKS], pb1[NKS], ab[CS];
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {         // all table reads in flight, one wait
+        pb0[ks] = (uint32_t)prow[ks * 16 + trow];
+        pb1[ks] = (uint32_t)prow[ks * 16 + trow + 4];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        pb0[ks] = xbase + (pb0[ks] << 6);
+        pb1[ks] = xbase + (pb1[ks] << 6);
+        asm volatile("" : "+v"(pb0[ks]), "+v"(pb1[ks]));      // keep base + immediate (no re-association)
+      }
+#pragma unroll
+      for (int c = 0; c < CS; ++c) {
+        ab[c] = sDo + b * DB + aoff[c];
+        asm volatile("" : "+v"(ab[c]));
+      }
+      auto step = [&](auto KS) {
+        constexpr int ks = decltype(KS)::value;
+        bf16x8 a[CS], bfr[3];
+#pragma unroll
+        for (int c = 0; c < CS; ++c) a[c] = wdp_frag_pair<ks * 16 * DROW, 4 * DROW, ASMRD>(ab[c]);
+        bfr[0] = wdp_frag<0, ASMRD>(pb0[ks], pb1[ks]);
+        bfr[1] = wdp_frag<64 * TXS, ASMRD>(pb0[ks], pb1[ks]);
+        bfr[2] = wdp_frag<128 * TXS, ASMRD>(pb0[ks], pb1[ks]);
+        if (ASMRD) {       // LDS returns in order: 4 (2) dY reads, then 2 per tap
+          if (CS == 2)
+            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a[0]), "+v"(a[1]), "+v"(bfr[0]));
+          else
+            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a[0]), "+v"(bfr[0]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < CS; ++c)
+          acc[0][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[c], bfr[0], acc[0][c], 0, 0, 0);
+        if (ASMRD) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bfr[1]));
+#pragma unroll
+        for (int c = 0; c < CS; ++c)
+          acc[1][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[c], bfr[1], acc[1][c], 0, 0, 0);
+        if (ASMRD) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bfr[2]));
+#pragma unroll
+        for (int c = 0; c < CS; ++c)
+          acc[2][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[c], bfr[2], acc[2][c], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      wdp_unroll<NKS>(step);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    float* dst = partials + (((long)split * g.ntaps + (tfirst + t)) * g.Cout + co0) * g.Cin + ci0;
+#pragma unroll
+    for (int c = 0; c < CS; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * (COT / 2) + c * 32 + mfma32_row(r, lane);
+        const int col = wn * 32 + l31;
+        dst[(long)row * g.Cin + col] = acc[t][c][r];
+      }
+  }
+}
+
+static long wdp_plane_bytes(int np) { return (((long)np * 64) + 1023) & ~1023L; }
+static long wdp_lds(int np, int cot, int bmk, int nbuf) {
+  return nbuf * (2 * wdp_plane_bytes(np) + (long)bmk * cot * 2) + WDP_TAB_BYTES(bmk) + 64;
+}
+
 static long wd_xb_bytes(int np) { return (((long)np * 128) + 1023) & ~1023L; }
 static long wd_lds(int np, int cot, int bmk, int nbuf) {
   return nbuf * (wd_xb_bytes(np) + (long)bmk * cot * 2) + WD_TAB_BYTES(bmk) + 64;
@@ -457,6 +721,9 @@ IIC_SWITCH(g_wd_prefetch, 0, iic_debug_wgrad_prefetch)
 // 215.5 -> 209.1 us, layer 3 159.1 -> 155.4), and 36.31 / 36.26 -> 36.38 / 36.34 ms per step interleaved on one box: the
 // wave-level lgkmcnt park was not what sets the step.  Default 0; instantiated in the instrumented library only.
 IIC_SWITCH(g_wd_swp, 0, iic_debug_wgrad_swp)
+// 1: the planar-patch kernel (conv_wgrad_pl_kernel) where its layout fits; 2: the same with inline-asm reads (no
+// compiler-inserted vmcnt(0) between the next tile's DMA and this tile's reads); 0: the first-generation K loop.
+IIC_SWITCH(g_wd_planar, 2, iic_debug_wgrad_planar)
 IIC_SWITCH(g_wd_enabled, 1, iic_debug_enable_wgrad_dma)     // 0: register-staged kernel, 1: DMA kernel, 3: force 64-pixel K-tiles
 
 // K-tile size / ring depth.  Measured at the ClusterNet5g shapes (tools/conv_perf.py): 128-pixel
@@ -509,6 +776,46 @@ int iic_wgrad_dma_launch(const iic_conv_geom* g, const void* x, const void* dy, 
   for (int i = 0; i < g->ntaps; ++i) mto = g->tap_off[i] > mto ? g->tap_off[i] : mto;
   dim3 grid((g->Cout / cot) * (g->Cin / 64), nsplit);
   hipStream_t s = (hipStream_t)stream;
+  // planar-patch kernel: a wave's three taps must be one tap row with a fixed x step (1, or 2 = dilation 2), dY row
+  // offsets must fit 32 bits, 64 * patch row must fit the 16-bit table
+  int txs = g->tap_off[1] - g->tap_off[0];
+  for (int ty = 0; ty < 3; ++ty)
+    for (int tx = 0; tx < 3; ++tx)
+      if (g->tap_off[3 * ty + tx] != g->tap_off[3 * ty] + tx * txs) txs = 0;
+  const long dy_bytes = (long)g->N * g->out_Hp * g->out_Wp * g->Cout * 2;
+  if (g_wd_planar && (txs == 1 || txs == 2) && dy_bytes < (1L << 32) &&
+      wdp_lds(np, cot, bmk, nbuf) <= 160 * 1024) {
+    const int plane = (int)wdp_plane_bytes(np);
+    const long ldsp = wdp_lds(np, cot, bmk, nbuf);
+#define WDP_LAUNCH3(COT_, BMK_, NBUF_, TXS_, ASM_)                                               \
+  do {                                                                                          \
+    static bool attr = false;                                                                   \
+    if (!attr) {                                                                                \
+      (void)hipFuncSetAttribute(                                                                \
+          reinterpret_cast<const void*>(&conv_wgrad_pl_kernel<COT_, BMK_, NBUF_, TXS_, ASM_>),  \
+          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                              \
+      attr = true;                                                                              \
+    }                                                                                           \
+    hipLaunchKernelGGL((conv_wgrad_pl_kernel<COT_, BMK_, NBUF_, TXS_, ASM_>), grid,             \
+                       dim3(WD_THREADS), ldsp, s, *g, (const bf16_t*)x, (const bf16_t*)dy,      \
+                       partials, nsplit, kt, plane, mto, g_wd_ablate);                          \
+  } while (0)
+#define WDP_LAUNCH2(COT_, BMK_, NBUF_, TXS_)                                                     \
+  do {                                                                                          \
+    if (g_wd_planar == 2) WDP_LAUNCH3(COT_, BMK_, NBUF_, TXS_, true);                           \
+    else WDP_LAUNCH3(COT_, BMK_, NBUF_, TXS_, false);                                           \
+  } while (0)
+#define WDP_LAUNCH(BMK_, NBUF_)                                                                  \
+  do {                                                                                          \
+    if (cot == 128) { if (txs == 1) WDP_LAUNCH2(128, BMK_, NBUF_, 1); else WDP_LAUNCH2(128, BMK_, NBUF_, 2); } \
+    else { if (txs == 1) WDP_LAUNCH2(64, BMK_, NBUF_, 1); else WDP_LAUNCH2(64, BMK_, NBUF_, 2); } \
+  } while (0)
+    if (bmk == 128) WDP_LAUNCH(128, 2);
+    else if (nbuf == 4) WDP_LAUNCH(64, 4);
+    else if (nbuf == 3) WDP_LAUNCH(64, 3);
+    else WDP_LAUNCH(64, 2);
+    return iic_launch_status();
+  }
 #define WD_LAUNCH2(COT_, BMK_, NBUF_, ASM_, PF_, SWP_)                                           \
   do {                                                                                          \
     static bool attr = false;                                                                   \

@@ -1,0 +1,71 @@
+"""Weight-gradient DMA kernel: first-generation K loop (iic_debug_wgrad_planar 0) against the planar-patch K loop (1 =
+builtin transposing reads, 2 = inline-asm reads) at the north-star layer shapes (660 images) and the 3x3 layers of the
+other configs, interleaved in one process; results must be bit-identical (same MFMAs in the same order).
+python tools/wgrad_pl_ab.py [N]"""
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("IIC_HIP_LIB", "dbg")      # the iic_debug_* switches live in libiic_hip_dbg.so only (make -C iic_amd/csrc dbg)
+import torch  # noqa: E402
+
+from iic_amd import _lib, geom, ops  # noqa: E402
+
+# name, cin, cout, H, W, images, dilation, count per view
+LAYERS = [("5g l1 64->64 @49", 64, 64, 49, 49, 0, 1, 6), ("5g l2 128->128 @25", 128, 128, 25, 25, 0, 1, 7),
+          ("5g l3 256->256 @13", 256, 256, 13, 13, 0, 1, 11), ("5g l4 512->512 @7", 512, 512, 7, 7, 0, 1, 5),
+          ("6c 64->128 @12 n700", 64, 128, 12, 12, 700, 1, 0), ("6c 128->256 @6 n700", 128, 256, 6, 6, 700, 1, 0),
+          ("10a 64->128 @100 n75", 64, 128, 100, 100, 75, 1, 0), ("10a 128->256 @100 n75", 128, 256, 100, 100, 75, 1, 0),
+          ("10a 256->256 @100 n75", 256, 256, 100, 100, 75, 1, 0), ("10a 256->512 d2 @100 n75", 256, 512, 100, 100, 75, 2, 0),
+          ("10a 512->512 d2 @100 n75", 512, 512, 100, 100, 75, 2, 0)]
+
+
+def timeit(fn, iters=20):
+  for _ in range(3):
+    fn()
+  torch.cuda.synchronize()
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  e0.record()
+  for _ in range(iters):
+    fn()
+  e1.record()
+  torch.cuda.synchronize()
+  return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def main():
+  L = ctypes.CDLL(_lib.LIB_PATH)
+  dev = torch.device("cuda", 0)
+  N0 = int(sys.argv[1]) if len(sys.argv) > 1 else 660
+  tot = {0: 0.0, 1: 0.0, 2: 0.0}
+  for name, cin, cout, H, W, n, dil, cnt in LAYERS:
+    N = n or N0
+    spec = geom.ConvSpec(cin, cout, 3, 1, dil, dil)
+    P = dil
+    gf = geom.fwd_geom(spec, N, H, W, P, P)
+    x = torch.randn(N, H + 2 * P, W + 2 * P, cin, device=dev).to(torch.bfloat16)
+    dy = torch.randn(N, H + 2 * P, W + 2 * P, cout, device=dev).to(torch.bfloat16)
+    for t_ in (x, dy):
+      t_[:, :P] = 0; t_[:, -P:] = 0; t_[:, :, :P] = 0; t_[:, :, -P:] = 0
+    flops = 2.0 * N * H * W * cout * cin * 9
+    t, out = {}, {}
+    for rep in range(2):
+      for v in (0, 1, 2):
+        L.iic_debug_wgrad_planar(v)
+        tt = timeit(lambda: ops.conv_wgrad(gf, x, dy, 9, True))
+        t[v] = min(t.get(v, 1e9), tt)
+        out[v] = ops.conv_wgrad(gf, x, dy, 9, True).clone()
+    torch.cuda.synchronize()
+    same = bool(torch.equal(out[0], out[1])) and bool(torch.equal(out[0], out[2]))
+    print("%-26s gen-1 %7.1f us %5.0f TF/s | planar %7.1f us %5.0f TF/s (%.3fx) | planar asm %7.1f us %5.0f TF/s (%.3fx)  bit-identical %s" % (
+      name, t[0], flops / t[0] / 1e6, t[1], flops / t[1] / 1e6, t[0] / t[1], t[2], flops / t[2] / 1e6, t[0] / t[2], same), flush=True)
+    for v in t:
+      tot[v] += cnt * t[v]
+  print("ClusterNet5g per view (x layer counts, incl. the reduce pass): gen-1 %.2f ms, planar %.2f ms, planar asm %.2f ms" % (
+    tot[0] / 1e3, tot[1] / 1e3, tot[2] / 1e3))
+  L.iic_debug_wgrad_planar(2)
+
+
+if __name__ == "__main__":
+  main()
