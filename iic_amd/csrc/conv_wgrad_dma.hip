@@ -617,13 +617,15 @@ __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_pl_kernel(
 
     for (int kt = kt0; kt < kt1; ++kt) {
       const int b = (kt - kt0) % NBUF;
-      if (NBUF == 2) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      } else {
-        const int ahead = min(NBUF - 2, kt1 - 1 - kt);
-        wd_wait_vmcnt(ahead * NI);
+      if (!(abl & 4)) {          // abl 4 (timing only, racy): no wait, no barrier
+        if (NBUF == 2) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+          const int ahead = min(NBUF - 2, kt1 - 1 - kt);
+          wd_wait_vmcnt(ahead * NI);
+        }
+        __syncthreads();
       }
-      __syncthreads();
       if (kt + NBUF - 1 < kt1 && !(abl & 1)) dma_issue((b + NBUF - 1) % NBUF, kt + NBUF - 1);
       tabulate(kt + NBUF);
       const int* prow = s_pin + (kt & (WD_NTAB - 1)) * WD_BM;
@@ -676,7 +678,309 @@ __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_pl_kernel(
           acc[2][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[c], bfr[2], acc[2][c], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       };
-      wdp_unroll<NKS>(step);
+      if (!(abl & 2)) wdp_unroll<NKS>(step);      // abl 2 (timing only): DMA + bookkeeping without the k-steps
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    float* dst = partials + (((long)split * g.ntaps + (tfirst + t)) * g.Cout + co0) * g.Cin + ci0;
+#pragma unroll
+    for (int c = 0; c < CS; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * (COT / 2) + c * 32 + mfma32_row(r, lane);
+        const int col = wn * 32 + l31;
+        dst[(long)row * g.Cin + col] = acc[t][c][r];
+      }
+  }
+}
+
+// Third form of the loop (iic_debug_wgrad_planar = 3, the default): the planar-patch kernel above with the per-tile work
+// taken off the critical path between the tile barrier and the first MFMA (LAB.md R6.6: of a 144-us launch at layer 3,
+// 61 us are MFMA time, 26 us the k-steps' own inefficiency, 27 us DMA / compute overlap loss, 30 us fixed):
+//   * the read addresses of tile kt + 1 are formed at the END of tile kt (their table reads are issued behind the last
+//     k-step's fragment reads and land under its MFMAs), so the first fragment reads issue right after the barrier;
+//   * the next tile's DMA is issued behind those first reads (its scalar address work runs under their LDS latency);
+//   * SWP: the fragment reads of k-step ks + 1 are issued before the MFMAs of k-step ks (two register sets);
+//   * row tables by an incremental walker (adds and selects; the first two forms recompute four products per row).
+// All transposing reads are inline asm with hand-counted lgkmcnt waits (LDS operations complete in order, so a wait for
+// "at most N outstanding" retires everything but the N youngest whatever else the compiler has in flight).
+struct WdpRow {
+  int n, y, x, pin;
+  uint32_t dyo;
+};
+
+template <int OFF0, int OFF1>
+__device__ __forceinline__ void wdp_tab_read(uint32_t addr, u32x2& d) {      // two table words (dword offsets)
+  asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(d) : "v"(addr), "n"(OFF0), "n"(OFF1));
+}
+template <int N>
+__device__ __forceinline__ void wdp_lgkm_wait() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int COT, int WD_BM, int NBUF, int TXS, bool SWP>
+__global__ __launch_bounds__(WD_THREADS) void conv_wgrad_pl2_kernel(
+    const iic_conv_geom g, const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+    float* __restrict__ partials, int nsplit, int num_ktiles, int plane_bytes, int max_tap_off, int abl) {
+  constexpr int CS = COT / 64;
+  constexpr int NW = WD_THREADS / 64;
+  constexpr int DROW = COT * 2;
+  constexpr int DB = WD_BM * DROW;
+  constexpr int DBLK = DB / 1024;
+  constexpr int NKS = WD_BM / 16;
+  constexpr int NRD = 2 * CS + 6;               // transposing reads per k-step
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  typedef unsigned char __attribute__((address_space(3))) * lds_u8_ptr;
+  const int xb_bytes = 2 * plane_bytes;
+  unsigned char* const sX = smem_raw;
+  unsigned char* const sD = smem_raw + NBUF * xb_bytes;
+  uint32_t* const s_dyoff = reinterpret_cast<uint32_t*>(sD + NBUF * DB);
+  int* const s_pin = reinterpret_cast<int*>(s_dyoff + WD_NTAB * WD_BM);
+  const uint32_t sXo = (uint32_t)(uintptr_t)(lds_u8_ptr)sX, sDo = (uint32_t)(uintptr_t)(lds_u8_ptr)sD;
+  const uint32_t sPo = (uint32_t)(uintptr_t)(lds_u8_ptr)reinterpret_cast<unsigned char*>(s_pin);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tg = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+  const int l31 = lane & 31;
+  const int q = lane >> 4, i16 = lane & 15;
+  const int ncit = g.Cin >> 6;
+  int tile = blockIdx.x, split = blockIdx.y;
+  if ((gridDim.y & 7) == 0) {
+    const int L = blockIdx.y * gridDim.x + blockIdx.x;
+    const int xcd = L & 7, j = L >> 3;
+    tile = j % (int)gridDim.x;
+    split = xcd + 8 * (j / (int)gridDim.x);
+  }
+  const int cot = tile / ncit, cit = tile - cot * ncit;
+  const int co0 = cot * COT, ci0 = cit * 64;
+  const int per = (num_ktiles + nsplit - 1) / nsplit;
+  const int kt0 = split * per;
+  const int kt1 = min(num_ktiles, kt0 + per);
+  const int in_pixels = g.N * g.in_Hp * g.in_Wp;
+  const int tfirst = tg * 3;
+  const int toff0 = __builtin_amdgcn_readfirstlane(g.tap_off[tfirst]);
+
+  const int trow = 8 * (q >> 1) + (i16 >> 2);
+  const int tsub = (2 * (q & 1) + ((i16 & 3) >> 1)) * 16 + (i16 & 1) * 8;
+  uint32_t aoff[CS];
+#pragma unroll
+  for (int c = 0; c < CS; ++c) {
+    const int unit = (COT == 128) ? ((wm * 2 + c) ^ (trow & 3)) : (wm ^ ((trow >> 1) & 1));
+    aoff[c] = trow * DROW + unit * 64 + tsub;
+  }
+  const uint32_t lane_x = (uint32_t)(lane >> 2) * (uint32_t)(g.Cin * 2) + (lane & 3) * 16;
+  const int drow_l = (COT == 128) ? (lane >> 4) : (lane >> 3);
+  const uint32_t lane_d = (COT == 128) ? (uint32_t)(((lane & 15) ^ ((drow_l & 3) << 2)) * 16)
+                                       : (uint32_t)(((lane & 7) ^ (((drow_l >> 1) & 1) << 2)) * 16);
+
+  f32x16 acc[3][CS];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int c = 0; c < CS; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][c][r] = 0.f;
+
+  if (kt0 < kt1) {
+    const bool padded = wd_padded(g);
+    const uint32_t dyrb = (uint32_t)g.Cout * 2u;
+    // incremental walker constants (dense numbering): one K-tile further = d_y image rows + d_x pixels
+    const int d_y = WD_BM / g.MX, d_x = WD_BM - d_y * g.MX;
+    const int pin_step = d_y * g.sy * g.in_Wp + d_x * g.sx, pin_xw = g.sy * g.in_Wp - g.MX * g.sx,
+              pin_yw = (g.in_Hp - g.MY * g.sy) * g.in_Wp;
+    const uint32_t dyo_step = (uint32_t)(d_y * g.ty * g.out_Wp + d_x * g.tx) * dyrb,
+                   dyo_xw = (uint32_t)(g.ty * g.out_Wp - g.MX * g.tx) * dyrb,
+                   dyo_yw = (uint32_t)((g.out_Hp - g.MY * g.ty) * g.out_Wp) * dyrb;
+    const int pin_last = ((g.N - 1) * g.in_Hp + (g.MY - 1) * g.sy + g.oy) * g.in_Wp + (g.MX - 1) * g.sx + g.ox;
+    WdpRow wr = {0, 0, 0, 0, 0u};
+    if (tid < WD_BM) {
+      WdWalk w;
+      wd_walk_init(w, g, kt0 * WD_BM + tid);
+      wr.n = w.n; wr.y = w.y; wr.x = w.x;
+      if (!padded) {
+        wr.pin = (w.n * g.in_Hp + w.y * g.sy + g.oy) * g.in_Wp + w.x * g.sx + g.ox;
+        wr.dyo = (uint32_t)((w.n * g.out_Hp + w.y * g.ty + g.py) * g.out_Wp + w.x * g.tx + g.px) * dyrb;
+      }
+    }
+    auto tabulate = [&](int kt) {
+      if (tid < WD_BM) {
+        int pin;
+        uint32_t dyo;
+        if (padded) {                      // (large images: one division per row and tile)
+          WdWalk w = {wr.n, wr.y, 0};
+          int pout;
+          wd_walk_pixels(w, g, pin, pout);
+          dyo = pout < 0 ? 0u : (uint32_t)pout * dyrb;
+          wd_walk_advance(w, g, 0, 0, WD_BM);
+          wr.n = w.n; wr.y = w.y;
+        } else {
+          const bool valid = wr.n < g.N;
+          pin = valid ? wr.pin : pin_last;
+          dyo = valid ? wr.dyo : 0u;       // 0 = pixel 0 of the PT tensor: zero border
+          wr.x += d_x; wr.y += d_y; wr.pin += pin_step; wr.dyo += dyo_step;
+          if (wr.x >= g.MX) { wr.x -= g.MX; ++wr.y; wr.pin += pin_xw; wr.dyo += dyo_xw; }
+          while (wr.y >= g.MY) { wr.y -= g.MY; ++wr.n; wr.pin += pin_yw; wr.dyo += dyo_yw; }
+        }
+        s_dyoff[(kt & (WD_NTAB - 1)) * WD_BM + tid] = dyo;
+        s_pin[(kt & (WD_NTAB - 1)) * WD_BM + tid] = pin;
+      }
+    };
+    const int NI = (2 * (plane_bytes >> 10) + DBLK + NW - 1) / NW;
+    const unsigned char* const xg = reinterpret_cast<const unsigned char*>(x) + (long)ci0 * 2;
+    const unsigned char* const dg = reinterpret_cast<const unsigned char*>(dy) + (long)co0 * 2;
+    auto dma_issue = [&](int buf, int kt) {
+      const int tab = kt & (WD_NTAB - 1);
+      const int plo = __builtin_amdgcn_readfirstlane(s_pin[tab * WD_BM]);
+      const int phi = __builtin_amdgcn_readfirstlane(s_pin[tab * WD_BM + WD_BM - 1]);
+      const int nbp = (phi + max_tap_off - plo + 1 + 15) >> 4;
+      unsigned char* const dX = sX + buf * xb_bytes;
+      unsigned char* const dD = sD + buf * DB;
+      for (int i = 0; i < NI; ++i) {
+        int b = wave + i * NW;
+        b = b < 2 * nbp + DBLK ? b : 2 * nbp + DBLK - 1;
+        if (b < 2 * nbp) {
+          const int pl = b >= nbp ? 1 : 0;
+          const int j = b - pl * nbp;
+          const int r0 = plo + j * 16;
+          const unsigned char* src;
+          uint32_t vo = lane_x;
+          if (r0 + 15 < in_pixels) {
+            src = xg + ((long)r0 * g.Cin) * 2 + pl * 64;
+          } else {
+            const int rb = r0 < in_pixels ? r0 : in_pixels - 1;
+            int p = r0 + (lane >> 2);
+            p = p < in_pixels ? p : in_pixels - 1;
+            src = xg + ((long)rb * g.Cin) * 2 + pl * 64;
+            vo = (uint32_t)(p - rb) * (uint32_t)(g.Cin * 2) + (lane & 3) * 16;
+          }
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)vo),
+                                           (__attribute__((address_space(3))) void*)(dX + pl * plane_bytes + j * 1024),
+                                           16, 0, 0);
+        } else {
+          const int bd = b - 2 * nbp;
+          const int row = bd * (COT == 128 ? 4 : 8) + drow_l;
+          const uint32_t vo = s_dyoff[tab * WD_BM + row] + lane_d;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dg + (size_t)vo),
+                                           (__attribute__((address_space(3))) void*)(dD + bd * 1024), 16, 0, 0);
+        }
+      }
+    };
+
+#pragma unroll
+    for (int i = 0; i < NBUF; ++i) tabulate(kt0 + i);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NBUF - 1; ++i)
+      if (kt0 + i < kt1) dma_issue(i, kt0 + i);
+
+    // read addresses of a tile: pb[ks] = (row trow, row trow + 4) of k-step ks in this wave's plane, tap (ty, 0)
+    u32x2 pb[NKS];
+    uint32_t ab[CS];
+    const uint32_t tab_lane = sPo + trow * 4;
+    auto prep_issue = [&](int kt) {                 // NKS table reads (inline asm: counted by the callers' waits)
+      const uint32_t ta = tab_lane + (kt & (WD_NTAB - 1)) * (WD_BM * 4);
+      auto rd = [&](auto KS) {
+        constexpr int ks = decltype(KS)::value;
+        wdp_tab_read<ks * 16, ks * 16 + 4>(ta, pb[ks]);
+      };
+      wdp_unroll<NKS>(rd);
+    };
+    auto prep_finish = [&](int kt, int buf) {       // waits for the table reads, then forms the addresses
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pb[0]));
+#pragma unroll
+      for (int ks = 1; ks < NKS; ++ks) asm volatile("" : "+v"(pb[ks]));
+      const int plo = __builtin_amdgcn_readfirstlane(s_pin[(kt & (WD_NTAB - 1)) * WD_BM]);
+      const uint32_t xbase = sXo + buf * xb_bytes + wn * plane_bytes + (toff0 - plo) * 64 + tsub;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        pb[ks][0] = xbase + (pb[ks][0] << 6);
+        pb[ks][1] = xbase + (pb[ks][1] << 6);
+        asm volatile("" : "+v"(pb[ks]));
+      }
+#pragma unroll
+      for (int c = 0; c < CS; ++c) {
+        ab[c] = sDo + buf * DB + aoff[c];
+        asm volatile("" : "+v"(ab[c]));
+      }
+    };
+    bf16x8 fa[SWP ? 2 : 1][CS], fb[SWP ? 2 : 1][3];
+    auto reads = [&](auto KS) {                     // the NRD transposing reads of k-step ks, dY first, then tap by tap
+      constexpr int ks = decltype(KS)::value;
+      constexpr int s = SWP ? (ks & 1) : 0;
+#pragma unroll
+      for (int c = 0; c < CS; ++c) fa[s][c] = wdp_frag_pair<ks * 16 * DROW, 4 * DROW, true>(ab[c]);
+      fb[s][0] = wdp_frag<0, true>(pb[ks][0], pb[ks][1]);
+      fb[s][1] = wdp_frag<64 * TXS, true>(pb[ks][0], pb[ks][1]);
+      fb[s][2] = wdp_frag<128 * TXS, true>(pb[ks][0], pb[ks][1]);
+    };
+    auto mfmas = [&](auto KS, auto YOUNGER) {       // YOUNGER: LDS operations issued after this k-step's reads
+      constexpr int ks = decltype(KS)::value;
+      constexpr int s = SWP ? (ks & 1) : 0;
+      constexpr int Y = decltype(YOUNGER)::value;
+      constexpr int W0 = Y + 4 > 15 ? 15 : Y + 4, W1 = Y + 2 > 15 ? 15 : Y + 2, W2 = Y > 15 ? 15 : Y;
+      if (CS == 2) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(fa[s][0]), "+v"(fa[s][1]), "+v"(fb[s][0]) : "n"(W0));
+      else asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fa[s][0]), "+v"(fb[s][0]) : "n"(W0));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < CS; ++c)
+        acc[0][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][c], fb[s][0], acc[0][c], 0, 0, 0);
+      asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fb[s][1]) : "n"(W1));
+#pragma unroll
+      for (int c = 0; c < CS; ++c)
+        acc[1][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][c], fb[s][1], acc[1][c], 0, 0, 0);
+      asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fb[s][2]) : "n"(W2));
+#pragma unroll
+      for (int c = 0; c < CS; ++c)
+        acc[2][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][c], fb[s][2], acc[2][c], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+
+    prep_issue(kt0);
+    prep_finish(kt0, 0);
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const int b = (kt - kt0) % NBUF;
+      if (!(abl & 4)) {
+        if (NBUF == 2) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+          const int ahead = min(NBUF - 2, kt1 - 1 - kt);
+          wd_wait_vmcnt(ahead * NI);
+        }
+        __syncthreads();
+      }
+      if (!(abl & 2)) reads(std::integral_constant<int, 0>{});
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + NBUF - 1 < kt1 && !(abl & 1)) dma_issue((b + NBUF - 1) % NBUF, kt + NBUF - 1);
+      tabulate(kt + NBUF);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(abl & 2)) {
+        auto step = [&](auto KS) {
+          constexpr int ks = decltype(KS)::value;
+          if constexpr (SWP) {
+            if constexpr (ks + 1 < NKS) {
+              reads(std::integral_constant<int, ks + 1>{});
+              mfmas(KS, std::integral_constant<int, NRD>{});
+            } else {
+              prep_issue(kt + 1);
+              mfmas(KS, std::integral_constant<int, NKS>{});
+            }
+          } else {
+            if constexpr (ks > 0) reads(KS);
+            if constexpr (ks + 1 < NKS) {
+              mfmas(KS, std::integral_constant<int, 0>{});
+            } else {
+              prep_issue(kt + 1);
+              mfmas(KS, std::integral_constant<int, NKS>{});
+            }
+          }
+        };
+        wdp_unroll<NKS>(step);
+      } else {
+        prep_issue(kt + 1);
+      }
+      prep_finish(kt + 1, (b + 1) % NBUF);
     }
   }
 #pragma unroll
@@ -713,7 +1017,8 @@ IIC_SWITCH(g_wd_asm, 0, iic_debug_wgrad_asm)
 // Measured (tools/wgrad_ab.sh, per launch incl. the reduce pass): layer2-4 within 2 % of the 12-wave
 // kernel, layer1 28 % slower -- 27 % less LDS-read traffic buys nothing, i.e. the kernel is not
 // LDS-read-bound as round 1 assumed.  Default 0 (12 waves).
-// timing ablation (WRONG results): 1 = no DMA after the prologue (compute-only time of the K loop)
+// timing ablation (WRONG results): 1 = no DMA after the prologue (compute-only time of the K loop); planar kernel also
+// 2 = no k-steps (DMA + bookkeeping only), 4 = no per-tile wait / barrier
 IIC_SWITCH(g_wd_ablate, 0, iic_debug_wgrad_ablate)
 IIC_SWITCH(g_wd_prefetch, 0, iic_debug_wgrad_prefetch)
 // 1: 12-wave kernel with the next k-step's fragments read under the current k-step's MFMAs (template SWP).  Measured
@@ -721,9 +1026,12 @@ IIC_SWITCH(g_wd_prefetch, 0, iic_debug_wgrad_prefetch)
 // 215.5 -> 209.1 us, layer 3 159.1 -> 155.4), and 36.31 / 36.26 -> 36.38 / 36.34 ms per step interleaved on one box: the
 // wave-level lgkmcnt park was not what sets the step.  Default 0; instantiated in the instrumented library only.
 IIC_SWITCH(g_wd_swp, 0, iic_debug_wgrad_swp)
-// 1: the planar-patch kernel (conv_wgrad_pl_kernel) where its layout fits; 2: the same with inline-asm reads (no
-// compiler-inserted vmcnt(0) between the next tile's DMA and this tile's reads); 0: the first-generation K loop.
-IIC_SWITCH(g_wd_planar, 2, iic_debug_wgrad_planar)
+// K-loop form where the planar layout fits: 0 = first generation; 1 = planar patch, builtin transposing reads; 2 = planar,
+// inline-asm reads (no compiler-inserted vmcnt(0) between the next tile's DMA and this tile's reads); 3 = pipelined form
+// (conv_wgrad_pl2_kernel); 4 = pipelined + software-pipelined k-steps; 5 (default) = 4 for 64-cout tiles (115 registers: no
+// spills; layer 1: 172 -> 164 us), 2 for 128-cout tiles (form 4 spills there and measured 6 % slower, form 3 equal to form 2:
+// tools/wgrad_pl_ab.py, profiles/r06_wgrad_planar_ab.txt).
+IIC_SWITCH(g_wd_planar, 5, iic_debug_wgrad_planar)
 IIC_SWITCH(g_wd_enabled, 1, iic_debug_enable_wgrad_dma)     // 0: register-staged kernel, 1: DMA kernel, 3: force 64-pixel K-tiles
 
 // K-tile size / ring depth.  Measured at the ClusterNet5g shapes (tools/conv_perf.py): 128-pixel
@@ -800,11 +1108,34 @@ int iic_wgrad_dma_launch(const iic_conv_geom* g, const void* x, const void* dy, 
                        dim3(WD_THREADS), ldsp, s, *g, (const bf16_t*)x, (const bf16_t*)dy,      \
                        partials, nsplit, kt, plane, mto, g_wd_ablate);                          \
   } while (0)
+#define WDP2_LAUNCH3(COT_, BMK_, NBUF_, TXS_, SWP_)                                              \
+  do {                                                                                          \
+    static bool attr = false;                                                                   \
+    if (!attr) {                                                                                \
+      (void)hipFuncSetAttribute(                                                                \
+          reinterpret_cast<const void*>(&conv_wgrad_pl2_kernel<COT_, BMK_, NBUF_, TXS_, SWP_>), \
+          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                              \
+      attr = true;                                                                              \
+    }                                                                                           \
+    hipLaunchKernelGGL((conv_wgrad_pl2_kernel<COT_, BMK_, NBUF_, TXS_, SWP_>), grid,            \
+                       dim3(WD_THREADS), ldsp, s, *g, (const bf16_t*)x, (const bf16_t*)dy,      \
+                       partials, nsplit, kt, plane, mto, g_wd_ablate);                          \
+  } while (0)
+#ifdef IIC_DEBUG_HOOKS
 #define WDP_LAUNCH2(COT_, BMK_, NBUF_, TXS_)                                                     \
   do {                                                                                          \
-    if (g_wd_planar == 2) WDP_LAUNCH3(COT_, BMK_, NBUF_, TXS_, true);                           \
-    else WDP_LAUNCH3(COT_, BMK_, NBUF_, TXS_, false);                                           \
+    if (g_wd_planar == 4 || (g_wd_planar == 5 && COT_ == 64)) WDP2_LAUNCH3(COT_, BMK_, NBUF_, TXS_, true); \
+    else if (g_wd_planar == 3) WDP2_LAUNCH3(COT_, BMK_, NBUF_, TXS_, false);                    \
+    else if (g_wd_planar == 1) WDP_LAUNCH3(COT_, BMK_, NBUF_, TXS_, false);                     \
+    else WDP_LAUNCH3(COT_, BMK_, NBUF_, TXS_, true);                                            \
   } while (0)
+#else      /* the product library instantiates the default forms only */
+#define WDP_LAUNCH2(COT_, BMK_, NBUF_, TXS_)                                                     \
+  do {                                                                                          \
+    if (COT_ == 64) WDP2_LAUNCH3(64, BMK_, NBUF_, TXS_, true);                                  \
+    else WDP_LAUNCH3(128, BMK_, NBUF_, TXS_, true);                                             \
+  } while (0)
+#endif
 #define WDP_LAUNCH(BMK_, NBUF_)                                                                  \
   do {                                                                                          \
     if (cot == 128) { if (txs == 1) WDP_LAUNCH2(128, BMK_, NBUF_, 1); else WDP_LAUNCH2(128, BMK_, NBUF_, 2); } \

@@ -38,8 +38,12 @@ def main():
   L = ctypes.CDLL(_lib.LIB_PATH)
   dev = torch.device("cuda", 0)
   N0 = int(sys.argv[1]) if len(sys.argv) > 1 else 660
-  tot = {0: 0.0, 1: 0.0, 2: 0.0}
+  tot = {}
+  only = os.environ.get("WGRAD_ONLY", "")
+  variants = tuple(int(v) for v in os.environ.get("WGRAD_VARIANTS", "0,2,3,4,5").split(","))
   for name, cin, cout, H, W, n, dil, cnt in LAYERS:
+    if only and only not in name:
+      continue
     N = n or N0
     spec = geom.ConvSpec(cin, cout, 3, 1, dil, dil)
     P = dil
@@ -51,20 +55,29 @@ def main():
     flops = 2.0 * N * H * W * cout * cin * 9
     t, out = {}, {}
     for rep in range(2):
-      for v in (0, 1, 2):
+      for v in variants:
         L.iic_debug_wgrad_planar(v)
         tt = timeit(lambda: ops.conv_wgrad(gf, x, dy, 9, True))
         t[v] = min(t.get(v, 1e9), tt)
         out[v] = ops.conv_wgrad(gf, x, dy, 9, True).clone()
     torch.cuda.synchronize()
-    same = bool(torch.equal(out[0], out[1])) and bool(torch.equal(out[0], out[2]))
-    print("%-26s gen-1 %7.1f us %5.0f TF/s | planar %7.1f us %5.0f TF/s (%.3fx) | planar asm %7.1f us %5.0f TF/s (%.3fx)  bit-identical %s" % (
-      name, t[0], flops / t[0] / 1e6, t[1], flops / t[1] / 1e6, t[0] / t[1], t[2], flops / t[2] / 1e6, t[0] / t[2], same), flush=True)
+    same = all(bool(torch.equal(out[variants[0]], out[v])) for v in variants)
+    names = {0: "gen-1", 1: "planar", 2: "planar asm", 3: "pipelined", 4: "pipelined swp", 5: "default"}
+    v0 = variants[0]
+    print("%-26s " % name + " | ".join("%s %7.1f us %5.0f TF/s (%.3fx)" % (names[v], t[v], flops / t[v] / 1e6, t[v0] / t[v])
+                                        for v in variants) + "  bit-identical %s" % same, flush=True)
     for v in t:
-      tot[v] += cnt * t[v]
-  print("ClusterNet5g per view (x layer counts, incl. the reduce pass): gen-1 %.2f ms, planar %.2f ms, planar asm %.2f ms" % (
-    tot[0] / 1e3, tot[1] / 1e3, tot[2] / 1e3))
-  L.iic_debug_wgrad_planar(2)
+      tot[v] = tot.get(v, 0.0) + cnt * t[v]
+    if os.environ.get("WGRAD_ABL"):      # timing ablations of the planar kernel (results wrong by design)
+      L.iic_debug_wgrad_planar(int(os.environ.get("WGRAD_ABL_VARIANT", "5")))
+      row = []
+      for code in [int(c) for c in os.environ["WGRAD_ABL"].split(",")]:
+        L.iic_debug_wgrad_ablate(code)
+        row.append("abl%d %.1f" % (code, timeit(lambda: ops.conv_wgrad(gf, x, dy, 9, True))))
+      L.iic_debug_wgrad_ablate(0)
+      print("    planar asm, ablations (us incl. reduce): " + ", ".join(row), flush=True)
+  print("ClusterNet5g per view (x layer counts, incl. the reduce pass): " + ", ".join("variant %d %.2f ms" % (v, tot[v] / 1e3) for v in sorted(tot)))
+  L.iic_debug_wgrad_planar(5)
 
 
 if __name__ == "__main__":
