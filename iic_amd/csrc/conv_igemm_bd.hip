@@ -79,6 +79,10 @@ __device__ __forceinline__ void bd_tile(
   constexpr int CLD = BNT + 8;
   constexpr bool PROF = (ABL & 128) != 0;
   constexpr bool NEWORD = (ABL & 256) == 0;     // ABL bit 256: the round-2 K-loop order (A/B runs)
+  // ABL bit 512 (timing only, WRONG results): A-fragment addresses as for a 144-byte row pitch -- one add per tap and
+  // sub-tile, immediate k-step offsets -- while the DMA still writes the swizzled 128-byte rows: what the K loop would
+  // cost without its ~70 VALU of swizzle arithmetic per tap (LAB.md R6.7)
+  constexpr bool SWZ = DMA && (ABL & 512) == 0;
   // PROF (ABL bit 128, results CORRECT): wave 0 stamps s_memtime at the phase boundaries of its tile
   // into prof[blockIdx][BD_PROF_SLOTS] (tools/bd_timeline.py decodes them)
   unsigned long long t_stamp[8];
@@ -140,8 +144,8 @@ __device__ __forceinline__ void bd_tile(
   for (int ms = 0; ms < MS; ++ms) {
     const int row = wm * WR + ms * 32 + l31;
     const int pr = GATHER ? row : (s_pin[row] - p_lo);
-    arow[ms] = DMA ? pr : pr * ROWB + g5 * 16;
-    drow[ms] = (DMA && !GATHER) ? dense_of(s_pin[row]) : pr;
+    arow[ms] = SWZ ? pr : pr * ROWB + g5 * 16;
+    drow[ms] = (SWZ && !GATHER) ? dense_of(s_pin[row]) : pr;
   }
   if (DMA && !GATHER && jskip != 0) {     // (without a skip the key is a function of r alone: no table)
     for (int r = tid; r < npix; r += BD_THREADS) s_key[r] = (unsigned char)((dense_of(p_lo + r) >> 1) & 7);
@@ -226,7 +230,7 @@ __device__ __forceinline__ void bd_tile(
 #pragma unroll
   for (int ms = 0; ms < MS; ++ms) {
     const int t0 = GATHER ? 0 : __builtin_amdgcn_readlane(v_tapoff, 0);
-    if (DMA) {
+    if (SWZ) {
       const int R = arow[ms] + t0;
       const int D = drow[ms] + (GATHER ? 0 : __builtin_amdgcn_readlane(v_tapd, 0));
       pcur[ms] = a_base(R, D);
@@ -249,7 +253,7 @@ __device__ __forceinline__ void bd_tile(
     int pnext[MS], knext[MS];
 #pragma unroll
     for (int ms = 0; ms < MS; ++ms) {
-      if (DMA) {
+      if (SWZ) {
         const int R = arow[ms] + toffn;
         const int D = drow[ms] + tdn;
         pnext[ms] = a_base(R, D);
@@ -261,7 +265,7 @@ __device__ __forceinline__ void bd_tile(
     }
     auto a_read = [&](int ks, int nxt, int cur, int ms) {
       if (!(ABL & 16)) {
-        if (DMA)
+        if (SWZ)
           a[nxt][ms] = (ks < 3) ? *reinterpret_cast<const bf16x8*>(sA + pcur[ms] + (((ks + 1) << 5) ^ kcur[ms]))
                                 : *reinterpret_cast<const bf16x8*>(sA + pnext[ms] + knext[ms]);
         else
@@ -333,7 +337,7 @@ __device__ __forceinline__ void bd_tile(
       if (PROF) { t_bsum += __builtin_readcyclecounter() - t_b0; ++t_nb; }
 #pragma unroll
       for (int ms = 0; ms < MS; ++ms)
-        a[0][ms] = *reinterpret_cast<const bf16x8*>(sA + pcur[ms] + (DMA ? kcur[ms] : 0));
+        a[0][ms] = *reinterpret_cast<const bf16x8*>(sA + pcur[ms] + (SWZ ? kcur[ms] : 0));
     }
     tap = tn;
     chunk = cn;
@@ -736,6 +740,7 @@ int iic_conv_igemm_frag_red(const iic_conv_geom* g, const void* in, const void* 
     case 96: BD_LAUNCH(false, 96); break;
     case 128: BD_LAUNCH(false, 128); break;
     case 256: BD_LAUNCH(false, 256); break;
+    case 512: BD_LAUNCH(false, 512); break;
 #endif
     default: BD_LAUNCH(false, 0); break;
   }

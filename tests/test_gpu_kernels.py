@@ -526,6 +526,70 @@ def test_conv_backward_weight_padded_row_numbering(cin, cout, H, dil, dma):
   assert (got - ref).abs().max().item() <= 2e-3 * scale, (got - ref).abs().max().item() / scale
 
 
+@HOOKS
+@pytest.mark.parametrize("cin,cout,H,dil,N,nsplit,dma", [
+    (64, 64, 49, 1, 3, 2, 1),        # 64-cout tiles: pipelined + software-pipelined form by default
+    (128, 128, 25, 1, 20, 3, 1),     # 128-cout tiles: planar asm form by default
+    (256, 256, 13, 1, 10, 1, 1),     # one split: a workgroup walks every K-tile (images straddle tiles)
+    (512, 512, 7, 1, 6, 2, 1),
+    (128, 128, 20, 2, 4, 1, 1),      # dilation 2: a wave's taps are 2 pixels apart (template TXS = 2)
+    (64, 128, 12, 1, 9, 1, 1),       # ClusterNet6c 12 x 12: short image rows, many row / image wraps per tile
+    (64, 64, 200, 1, 2, 2, 3),       # 64-pixel ring, padded row numbering, 64-cout tiles
+    (64, 128, 200, 1, 2, 2, 3)])     # 64-pixel ring, padded row numbering, 128-cout tiles
+def test_weight_gradient_k_loop_forms_are_bit_identical(cin, cout, H, dil, N, nsplit, dma):
+  """conv_wgrad_dma.hip holds five forms of the K loop behind iic_debug_wgrad_planar (0 = first generation, 1 / 2 =
+  planar patch with builtin / inline-asm reads, 3 / 4 = pipelined, 5 = the default choice): same work split, same k
+  order, same MFMA sequence => the same bits; and the result against F.conv2d's weight gradient."""
+  from iic_amd import geom, ops
+  K, P = 3, max(dil, 1) if H < 200 else 3
+  x, w = _conv_inputs(cin, cout, K, N, H, 21)
+  wt = w.clone().requires_grad_(True)
+  y = F.conv2d(x, wt, stride=1, padding=dil, dilation=dil)
+  dy = bf16_round(torch.from_numpy(np.random.default_rng(8).standard_normal(tuple(y.shape)).astype(np.float32)))
+  y.backward(dy)
+  ref = wt.grad
+  spec = geom.ConvSpec(cin, cout, K, 1, dil, dil)
+  g = geom.fwd_geom(spec, N, H, H, P, P)
+  xp, dyp = ops.pt_from_nchw(x.to(dev()), P), ops.pt_from_nchw(dy.to(dev()), P)
+  out = {}
+  _wgrad_dma(dma)
+  try:
+    for form in (0, 1, 2, 3, 4, 5):
+      hook("iic_debug_wgrad_planar", form)
+      out[form] = ops.conv_wgrad(g, xp, dyp, K * K, use_tr=True, nsplit=nsplit).clone()
+    torch.cuda.synchronize()
+  finally:
+    hook("iic_debug_wgrad_planar", 5)
+    _wgrad_dma(1)
+  for form in (1, 2, 3, 4, 5):
+    assert torch.equal(out[form], out[0]), form
+  got = out[5].view(cout, cin, K, K).cpu()
+  scale = ref.abs().max().item()
+  assert (got - ref).abs().max().item() <= 2e-3 * scale, (got - ref).abs().max().item() / scale
+
+
+@pytest.mark.parametrize("cin,cout,H,dil,N", [(128, 128, 20, 2, 4), (64, 128, 12, 1, 9), (64, 64, 30, 2, 3)])
+def test_conv_backward_weight_planar_kernel_shapes(cin, cout, H, dil, N):
+  """Shapes the planar-patch weight-gradient kernels take in the product library that the ClusterNet5g cases above do
+  not reach: dilation 2 (a wave's three taps two pixels apart) and short image rows; against F.conv2d."""
+  from iic_amd import geom, ops
+  K, P = 3, dil
+  x, w = _conv_inputs(cin, cout, K, N, H, 22)
+  wt = w.clone().requires_grad_(True)
+  y = F.conv2d(x, wt, stride=1, padding=dil, dilation=dil)
+  dy = bf16_round(torch.from_numpy(np.random.default_rng(9).standard_normal(tuple(y.shape)).astype(np.float32)))
+  y.backward(dy)
+  ref = wt.grad
+  g = geom.fwd_geom(geom.ConvSpec(cin, cout, K, 1, dil, dil), N, H, H, P, P)
+  for nsplit in (1, 3):
+    dW = ops.conv_wgrad(g, ops.pt_from_nchw(x.to(dev()), P), ops.pt_from_nchw(dy.to(dev()), P), K * K, use_tr=True,
+                        nsplit=nsplit)
+    torch.cuda.synchronize()
+    got = dW.view(cout, cin, K, K).cpu()
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() <= 2e-3 * scale, (nsplit, (got - ref).abs().max().item() / scale)
+
+
 def _conv_backward_weight(case, use_tr, nsplit=None):
   from iic_amd import geom, ops
   cin, cout, K, s, p, N, H = case

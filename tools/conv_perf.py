@@ -47,10 +47,16 @@ def main():
   ap.add_argument("--no-wgrad", action="store_true")
   ap.add_argument("--bd-dma", type=int, default=1, help="weights-direct kernel: 1 = LDS-DMA patch loads, 0 = register-staged")
   ap.add_argument("--frag-ablate", type=str, default="", help="comma list of ablation codes for the frag kernel")
+  ap.add_argument("--no-pw", action="store_true", help="persistent kernel off: every launch on conv_igemm_bd_kernel (the ablation codes' baseline)")
   ap.add_argument("--dense-key-ab", action="store_true", help="A/B the weights-direct kernel's swizzle key (dense pixel count vs raw index)")
   a = ap.parse_args()
   dev = torch.device("cuda:0")
   N = a.n
+  if a.no_pw:
+    import ctypes
+    from iic_amd import _lib
+    ctypes.CDLL(_lib.LIB_PATH).iic_debug_enable_pw(0)
+    print("persistent kernel off")
   if not a.bd_dma:
     import ctypes
     from iic_amd import _lib
