@@ -81,7 +81,7 @@ __device__ __forceinline__ void bd_tile(
   constexpr bool NEWORD = (ABL & 256) == 0;     // ABL bit 256: the round-2 K-loop order (A/B runs)
   // ABL bit 512 (timing only, WRONG results): A-fragment addresses as for a 144-byte row pitch -- one add per tap and
   // sub-tile, immediate k-step offsets -- while the DMA still writes the swizzled 128-byte rows: what the K loop would
-  // cost without its ~70 VALU of swizzle arithmetic per tap (LAB.md R6.7)
+  // cost without its ~70 VALU of swizzle arithmetic per tap (LAB.md R6.9)
   constexpr bool SWZ = DMA && (ABL & 512) == 0;
   // PROF (ABL bit 128, results CORRECT): wave 0 stamps s_memtime at the phase boundaries of its tile
   // into prof[blockIdx][BD_PROF_SLOTS] (tools/bd_timeline.py decodes them)

@@ -441,7 +441,7 @@ __global__ __launch_bounds__(PF ? 256 : WD_THREADS) void conv_wgrad_dma_kernel(
 // instructions per k-step on the ADDRESSES of its 10 transposing reads (5 per input-patch read: the row's XOR swizzle
 // is a function of row + tap offset, so nothing of it is loop-invariant) against 6 MFMAs, and VALU and MFMA share a
 // SIMD's issue port: 3 waves x (48 MFMA + ~500 VALU) issue slots per K-tile exceed the 3 x 48 x 8 slots the matrix
-// pipe needs (LAB.md R6.6).  Here the 64-channel input patch lives in LDS as TWO PLANES of 64-byte half rows
+// pipe needs (LAB.md R6.8).  Here the 64-channel input patch lives in LDS as TWO PLANES of 64-byte half rows
 // (channels 0-31 | 32-63): a wave (one channel half) reads rows R .. R+3 of its plane = 256 consecutive bytes = every
 // bank once, with NO swizzle, so a read's address is  plane + 64 * (row + tap offset)  -- the per-row part is
 // tabulated (pre-multiplied) once per K-tile and the three taps of a wave's tap row are IMMEDIATE offsets
@@ -449,6 +449,20 @@ __global__ __launch_bounds__(PF ? 256 : WD_THREADS) void conv_wgrad_dma_kernel(
 // on its source side (a 1-KB block = 16 half rows of one plane); its global addresses are a uniform base + a lane
 // constant (input) or + a tabulated row offset (dY).  Same work split, same k order, same MFMA sequence as above:
 // bit-identical partial sums.
+// XCD-aware work mapping for ANY split count (the first-generation kernels remap only when the split count divides by
+// 8): workgroups are dealt to the 8 XCDs round-robin by linear id L, so XCD x runs L = x, x + 8, ...; its j-th workgroup
+// takes virtual index v = (workgroups of the XCDs before it) + j, and v walks the (co, ci) tiles of one K-split before it
+// moves to the next split -- the tiles of a split read the same input patch / dY rows and now meet in one L2.
+__device__ __forceinline__ void wdp_xcd_map(int& tile, int& split) {
+  const int tiles = (int)gridDim.x, G = tiles * (int)gridDim.y;
+  const int L = (int)blockIdx.y * tiles + (int)blockIdx.x;
+  const int xcd = L & 7, j = L >> 3;
+  const int q = G >> 3, r = G & 7;
+  const int v = xcd * q + (xcd < r ? xcd : r) + j;
+  split = v / tiles;
+  tile = v - split * tiles;
+}
+
 template <int OFF>
 __device__ __forceinline__ void wdp_tr_asm(uint32_t addr, s16x4& d) {
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
@@ -512,13 +526,8 @@ __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_pl_kernel(
   const int l31 = lane & 31;
   const int q = lane >> 4, i16 = lane & 15;
   const int ncit = g.Cin >> 6;
-  int tile = blockIdx.x, split = blockIdx.y;    // XCD-aware mapping as above
-  if ((gridDim.y & 7) == 0) {
-    const int L = blockIdx.y * gridDim.x + blockIdx.x;
-    const int xcd = L & 7, j = L >> 3;
-    tile = j % (int)gridDim.x;
-    split = xcd + 8 * (j / (int)gridDim.x);
-  }
+  int tile, split;
+  wdp_xcd_map(tile, split);
   const int cot = tile / ncit, cit = tile - cot * ncit;
   const int co0 = cot * COT, ci0 = cit * 64;
   const int per = (num_ktiles + nsplit - 1) / nsplit;
@@ -681,6 +690,7 @@ __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_pl_kernel(
       if (!(abl & 2)) wdp_unroll<NKS>(step);      // abl 2 (timing only): DMA + bookkeeping without the k-steps
     }
   }
+  if (abl & 8) return;                   // abl 8 (timing only): no partial stores
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
     float* dst = partials + (((long)split * g.ntaps + (tfirst + t)) * g.Cout + co0) * g.Cin + ci0;
@@ -690,13 +700,14 @@ __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_pl_kernel(
       for (int r = 0; r < 16; ++r) {
         const int row = wm * (COT / 2) + c * 32 + mfma32_row(r, lane);
         const int col = wn * 32 + l31;
-        dst[(long)row * g.Cin + col] = acc[t][c][r];
+        if (abl & 16) __builtin_nontemporal_store(acc[t][c][r], dst + (long)row * g.Cin + col);   // abl 16: nt stores (results correct)
+        else dst[(long)row * g.Cin + col] = acc[t][c][r];
       }
   }
 }
 
 // Third form of the loop (iic_debug_wgrad_planar = 3, the default): the planar-patch kernel above with the per-tile work
-// taken off the critical path between the tile barrier and the first MFMA (LAB.md R6.6: of a 144-us launch at layer 3,
+// taken off the critical path between the tile barrier and the first MFMA (LAB.md R6.8: of a 144-us launch at layer 3,
 // 61 us are MFMA time, 26 us the k-steps' own inefficiency, 27 us DMA / compute overlap loss, 30 us fixed):
 //   * the read addresses of tile kt + 1 are formed at the END of tile kt (their table reads are issued behind the last
 //     k-step's fragment reads and land under its MFMAs), so the first fragment reads issue right after the barrier;
@@ -746,13 +757,8 @@ __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_pl2_kernel(
   const int l31 = lane & 31;
   const int q = lane >> 4, i16 = lane & 15;
   const int ncit = g.Cin >> 6;
-  int tile = blockIdx.x, split = blockIdx.y;
-  if ((gridDim.y & 7) == 0) {
-    const int L = blockIdx.y * gridDim.x + blockIdx.x;
-    const int xcd = L & 7, j = L >> 3;
-    tile = j % (int)gridDim.x;
-    split = xcd + 8 * (j / (int)gridDim.x);
-  }
+  int tile, split;
+  wdp_xcd_map(tile, split);
   const int cot = tile / ncit, cit = tile - cot * ncit;
   const int co0 = cot * COT, ci0 = cit * 64;
   const int per = (num_ktiles + nsplit - 1) / nsplit;
@@ -983,6 +989,7 @@ __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_pl2_kernel(
       prep_finish(kt + 1, (b + 1) % NBUF);
     }
   }
+  if (abl & 8) return;                   // abl 8 (timing only): no partial stores
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
     float* dst = partials + (((long)split * g.ntaps + (tfirst + t)) * g.Cout + co0) * g.Cin + ci0;
@@ -992,7 +999,8 @@ __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_pl2_kernel(
       for (int r = 0; r < 16; ++r) {
         const int row = wm * (COT / 2) + c * 32 + mfma32_row(r, lane);
         const int col = wn * 32 + l31;
-        dst[(long)row * g.Cin + col] = acc[t][c][r];
+        if (abl & 16) __builtin_nontemporal_store(acc[t][c][r], dst + (long)row * g.Cin + col);   // abl 16: nt stores (results correct)
+        else dst[(long)row * g.Cin + col] = acc[t][c][r];
       }
   }
 }
