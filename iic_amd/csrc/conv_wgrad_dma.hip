@@ -1,5 +1,13 @@
-// Convolution backward-weight, DMA-fed variant for the stride-1 3x3 layers (the bulk of
-// /root/reference/code/archs/cluster/residual.py:4-7,19,22): same math and work split as
+// Convolution backward-weight, DMA-fed kernels for the 3x3 layers (the bulk of
+// /root/reference/code/archs/cluster/residual.py:4-7,19,22; vgg.py:24-26 where the patch fits LDS twice).
+// Three generations of the same work split live in this file and produce the same bits:
+//   conv_wgrad_dma_kernel   (rounds 2-5)  swizzled 128-byte patch rows; fallback for tap layouts / sizes the planar
+//                                         kernels refuse (and the A/B baseline, iic_debug_wgrad_planar = 0)
+//   conv_wgrad_pl_kernel    (round 6)     planar patch: read addresses = per-tile base + immediates; the default for
+//                                         128-cout tiles
+//   conv_wgrad_pl2_kernel   (round 6)     planar patch + per-tile work off the critical path + software-pipelined
+//                                         k-steps; the default for 64-cout tiles
+// (see the comments at each kernel and LAB.md R6.8).  First generation: same math and work split as
 // conv_wgrad.hip,
 //   dW[t][co][ci] = sum_m dY[pout(m)][co] * X[pin(m) + tap_off[t]][ci],
 // workgroup = COT co x 64 ci x 9 taps over a range of 128-pixel K-tiles, 12 waves
