@@ -36,6 +36,27 @@ def timeit(fn, iters):
   return e0.elapsed_time(e1) * 1e3 / iters
 
 
+_FLUSH = []
+
+
+def timeit_cold(fn, iters):
+  """Per-launch time with the caches cold: a 1-GB fill runs in front of every timed call (the 256-MB MALL and the L2s hold
+  nothing of the operands; in a timeit() loop the same 0.2-0.4 GB of operands are re-read from the MALL every time)."""
+  if not _FLUSH:
+    _FLUSH.append(torch.empty(1 << 30, dtype=torch.uint8, device="cuda"))
+  fn()
+  tot = 0.0
+  for i in range(iters):
+    _FLUSH[0].fill_(i & 1)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn()
+    e1.record()
+    torch.cuda.synchronize()
+    tot += e0.elapsed_time(e1)
+  return tot * 1e3 / iters
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--n", type=int, default=660)
@@ -47,6 +68,7 @@ def main():
   ap.add_argument("--no-wgrad", action="store_true")
   ap.add_argument("--bd-dma", type=int, default=1, help="weights-direct kernel: 1 = LDS-DMA patch loads, 0 = register-staged")
   ap.add_argument("--frag-ablate", type=str, default="", help="comma list of ablation codes for the frag kernel")
+  ap.add_argument("--cold", action="store_true", help="also time every kernel with cold caches (a 1-GB fill in front of each launch)")
   ap.add_argument("--no-pw", action="store_true", help="persistent kernel off: every launch on conv_igemm_bd_kernel (the ablation codes' baseline)")
   ap.add_argument("--dense-key-ab", action="store_true", help="A/B the weights-direct kernel's swizzle key (dense pixel count vs raw index)")
   a = ap.parse_args()
@@ -133,6 +155,14 @@ def main():
         t2 = timeit(lambda: [ops.conv_igemm(g, dy, pw[1], dx) for g in gb], a.iters)
         extra += " | frag bwdD %7.1f us %7.1f TF/s" % (t2, flops / t2 / 1e6)
         tot["bwd2"] = tot.get("bwd2", 0.0) + COUNT[li] * (t2 - t_b)
+    if a.cold:
+      extra += " | COLD:"
+      if ops.frag_supported(gf):
+        extra += " frag fwd %7.1f" % timeit_cold(lambda: ops.conv_igemm(gf, x, pw[0], y, stats=st), a.iters)
+      if all(ops.frag_supported(g) for g in gb):
+        extra += " frag bwdD %7.1f" % timeit_cold(lambda: [ops.conv_igemm(g, dy, pw[1], dx) for g in gb], a.iters)
+      if not a.no_wgrad:
+        extra += " wgrad %7.1f" % timeit_cold(lambda: ops.conv_wgrad(gf, x, dy, K * K, True), a.iters)
     c = COUNT[li]
     tot["fwd"] += c * t_f; tot["bwd"] += c * t_b; tot["wg"] += c * t_w
     print("%-28s %9.1f %8.1f | %9.1f %8.1f | %9.1f %8.1f | %d%s" % (
