@@ -509,7 +509,8 @@ __device__ __forceinline__ void wdp_unroll(F& f) {
   }
 }
 
-template <int COT, int WD_BM, int NBUF, int TXS, bool ASMRD>
+// NTAB: row-table ring (power of two >= NBUF + 2): 8, or 4 where the last 4 KB decide whether the layout fits
+template <int COT, int WD_BM, int NBUF, int TXS, bool ASMRD, int NTAB = WD_NTAB>
 __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_pl_kernel(
     const iic_conv_geom g, const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
     float* __restrict__ partials, int nsplit, int num_ktiles, int plane_bytes, int max_tap_off, int abl) {
@@ -519,13 +520,14 @@ __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_pl_kernel(
   constexpr int DB = WD_BM * DROW;
   constexpr int DBLK = DB / 1024;
   constexpr int NKS = WD_BM / 16;
+  static_assert((NTAB & (NTAB - 1)) == 0 && NTAB >= NBUF + 2, "table ring: a power of two, at least NBUF + 2 tiles");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   typedef unsigned char __attribute__((address_space(3))) * lds_u8_ptr;
   const int xb_bytes = 2 * plane_bytes;
   unsigned char* const sX = smem_raw;                        // [NBUF][2 planes][plane_bytes]
   unsigned char* const sD = smem_raw + NBUF * xb_bytes;      // [NBUF][DB]
   uint32_t* const s_dyoff = reinterpret_cast<uint32_t*>(sD + NBUF * DB);   // [NTAB][BMK] byte offset of the dY row
-  int* const s_pin = reinterpret_cast<int*>(s_dyoff + WD_NTAB * WD_BM);    // [NTAB][BMK] input pixel of the row (tap 0)
+  int* const s_pin = reinterpret_cast<int*>(s_dyoff + NTAB * WD_BM);    // [NTAB][BMK] input pixel of the row (tap 0)
   const uint32_t sXo = (uint32_t)(uintptr_t)(lds_u8_ptr)sX, sDo = (uint32_t)(uintptr_t)(lds_u8_ptr)sD;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -579,8 +581,8 @@ __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_pl_kernel(
       if (tid < WD_BM) {
         int pin, pout;
         wd_walk_pixels(wr, g, pin, pout);
-        s_dyoff[(kt & (WD_NTAB - 1)) * WD_BM + tid] = pout < 0 ? 0u : (uint32_t)pout * dy_row_bytes;   // 0 = zero border
-        s_pin[(kt & (WD_NTAB - 1)) * WD_BM + tid] = pin;
+        s_dyoff[(kt & (NTAB - 1)) * WD_BM + tid] = pout < 0 ? 0u : (uint32_t)pout * dy_row_bytes;   // 0 = zero border
+        s_pin[(kt & (NTAB - 1)) * WD_BM + tid] = pin;
         wd_walk_advance(wr, g, d_y, d_x, WD_BM);
       }
     };
@@ -588,7 +590,7 @@ __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_pl_kernel(
     const unsigned char* const xg = reinterpret_cast<const unsigned char*>(x) + (long)ci0 * 2;
     const unsigned char* const dg = reinterpret_cast<const unsigned char*>(dy) + (long)co0 * 2;
     auto dma_issue = [&](int buf, int kt) {
-      const int tab = kt & (WD_NTAB - 1);
+      const int tab = kt & (NTAB - 1);
       const int plo = __builtin_amdgcn_readfirstlane(s_pin[tab * WD_BM]);
       const int phi = __builtin_amdgcn_readfirstlane(s_pin[tab * WD_BM + WD_BM - 1]);
       const int nbp = (phi + max_tap_off - plo + 1 + 15) >> 4;        // 16-row blocks per plane
@@ -645,7 +647,7 @@ __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_pl_kernel(
       }
       if (kt + NBUF - 1 < kt1 && !(abl & 1)) dma_issue((b + NBUF - 1) % NBUF, kt + NBUF - 1);
       tabulate(kt + NBUF);
-      const int* prow = s_pin + (kt & (WD_NTAB - 1)) * WD_BM;
+      const int* prow = s_pin + (kt & (NTAB - 1)) * WD_BM;
       // read addresses of the tile: input rows for tap (ty, 0) of this wave's plane; dY base per co sub-tile
       const int plo = __builtin_amdgcn_readfirstlane(prow[0]);
       const uint32_t xbase = sXo + b * xb_bytes + wn * plane_bytes + (toff0 - plo) * 64 + tsub;
@@ -738,7 +740,7 @@ __device__ __forceinline__ void wdp_lgkm_wait() {
   asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int COT, int WD_BM, int NBUF, int TXS, bool SWP>
+template <int COT, int WD_BM, int NBUF, int TXS, bool SWP, int NTAB = WD_NTAB>
 __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_pl2_kernel(
     const iic_conv_geom g, const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
     float* __restrict__ partials, int nsplit, int num_ktiles, int plane_bytes, int max_tap_off, int abl) {
@@ -748,6 +750,7 @@ __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_pl2_kernel(
   constexpr int DB = WD_BM * DROW;
   constexpr int DBLK = DB / 1024;
   constexpr int NKS = WD_BM / 16;
+  static_assert((NTAB & (NTAB - 1)) == 0 && NTAB >= NBUF + 2, "table ring: a power of two, at least NBUF + 2 tiles");
   constexpr int NRD = 2 * CS + 6;               // transposing reads per k-step
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   typedef unsigned char __attribute__((address_space(3))) * lds_u8_ptr;
@@ -755,7 +758,7 @@ __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_pl2_kernel(
   unsigned char* const sX = smem_raw;
   unsigned char* const sD = smem_raw + NBUF * xb_bytes;
   uint32_t* const s_dyoff = reinterpret_cast<uint32_t*>(sD + NBUF * DB);
-  int* const s_pin = reinterpret_cast<int*>(s_dyoff + WD_NTAB * WD_BM);
+  int* const s_pin = reinterpret_cast<int*>(s_dyoff + NTAB * WD_BM);
   const uint32_t sXo = (uint32_t)(uintptr_t)(lds_u8_ptr)sX, sDo = (uint32_t)(uintptr_t)(lds_u8_ptr)sD;
   const uint32_t sPo = (uint32_t)(uintptr_t)(lds_u8_ptr)reinterpret_cast<unsigned char*>(s_pin);
 
@@ -837,15 +840,15 @@ __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_pl2_kernel(
           if (wr.x >= g.MX) { wr.x -= g.MX; ++wr.y; wr.pin += pin_xw; wr.dyo += dyo_xw; }
           while (wr.y >= g.MY) { wr.y -= g.MY; ++wr.n; wr.pin += pin_yw; wr.dyo += dyo_yw; }
         }
-        s_dyoff[(kt & (WD_NTAB - 1)) * WD_BM + tid] = dyo;
-        s_pin[(kt & (WD_NTAB - 1)) * WD_BM + tid] = pin;
+        s_dyoff[(kt & (NTAB - 1)) * WD_BM + tid] = dyo;
+        s_pin[(kt & (NTAB - 1)) * WD_BM + tid] = pin;
       }
     };
     const int NI = (2 * (plane_bytes >> 10) + DBLK + NW - 1) / NW;
     const unsigned char* const xg = reinterpret_cast<const unsigned char*>(x) + (long)ci0 * 2;
     const unsigned char* const dg = reinterpret_cast<const unsigned char*>(dy) + (long)co0 * 2;
     auto dma_issue = [&](int buf, int kt) {
-      const int tab = kt & (WD_NTAB - 1);
+      const int tab = kt & (NTAB - 1);
       const int plo = __builtin_amdgcn_readfirstlane(s_pin[tab * WD_BM]);
       const int phi = __builtin_amdgcn_readfirstlane(s_pin[tab * WD_BM + WD_BM - 1]);
       const int nbp = (phi + max_tap_off - plo + 1 + 15) >> 4;
@@ -894,7 +897,7 @@ __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_pl2_kernel(
     uint32_t ab[CS];
     const uint32_t tab_lane = sPo + trow * 4;
     auto prep_issue = [&](int kt) {                 // NKS table reads (inline asm: counted by the callers' waits)
-      const uint32_t ta = tab_lane + (kt & (WD_NTAB - 1)) * (WD_BM * 4);
+      const uint32_t ta = tab_lane + (kt & (NTAB - 1)) * (WD_BM * 4);
       auto rd = [&](auto KS) {
         constexpr int ks = decltype(KS)::value;
         wdp_tab_read<ks * 16, ks * 16 + 4>(ta, pb[ks]);
@@ -905,7 +908,7 @@ __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_pl2_kernel(
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pb[0]));
 #pragma unroll
       for (int ks = 1; ks < NKS; ++ks) asm volatile("" : "+v"(pb[ks]));
-      const int plo = __builtin_amdgcn_readfirstlane(s_pin[(kt & (WD_NTAB - 1)) * WD_BM]);
+      const int plo = __builtin_amdgcn_readfirstlane(s_pin[(kt & (NTAB - 1)) * WD_BM]);
       const uint32_t xbase = sXo + buf * xb_bytes + wn * plane_bytes + (toff0 - plo) * 64 + tsub;
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
@@ -1014,8 +1017,8 @@ __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_pl2_kernel(
 }
 
 static long wdp_plane_bytes(int np) { return (((long)np * 64) + 1023) & ~1023L; }
-static long wdp_lds(int np, int cot, int bmk, int nbuf) {
-  return nbuf * (2 * wdp_plane_bytes(np) + (long)bmk * cot * 2) + WDP_TAB_BYTES(bmk) + 64;
+static long wdp_lds(int np, int cot, int bmk, int nbuf, int ntab) {
+  return nbuf * (2 * wdp_plane_bytes(np) + (long)bmk * cot * 2) + (long)ntab * bmk * 8;
 }
 
 static long wd_xb_bytes(int np) { return (((long)np * 128) + 1023) & ~1023L; }
@@ -1080,89 +1083,127 @@ static int wd_config(const iic_conv_geom* g, int* bmk, int* nbuf) {
   return 0;
 }
 
-// used by conv_wgrad.hip's dispatcher
-int iic_wgrad_dma_supported(const iic_conv_geom* g) {
-  int bmk, nbuf;
-  return g_wd_enabled && wd_config(g, &bmk, &nbuf);
-}
-
-int iic_wgrad_dma_launch(const iic_conv_geom* g, const void* x, const void* dy, float* partials,
-                         int nsplit, void* stream) {
-  int bmk = 0, nbuf = 0;
-  if (!wd_config(g, &bmk, &nbuf)) return IIC_ERR_UNSUPPORTED;
-  const long M = (long)g->N * (g->MP > 0 ? g->MP : g->MY * g->MX);
-  const int kt = (int)((M + bmk - 1) / bmk);
-  const int cot = (g->Cout % 128 == 0) ? 128 : 64;
-  const int np = bmk == 64 ? g->NP64 : g->NP;
-  const int xb = (int)wd_xb_bytes(np);
-  const long lds = wd_lds(np, cot, bmk, nbuf);
-  int mto = 0;
-  for (int i = 0; i < g->ntaps; ++i) mto = g->tap_off[i] > mto ? g->tap_off[i] : mto;
-  dim3 grid((g->Cout / cot) * (g->Cin / 64), nsplit);
-  hipStream_t s = (hipStream_t)stream;
-  // planar-patch kernel: a wave's three taps must be one tap row with a fixed x step (1, or 2 = dilation 2), dY row
-  // offsets must fit 32 bits, 64 * patch row must fit the 16-bit table
+// Planar-patch kernels: K-tile size / ring depth / table ring.  Chosen on their own terms (a layout that fits these
+// kernels need not fit the first generation's and vice versa): 128-pixel tiles with 2 buffers where they fit (if need be
+// with the 4-tile table ring: SegmentationNet10a c3 / c4 fit 160 KB to the byte that way), else the 64-pixel ring.
+// A wave's three taps must be one tap row with a fixed x step (1, or 2 = dilation 2); dY row offsets must fit 32 bits.
+// Padded row numbering (large images): allowed (g_wd_planar_padded) -- LAB.md R6.12 / profiles/r06_wgrad_seg_ab.txt have
+// the per-layer A/B against the register-staged kernel that used to keep these layers (Potsdam c3 / c4: 1.28-1.30 x).
+IIC_SWITCH(g_wd_planar_padded, 1, iic_debug_wgrad_planar_padded)
+static int wdp_txs(const iic_conv_geom* g) {
+  if (g->ntaps != 9) return 0;
   int txs = g->tap_off[1] - g->tap_off[0];
   for (int ty = 0; ty < 3; ++ty)
     for (int tx = 0; tx < 3; ++tx)
       if (g->tap_off[3 * ty + tx] != g->tap_off[3 * ty] + tx * txs) txs = 0;
-  const long dy_bytes = (long)g->N * g->out_Hp * g->out_Wp * g->Cout * 2;
-  if (g_wd_planar && (txs == 1 || txs == 2) && dy_bytes < (1L << 32) &&
-      wdp_lds(np, cot, bmk, nbuf) <= 160 * 1024) {
+  return (txs == 1 || txs == 2) ? txs : 0;
+}
+static int wdp_config(const iic_conv_geom* g, int* bmk, int* nbuf, int* ntab) {
+  if (!g_wd_planar || g->ntaps != 9 || g->Cin % 64 != 0 || g->Cout % 64 != 0 || g->NP <= 0 || g->NP > 65535) return 0;
+  if (!wdp_txs(g)) return 0;
+  if ((long)g->N * g->out_Hp * g->out_Wp * g->Cout * 2 >= (1L << 32)) return 0;
+  const bool padded = g->MP > 0 && g->MP != g->MY * g->MX;
+  if (padded && !g_wd_planar_padded && g_wd_enabled != 3) return 0;
+  const int cot = (g->Cout % 128 == 0) ? 128 : 64;
+  const long lim = 160 * 1024;
+  if (g_wd_enabled != 3 && (g->MP <= 0 || g->MP % 128 == 0)) {
+    for (int nt = 8; nt >= 4; nt >>= 1)
+      if (wdp_lds(g->NP, cot, 128, 2, nt) <= lim) { *bmk = 128; *nbuf = 2; *ntab = nt; return 1; }
+  }
+  if (g->NP64 > 0 && (g->MP <= 0 || g->MP % 64 == 0)) {
+    for (int nb = 4; nb >= 3; --nb)
+      if (wdp_lds(g->NP64, cot, 64, nb, 8) <= lim) { *bmk = 64; *nbuf = nb; *ntab = 8; return 1; }
+    // two buffers of 64-pixel tiles: the patch is mostly halo there (NP64 / 64 = 5-8 rows fetched per row used) and the
+    // planar DMA moves it in 64-byte pieces -- measured (profiles/r06_wgrad_seg_ab.txt): 1.12-1.22 x the previous kernel
+    // up to 356 patch rows (COCO-Stuff c2 / c5 / c6), 1.04 x at 484 (Potsdam c2), 0.98 x at 492 (Potsdam c6)
+    if (g->NP64 <= 400 || g_wd_enabled == 3) {
+      if (wdp_lds(g->NP64, cot, 64, 2, 8) <= lim) { *bmk = 64; *nbuf = 2; *ntab = 8; return 1; }
+      if (wdp_lds(g->NP64, cot, 64, 2, 4) <= lim) { *bmk = 64; *nbuf = 2; *ntab = 4; return 1; }
+    }
+  }
+  return 0;
+}
+
+// used by conv_wgrad.hip's dispatcher
+int iic_wgrad_dma_supported(const iic_conv_geom* g) {
+  int bmk, nbuf, ntab;
+  return g_wd_enabled && (wdp_config(g, &bmk, &nbuf, &ntab) || wd_config(g, &bmk, &nbuf));
+}
+
+int iic_wgrad_dma_launch(const iic_conv_geom* g, const void* x, const void* dy, float* partials,
+                         int nsplit, void* stream) {
+  const int cot = (g->Cout % 128 == 0) ? 128 : 64;
+  const long M = (long)g->N * (g->MP > 0 ? g->MP : g->MY * g->MX);
+  int mto = 0;
+  for (int i = 0; i < g->ntaps; ++i) mto = g->tap_off[i] > mto ? g->tap_off[i] : mto;
+  dim3 grid((g->Cout / cot) * (g->Cin / 64), nsplit);
+  hipStream_t s = (hipStream_t)stream;
+  int pbmk = 0, pnbuf = 0, pntab = 0;
+  if (wdp_config(g, &pbmk, &pnbuf, &pntab)) {          // planar-patch kernels
+    const int txs = wdp_txs(g);
+    const int np = pbmk == 64 ? g->NP64 : g->NP;
+    const int kt = (int)((M + pbmk - 1) / pbmk);
     const int plane = (int)wdp_plane_bytes(np);
-    const long ldsp = wdp_lds(np, cot, bmk, nbuf);
-#define WDP_LAUNCH3(COT_, BMK_, NBUF_, TXS_, ASM_)                                               \
+    const long ldsp = wdp_lds(np, cot, pbmk, pnbuf, pntab);
+#define WDP_LAUNCH3(COT_, BMK_, NBUF_, TXS_, ASM_, NTAB_)                                        \
   do {                                                                                          \
     static bool attr = false;                                                                   \
     if (!attr) {                                                                                \
       (void)hipFuncSetAttribute(                                                                \
-          reinterpret_cast<const void*>(&conv_wgrad_pl_kernel<COT_, BMK_, NBUF_, TXS_, ASM_>),  \
+          reinterpret_cast<const void*>(&conv_wgrad_pl_kernel<COT_, BMK_, NBUF_, TXS_, ASM_, NTAB_>), \
           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                              \
       attr = true;                                                                              \
     }                                                                                           \
-    hipLaunchKernelGGL((conv_wgrad_pl_kernel<COT_, BMK_, NBUF_, TXS_, ASM_>), grid,             \
+    hipLaunchKernelGGL((conv_wgrad_pl_kernel<COT_, BMK_, NBUF_, TXS_, ASM_, NTAB_>), grid,      \
                        dim3(WD_THREADS), ldsp, s, *g, (const bf16_t*)x, (const bf16_t*)dy,      \
                        partials, nsplit, kt, plane, mto, g_wd_ablate);                          \
   } while (0)
-#define WDP2_LAUNCH3(COT_, BMK_, NBUF_, TXS_, SWP_)                                              \
+#define WDP2_LAUNCH3(COT_, BMK_, NBUF_, TXS_, SWP_, NTAB_)                                       \
   do {                                                                                          \
     static bool attr = false;                                                                   \
     if (!attr) {                                                                                \
       (void)hipFuncSetAttribute(                                                                \
-          reinterpret_cast<const void*>(&conv_wgrad_pl2_kernel<COT_, BMK_, NBUF_, TXS_, SWP_>), \
+          reinterpret_cast<const void*>(&conv_wgrad_pl2_kernel<COT_, BMK_, NBUF_, TXS_, SWP_, NTAB_>), \
           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                              \
       attr = true;                                                                              \
     }                                                                                           \
-    hipLaunchKernelGGL((conv_wgrad_pl2_kernel<COT_, BMK_, NBUF_, TXS_, SWP_>), grid,            \
+    hipLaunchKernelGGL((conv_wgrad_pl2_kernel<COT_, BMK_, NBUF_, TXS_, SWP_, NTAB_>), grid,     \
                        dim3(WD_THREADS), ldsp, s, *g, (const bf16_t*)x, (const bf16_t*)dy,      \
                        partials, nsplit, kt, plane, mto, g_wd_ablate);                          \
   } while (0)
 #ifdef IIC_DEBUG_HOOKS
-#define WDP_LAUNCH2(COT_, BMK_, NBUF_, TXS_)                                                     \
+#define WDP_LAUNCH2(COT_, BMK_, NBUF_, TXS_, NTAB_)                                              \
   do {                                                                                          \
-    if (g_wd_planar == 4 || (g_wd_planar == 5 && COT_ == 64)) WDP2_LAUNCH3(COT_, BMK_, NBUF_, TXS_, true); \
-    else if (g_wd_planar == 3) WDP2_LAUNCH3(COT_, BMK_, NBUF_, TXS_, false);                    \
-    else if (g_wd_planar == 1) WDP_LAUNCH3(COT_, BMK_, NBUF_, TXS_, false);                     \
-    else WDP_LAUNCH3(COT_, BMK_, NBUF_, TXS_, true);                                            \
+    if (g_wd_planar == 4 || (g_wd_planar == 5 && COT_ == 64)) WDP2_LAUNCH3(COT_, BMK_, NBUF_, TXS_, true, NTAB_); \
+    else if (g_wd_planar == 3) WDP2_LAUNCH3(COT_, BMK_, NBUF_, TXS_, false, NTAB_);             \
+    else if (g_wd_planar == 1) WDP_LAUNCH3(COT_, BMK_, NBUF_, TXS_, false, NTAB_);              \
+    else WDP_LAUNCH3(COT_, BMK_, NBUF_, TXS_, true, NTAB_);                                     \
   } while (0)
 #else      /* the product library instantiates the default forms only */
-#define WDP_LAUNCH2(COT_, BMK_, NBUF_, TXS_)                                                     \
+#define WDP_LAUNCH2(COT_, BMK_, NBUF_, TXS_, NTAB_)                                              \
   do {                                                                                          \
-    if (COT_ == 64) WDP2_LAUNCH3(64, BMK_, NBUF_, TXS_, true);                                  \
-    else WDP_LAUNCH3(128, BMK_, NBUF_, TXS_, true);                                             \
+    if (COT_ == 64) WDP2_LAUNCH3(64, BMK_, NBUF_, TXS_, true, NTAB_);                           \
+    else WDP_LAUNCH3(128, BMK_, NBUF_, TXS_, true, NTAB_);                                      \
   } while (0)
 #endif
-#define WDP_LAUNCH(BMK_, NBUF_)                                                                  \
+#define WDP_LAUNCH(BMK_, NBUF_, NTAB_)                                                           \
   do {                                                                                          \
-    if (cot == 128) { if (txs == 1) WDP_LAUNCH2(128, BMK_, NBUF_, 1); else WDP_LAUNCH2(128, BMK_, NBUF_, 2); } \
-    else { if (txs == 1) WDP_LAUNCH2(64, BMK_, NBUF_, 1); else WDP_LAUNCH2(64, BMK_, NBUF_, 2); } \
+    if (cot == 128) { if (txs == 1) WDP_LAUNCH2(128, BMK_, NBUF_, 1, NTAB_); else WDP_LAUNCH2(128, BMK_, NBUF_, 2, NTAB_); } \
+    else { if (txs == 1) WDP_LAUNCH2(64, BMK_, NBUF_, 1, NTAB_); else WDP_LAUNCH2(64, BMK_, NBUF_, 2, NTAB_); } \
   } while (0)
-    if (bmk == 128) WDP_LAUNCH(128, 2);
-    else if (nbuf == 4) WDP_LAUNCH(64, 4);
-    else if (nbuf == 3) WDP_LAUNCH(64, 3);
-    else WDP_LAUNCH(64, 2);
+    if (pbmk == 128) { if (pntab == 8) WDP_LAUNCH(128, 2, 8); else WDP_LAUNCH(128, 2, 4); }
+    else if (pnbuf == 4) WDP_LAUNCH(64, 4, 8);
+    else if (pnbuf == 3) WDP_LAUNCH(64, 3, 8);
+    else if (pntab == 8) WDP_LAUNCH(64, 2, 8);
+    else WDP_LAUNCH(64, 2, 4);
     return iic_launch_status();
   }
+  int bmk = 0, nbuf = 0;
+  if (!wd_config(g, &bmk, &nbuf)) return IIC_ERR_UNSUPPORTED;
+  const int kt = (int)((M + bmk - 1) / bmk);
+  const int np = bmk == 64 ? g->NP64 : g->NP;
+  const int xb = (int)wd_xb_bytes(np);
+  const long lds = wd_lds(np, cot, bmk, nbuf);
 #define WD_LAUNCH2(COT_, BMK_, NBUF_, ASM_, PF_, SWP_)                                           \
   do {                                                                                          \
     static bool attr = false;                                                                   \

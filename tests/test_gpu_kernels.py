@@ -568,6 +568,35 @@ def test_weight_gradient_k_loop_forms_are_bit_identical(cin, cout, H, dil, N, ns
   assert (got - ref).abs().max().item() <= 2e-3 * scale, (got - ref).abs().max().item() / scale
 
 
+@pytest.mark.parametrize("cin,cout,H,pad,dil,N", [
+    (128, 256, 100, 1, 1, 3),     # Potsdam c3: padded numbering, 128-pixel tiles that fit 160 KB only with the 4-tile table ring
+    (64, 128, 128, 1, 1, 2),      # COCO-Stuff c2: 64-pixel tiles, two buffers
+    (256, 512, 64, 1, 2, 2),      # COCO-Stuff c5: dilation 2 with padding 1 (62 x 62 outputs), padded numbering, 64-pixel tiles
+    (512, 512, 62, 1, 2, 2),      # COCO-Stuff c6
+    (64, 128, 200, 1, 1, 1)])     # Potsdam c2: stays on the register-staged kernel (484 patch rows per 64-pixel tile)
+def test_conv_backward_weight_segmentation_net_shapes(cin, cout, H, pad, dil, N):
+  """The 3 x 3 layers of SegmentationNet10a as archs/seg.py builds them (PT border 3, the dilated convs with padding 1:
+  /root/reference/code/archs/segmentation/net10a.py:16-22) -- the shapes for which conv_wgrad_dma.hip's planar kernels
+  choose the 4-tile table ring, the 64-pixel ring and the padded row numbering; against F.conv2d's weight gradient, and
+  the result must not depend on the split count beyond rounding."""
+  from iic_amd import geom, ops
+  K, P = 3, 3
+  x, w = _conv_inputs(cin, cout, K, N, H, 31)
+  wt = w.clone().requires_grad_(True)
+  y = F.conv2d(x, wt, stride=1, padding=pad, dilation=dil)
+  dy = bf16_round(torch.from_numpy(np.random.default_rng(10).standard_normal(tuple(y.shape)).astype(np.float32)))
+  y.backward(dy)
+  ref = wt.grad
+  g = geom.fwd_geom(geom.ConvSpec(cin, cout, K, 1, pad, dil), N, H, H, P, P)
+  xp, dyp = ops.pt_from_nchw(x.to(dev()), P), ops.pt_from_nchw(dy.to(dev()), P)
+  scale = ref.abs().max().item()
+  for nsplit in (None, 2):
+    dW = ops.conv_wgrad(g, xp, dyp, K * K, use_tr=True, nsplit=nsplit)
+    torch.cuda.synchronize()
+    got = dW.view(cout, cin, K, K).cpu()
+    assert (got - ref).abs().max().item() <= 2e-3 * scale, (nsplit, (got - ref).abs().max().item() / scale)
+
+
 @pytest.mark.parametrize("cin,cout,H,dil,N", [(128, 128, 20, 2, 4), (64, 128, 12, 1, 9), (64, 64, 30, 2, 3)])
 def test_conv_backward_weight_planar_kernel_shapes(cin, cout, H, dil, N):
   """Shapes the planar-patch weight-gradient kernels take in the product library that the ClusterNet5g cases above do
