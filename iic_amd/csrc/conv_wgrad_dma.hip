@@ -513,7 +513,8 @@ __device__ __forceinline__ void wdp_unroll(F& f) {
 template <int COT, int WD_BM, int NBUF, int TXS, bool ASMRD, int NTAB = WD_NTAB>
 __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_pl_kernel(
     const iic_conv_geom g, const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
-    float* __restrict__ partials, int nsplit, int num_ktiles, int plane_bytes, int max_tap_off, int abl) {
+    float* __restrict__ partials, int nsplit, int num_ktiles, int plane_bytes, int max_tap_off, int abl,
+    int band_pitch, int band_stride) {
   constexpr int CS = COT / 64;
   constexpr int NW = WD_THREADS / 64;           // 12 waves: 2 co halves x 2 ci halves x 3 tap rows
   constexpr int DROW = COT * 2;
@@ -593,7 +594,11 @@ __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_pl_kernel(
       const int tab = kt & (NTAB - 1);
       const int plo = __builtin_amdgcn_readfirstlane(s_pin[tab * WD_BM]);
       const int phi = __builtin_amdgcn_readfirstlane(s_pin[tab * WD_BM + WD_BM - 1]);
-      const int nbp = (phi + max_tap_off - plo + 1 + 15) >> 4;        // 16-row blocks per plane
+      // 16-row blocks per plane.  Banded patch (band_pitch > 0: dilated convolutions / wide images, where a tile's
+      // contiguous pixel span is mostly the rows BETWEEN its three tap rows): one band of band_pitch LDS rows per tap
+      // row, band ty holding input pixels plo + ty * band_stride + [0, span + 2 * TXS]
+      const int nbb = band_pitch > 0 ? (phi - plo + 2 * TXS + 1 + 15) >> 4 : 0;   // blocks per band
+      const int nbp = band_pitch > 0 ? 3 * nbb : (phi + max_tap_off - plo + 1 + 15) >> 4;
       unsigned char* const dX = sX + buf * xb_bytes;
       unsigned char* const dD = sD + buf * DB;
       for (int i = 0; i < NI; ++i) {
@@ -601,8 +606,14 @@ __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_pl_kernel(
         b = b < 2 * nbp + DBLK ? b : 2 * nbp + DBLK - 1;
         if (b < 2 * nbp) {
           const int pl = b >= nbp ? 1 : 0;
-          const int j = b - pl * nbp;
-          const int r0 = plo + j * 16;
+          int j = b - pl * nbp;                    // block of the plane
+          int r0 = plo + j * 16;
+          if (band_pitch > 0) {
+            const int band = (j >= nbb ? 1 : 0) + (j >= 2 * nbb ? 1 : 0);
+            const int jb = j - band * nbb;
+            r0 = plo + band * band_stride + jb * 16;
+            j = band * (band_pitch >> 4) + jb;     // LDS block: band ty starts at row ty * band_pitch
+          }
           const unsigned char* src;
           uint32_t vo = lane_x;
           if (r0 + 15 < in_pixels) {
@@ -650,7 +661,7 @@ __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_pl_kernel(
       const int* prow = s_pin + (kt & (NTAB - 1)) * WD_BM;
       // read addresses of the tile: input rows for tap (ty, 0) of this wave's plane; dY base per co sub-tile
       const int plo = __builtin_amdgcn_readfirstlane(prow[0]);
-      const uint32_t xbase = sXo + b * xb_bytes + wn * plane_bytes + (toff0 - plo) * 64 + tsub;
+      const uint32_t xbase = sXo + b * xb_bytes + wn * plane_bytes + ((band_pitch > 0 ? tg * band_pitch : toff0) - plo) * 64 + tsub;
       uint32_t pb0[NKS], pb1[NKS], ab[CS];
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {         // all table reads in flight, one wait
@@ -1098,9 +1109,23 @@ static int wdp_txs(const iic_conv_geom* g) {
       if (g->tap_off[3 * ty + tx] != g->tap_off[3 * ty] + tx * txs) txs = 0;
   return (txs == 1 || txs == 2) ? txs : 0;
 }
-static int wdp_config(const iic_conv_geom* g, int* bmk, int* nbuf, int* ntab) {
+// band (out): LDS rows per band of the banded patch, 0 = contiguous patch.  Banded: the three tap rows of a tile each
+// get their own band of span + 2 * txs + 1 input rows (rounded to the DMA's 16-row blocks) instead of one contiguous
+// span of span + max tap offset + 1 rows -- for dilated convolutions and wide images the rows between the tap rows are
+// most of that span (SegmentationNet10a c5 at Potsdam: 500 rows per 64-pixel tile contiguous, 3 x 80 banded).  Only
+// where the bands do not overlap (tap-row distance >= band) and only for the 128-cout kernel.
+IIC_SWITCH(g_wd_banded, 1, iic_debug_wgrad_banded)
+static int wdp_band_rows(const iic_conv_geom* g, int np, int txs) {
+  int mto = 0;
+  for (int i = 0; i < g->ntaps; ++i) mto = g->tap_off[i] > mto ? g->tap_off[i] : mto;
+  const int span = np - mto - 1;                    // last - first input pixel (tap 0) of a tile, at most
+  return (span + 2 * txs + 1 + 15) & ~15;
+}
+static int wdp_config(const iic_conv_geom* g, int* bmk, int* nbuf, int* ntab, int* band) {
+  *band = 0;
   if (!g_wd_planar || g->ntaps != 9 || g->Cin % 64 != 0 || g->Cout % 64 != 0 || g->NP <= 0 || g->NP > 65535) return 0;
-  if (!wdp_txs(g)) return 0;
+  const int txs = wdp_txs(g);
+  if (!txs) return 0;
   if ((long)g->N * g->out_Hp * g->out_Wp * g->Cout * 2 >= (1L << 32)) return 0;
   const bool padded = g->MP > 0 && g->MP != g->MY * g->MX;
   if (padded && !g_wd_planar_padded && g_wd_enabled != 3) return 0;
@@ -1113,6 +1138,15 @@ static int wdp_config(const iic_conv_geom* g, int* bmk, int* nbuf, int* ntab) {
   if (g->NP64 > 0 && (g->MP <= 0 || g->MP % 64 == 0)) {
     for (int nb = 4; nb >= 3; --nb)
       if (wdp_lds(g->NP64, cot, 64, nb, 8) <= lim) { *bmk = 64; *nbuf = nb; *ntab = 8; return 1; }
+    // banded 64-pixel ring: 3 bands of (64 + wraps + 2 txs + 1) rows instead of the contiguous span
+    const int bstride = g->tap_off[3] - g->tap_off[0];
+    if (g_wd_banded && cot == 128 && bstride > 0 && g->tap_off[6] - g->tap_off[3] == bstride) {
+      const int bp = wdp_band_rows(g, g->NP64, txs);
+      if (bp <= bstride && 3 * bp < g->NP64) {
+        for (int nb = 4; nb >= 2; --nb)
+          if (wdp_lds(3 * bp, cot, 64, nb, 8) <= lim) { *bmk = 64; *nbuf = nb; *ntab = 8; *band = bp; return 1; }
+      }
+    }
     // two buffers of 64-pixel tiles: the patch is mostly halo there (NP64 / 64 = 5-8 rows fetched per row used) and the
     // planar DMA moves it in 64-byte pieces -- measured (profiles/r06_wgrad_seg_ab.txt): 1.12-1.22 x the previous kernel
     // up to 356 patch rows (COCO-Stuff c2 / c5 / c6), 1.04 x at 484 (Potsdam c2), 0.98 x at 492 (Potsdam c6)
@@ -1126,8 +1160,8 @@ static int wdp_config(const iic_conv_geom* g, int* bmk, int* nbuf, int* ntab) {
 
 // used by conv_wgrad.hip's dispatcher
 int iic_wgrad_dma_supported(const iic_conv_geom* g) {
-  int bmk, nbuf, ntab;
-  return g_wd_enabled && (wdp_config(g, &bmk, &nbuf, &ntab) || wd_config(g, &bmk, &nbuf));
+  int bmk, nbuf, ntab, band;
+  return g_wd_enabled && (wdp_config(g, &bmk, &nbuf, &ntab, &band) || wd_config(g, &bmk, &nbuf));
 }
 
 int iic_wgrad_dma_launch(const iic_conv_geom* g, const void* x, const void* dy, float* partials,
@@ -1138,10 +1172,11 @@ int iic_wgrad_dma_launch(const iic_conv_geom* g, const void* x, const void* dy, 
   for (int i = 0; i < g->ntaps; ++i) mto = g->tap_off[i] > mto ? g->tap_off[i] : mto;
   dim3 grid((g->Cout / cot) * (g->Cin / 64), nsplit);
   hipStream_t s = (hipStream_t)stream;
-  int pbmk = 0, pnbuf = 0, pntab = 0;
-  if (wdp_config(g, &pbmk, &pnbuf, &pntab)) {          // planar-patch kernels
+  int pbmk = 0, pnbuf = 0, pntab = 0, pband = 0;
+  if (wdp_config(g, &pbmk, &pnbuf, &pntab, &pband)) {  // planar-patch kernels
     const int txs = wdp_txs(g);
-    const int np = pbmk == 64 ? g->NP64 : g->NP;
+    const int bstride = g->tap_off[3] - g->tap_off[0];
+    const int np = pband > 0 ? 3 * pband : (pbmk == 64 ? g->NP64 : g->NP);      // LDS rows per plane
     const int kt = (int)((M + pbmk - 1) / pbmk);
     const int plane = (int)wdp_plane_bytes(np);
     const long ldsp = wdp_lds(np, cot, pbmk, pnbuf, pntab);
@@ -1156,7 +1191,7 @@ int iic_wgrad_dma_launch(const iic_conv_geom* g, const void* x, const void* dy, 
     }                                                                                           \
     hipLaunchKernelGGL((conv_wgrad_pl_kernel<COT_, BMK_, NBUF_, TXS_, ASM_, NTAB_>), grid,      \
                        dim3(WD_THREADS), ldsp, s, *g, (const bf16_t*)x, (const bf16_t*)dy,      \
-                       partials, nsplit, kt, plane, mto, g_wd_ablate);                          \
+                       partials, nsplit, kt, plane, mto, g_wd_ablate, pband, bstride);          \
   } while (0)
 #define WDP2_LAUNCH3(COT_, BMK_, NBUF_, TXS_, SWP_, NTAB_)                                       \
   do {                                                                                          \
@@ -1174,8 +1209,8 @@ int iic_wgrad_dma_launch(const iic_conv_geom* g, const void* x, const void* dy, 
 #ifdef IIC_DEBUG_HOOKS
 #define WDP_LAUNCH2(COT_, BMK_, NBUF_, TXS_, NTAB_)                                              \
   do {                                                                                          \
-    if (g_wd_planar == 4 || (g_wd_planar == 5 && COT_ == 64)) WDP2_LAUNCH3(COT_, BMK_, NBUF_, TXS_, true, NTAB_); \
-    else if (g_wd_planar == 3) WDP2_LAUNCH3(COT_, BMK_, NBUF_, TXS_, false, NTAB_);             \
+    if (pband == 0 && (g_wd_planar == 4 || (g_wd_planar == 5 && COT_ == 64))) WDP2_LAUNCH3(COT_, BMK_, NBUF_, TXS_, true, NTAB_); \
+    else if (pband == 0 && g_wd_planar == 3) WDP2_LAUNCH3(COT_, BMK_, NBUF_, TXS_, false, NTAB_); \
     else if (g_wd_planar == 1) WDP_LAUNCH3(COT_, BMK_, NBUF_, TXS_, false, NTAB_);              \
     else WDP_LAUNCH3(COT_, BMK_, NBUF_, TXS_, true, NTAB_);                                     \
   } while (0)

@@ -573,7 +573,9 @@ def test_weight_gradient_k_loop_forms_are_bit_identical(cin, cout, H, dil, N, ns
     (64, 128, 128, 1, 1, 2),      # COCO-Stuff c2: 64-pixel tiles, two buffers
     (256, 512, 64, 1, 2, 2),      # COCO-Stuff c5: dilation 2 with padding 1 (62 x 62 outputs), padded numbering, 64-pixel tiles
     (512, 512, 62, 1, 2, 2),      # COCO-Stuff c6
-    (64, 128, 200, 1, 1, 1)])     # Potsdam c2: stays on the register-staged kernel (484 patch rows per 64-pixel tile)
+    (64, 128, 200, 1, 1, 1),      # Potsdam c2: banded patch (3 x 80 rows instead of 484 per 64-pixel tile)
+    (256, 512, 100, 1, 2, 1),     # Potsdam c5: dilation 2, padded numbering, banded patch
+    (512, 512, 98, 1, 2, 1)])     # Potsdam c6: dilation 2, dense numbering, banded patch
 def test_conv_backward_weight_segmentation_net_shapes(cin, cout, H, pad, dil, N):
   """The 3 x 3 layers of SegmentationNet10a as archs/seg.py builds them (PT border 3, the dilated convs with padding 1:
   /root/reference/code/archs/segmentation/net10a.py:16-22) -- the shapes for which conv_wgrad_dma.hip's planar kernels
