@@ -1149,8 +1149,11 @@ static int wdp_config(const iic_conv_geom* g, int* bmk, int* nbuf, int* ntab, in
     }
     // two buffers of 64-pixel tiles: the patch is mostly halo there (NP64 / 64 = 5-8 rows fetched per row used) and the
     // planar DMA moves it in 64-byte pieces -- measured (profiles/r06_wgrad_seg_ab.txt): 1.12-1.22 x the previous kernel
-    // up to 356 patch rows (COCO-Stuff c2 / c5 / c6), 1.04 x at 484 (Potsdam c2), 0.98 x at 492 (Potsdam c6)
-    if (g->NP64 <= 400 || g_wd_enabled == 3) {
+    // up to 284 halo rows (COCO-Stuff c2 / c5 / c6), 1.04 x at 414 (Potsdam c2), 0.98 x at 420 (Potsdam c6) -- where the
+    // banded form above does not apply
+    int mto = 0;
+    for (int i = 0; i < g->ntaps; ++i) mto = g->tap_off[i] > mto ? g->tap_off[i] : mto;
+    if (mto <= 400 || g_wd_enabled == 3) {          // (halo rows, not patch rows: the stride-2 layers' 64-row span is long by itself)
       if (wdp_lds(g->NP64, cot, 64, 2, 8) <= lim) { *bmk = 64; *nbuf = 2; *ntab = 8; return 1; }
       if (wdp_lds(g->NP64, cot, 64, 2, 4) <= lim) { *bmk = 64; *nbuf = 2; *ntab = 4; return 1; }
     }
