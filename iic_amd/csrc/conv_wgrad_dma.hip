@@ -34,7 +34,6 @@
 #define WD_THREADS 768
 #define WD_NTAB 8                               // table ring (>= NBUF + 2, power of two)
 #define WD_TAB_BYTES(BMK_) (WD_NTAB * (BMK_) * (4 + 2))
-#define WDP_TAB_BYTES(BMK_) (WD_NTAB * (BMK_) * (4 + 4))
 
 __device__ __forceinline__ void wd_wait_vmcnt(int n) {   // counted wait, n uniform
   switch (n) {
