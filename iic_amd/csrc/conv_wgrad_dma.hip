@@ -753,7 +753,8 @@ __device__ __forceinline__ void wdp_lgkm_wait() {
 template <int COT, int WD_BM, int NBUF, int TXS, bool SWP, int NTAB = WD_NTAB>
 __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_pl2_kernel(
     const iic_conv_geom g, const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
-    float* __restrict__ partials, int nsplit, int num_ktiles, int plane_bytes, int max_tap_off, int abl) {
+    float* __restrict__ partials, int nsplit, int num_ktiles, int plane_bytes, int max_tap_off, int abl,
+    int band_pitch, int band_stride) {
   constexpr int CS = COT / 64;
   constexpr int NW = WD_THREADS / 64;
   constexpr int DROW = COT * 2;
@@ -861,7 +862,8 @@ __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_pl2_kernel(
       const int tab = kt & (NTAB - 1);
       const int plo = __builtin_amdgcn_readfirstlane(s_pin[tab * WD_BM]);
       const int phi = __builtin_amdgcn_readfirstlane(s_pin[tab * WD_BM + WD_BM - 1]);
-      const int nbp = (phi + max_tap_off - plo + 1 + 15) >> 4;
+      const int nbb = band_pitch > 0 ? (phi - plo + 2 * TXS + 1 + 15) >> 4 : 0;   // banded patch: see conv_wgrad_pl_kernel
+      const int nbp = band_pitch > 0 ? 3 * nbb : (phi + max_tap_off - plo + 1 + 15) >> 4;
       unsigned char* const dX = sX + buf * xb_bytes;
       unsigned char* const dD = sD + buf * DB;
       for (int i = 0; i < NI; ++i) {
@@ -869,8 +871,14 @@ __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_pl2_kernel(
         b = b < 2 * nbp + DBLK ? b : 2 * nbp + DBLK - 1;
         if (b < 2 * nbp) {
           const int pl = b >= nbp ? 1 : 0;
-          const int j = b - pl * nbp;
-          const int r0 = plo + j * 16;
+          int j = b - pl * nbp;
+          int r0 = plo + j * 16;
+          if (band_pitch > 0) {
+            const int band = (j >= nbb ? 1 : 0) + (j >= 2 * nbb ? 1 : 0);
+            const int jb = j - band * nbb;
+            r0 = plo + band * band_stride + jb * 16;
+            j = band * (band_pitch >> 4) + jb;
+          }
           const unsigned char* src;
           uint32_t vo = lane_x;
           if (r0 + 15 < in_pixels) {
@@ -919,7 +927,7 @@ __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_pl2_kernel(
 #pragma unroll
       for (int ks = 1; ks < NKS; ++ks) asm volatile("" : "+v"(pb[ks]));
       const int plo = __builtin_amdgcn_readfirstlane(s_pin[(kt & (NTAB - 1)) * WD_BM]);
-      const uint32_t xbase = sXo + buf * xb_bytes + wn * plane_bytes + (toff0 - plo) * 64 + tsub;
+      const uint32_t xbase = sXo + buf * xb_bytes + wn * plane_bytes + ((band_pitch > 0 ? tg * band_pitch : toff0) - plo) * 64 + tsub;
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
         pb[ks][0] = xbase + (pb[ks][0] << 6);
@@ -1206,13 +1214,13 @@ int iic_wgrad_dma_launch(const iic_conv_geom* g, const void* x, const void* dy, 
     }                                                                                           \
     hipLaunchKernelGGL((conv_wgrad_pl2_kernel<COT_, BMK_, NBUF_, TXS_, SWP_, NTAB_>), grid,     \
                        dim3(WD_THREADS), ldsp, s, *g, (const bf16_t*)x, (const bf16_t*)dy,      \
-                       partials, nsplit, kt, plane, mto, g_wd_ablate);                          \
+                       partials, nsplit, kt, plane, mto, g_wd_ablate, pband, bstride);          \
   } while (0)
 #ifdef IIC_DEBUG_HOOKS
 #define WDP_LAUNCH2(COT_, BMK_, NBUF_, TXS_, NTAB_)                                              \
   do {                                                                                          \
-    if (pband == 0 && (g_wd_planar == 4 || (g_wd_planar == 5 && COT_ == 64))) WDP2_LAUNCH3(COT_, BMK_, NBUF_, TXS_, true, NTAB_); \
-    else if (pband == 0 && g_wd_planar == 3) WDP2_LAUNCH3(COT_, BMK_, NBUF_, TXS_, false, NTAB_); \
+    if (g_wd_planar == 4 || (g_wd_planar == 5 && COT_ == 64)) WDP2_LAUNCH3(COT_, BMK_, NBUF_, TXS_, true, NTAB_); \
+    else if (g_wd_planar == 3) WDP2_LAUNCH3(COT_, BMK_, NBUF_, TXS_, false, NTAB_);             \
     else if (g_wd_planar == 1) WDP_LAUNCH3(COT_, BMK_, NBUF_, TXS_, false, NTAB_);              \
     else WDP_LAUNCH3(COT_, BMK_, NBUF_, TXS_, true, NTAB_);                                     \
   } while (0)
