@@ -2,7 +2,7 @@
 # (rocprofv3 --kernel-trace of tools/wgrad_pl_ab.py, planar asm variant only; the tool times 23 launches per code in order)
 R=$GRAFT_REPO_ROOT; L="$1"; A="${2:-0,1,2,3,4}"
 cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/wtr
-WGRAD_ONLY="$L" WGRAD_VARIANTS=2 WGRAD_ABL=$A timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/wtr -o p -- python $R/tools/wgrad_pl_ab.py > /tmp/wtr.log 2>&1
+WGRAD_ONLY="$L" WGRAD_VARIANTS=${WGRAD_TRACE_VARIANT:-2} WGRAD_ABL_VARIANT=${WGRAD_TRACE_VARIANT:-2} WGRAD_ABL=$A timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/wtr -o p -- python $R/tools/wgrad_pl_ab.py > /tmp/wtr.log 2>&1
 tail -3 /tmp/wtr.log
 python3 - "$A" <<'P'
 import csv, glob, sys
