@@ -1168,6 +1168,20 @@ static int wdp_config(const iic_conv_geom* g, int* bmk, int* nbuf, int* ntab, in
   return 0;
 }
 
+#ifdef IIC_DEBUG_HOOKS
+// Which weight-gradient kernel / layout a 3 x 3 geometry gets (tests: a layer must not fall off the planar kernels by a
+// few bytes of LDS unnoticed -- SegmentationNet10a c3 / c4 did, by 64): 0 = register-staged (conv_wgrad.hip),
+// 1 = first-generation DMA kernel, 2 = planar, 3 = planar with the banded patch; + 100 * K-tile pixels + 10000 * ring
+// depth + 100000 * table ring.
+IIC_HOOK int iic_debug_wgrad_config(const iic_conv_geom* g) {
+  int bmk = 0, nbuf = 0, ntab = 0, band = 0;
+  if (!g || !g_wd_enabled) return 0;
+  if (wdp_config(g, &bmk, &nbuf, &ntab, &band)) return (band > 0 ? 3 : 2) + 100 * bmk + 10000 * nbuf + 100000 * ntab;
+  if (wd_config(g, &bmk, &nbuf)) return 1 + 100 * bmk + 10000 * nbuf + 100000 * WD_NTAB;
+  return 0;
+}
+#endif
+
 // used by conv_wgrad.hip's dispatcher
 int iic_wgrad_dma_supported(const iic_conv_geom* g) {
   int bmk, nbuf, ntab, band;
