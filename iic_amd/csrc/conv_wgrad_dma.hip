@@ -1034,6 +1034,230 @@ __global__ __launch_bounds__(WD_THREADS) void conv_wgrad_pl2_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Block-tiled form for large images (round 6, LAB.md R6.13): a K-tile is a 2-D block of bw x bh <= 128 OUTPUT pixels of
+// one image instead of 128 consecutive pixels of the row-major numbering.  The input patch of a tile is then the
+// (bw + 2 dx) x (bh + 2 dy) pixel sub-image under the block -- 1.5-1.9 x the pixels used instead of the 3.4-7.6 x of a
+// contiguous span (banded: 3.4-3.75 x) on 100-200-pixel image rows, dilated taps included -- and EVERY address of the loop
+// is a tile base + a per-lane constant: patch row of output (ky, kx), tap (ty, tx) = (ky + ty dy) PW + kx + tx dx, DMA
+// source of patch row (py, px) = tile pixel + py in_Wp + px, dY row of (ky, kx) = tile pixel + ky out_Wp + kx.  No row
+// tables, no walkers; per tile: a uniform tile decode, the DMA issue and 16 adds for the buffer switch.  Rows of a block
+// past the image edge (or past bw x bh) take their dY from pixel 0 of the PT tensor (zero border) and read whatever input
+// pixel lies there (finite x 0).  Same work split per wave, same partial-sum layout as the planar kernels; the summation
+// ORDER over pixels differs from theirs (so do the last bits).  Stride-1 3 x 3 taps on a regular grid, COT = 128 only.
+#define WDB_MAXNI 6
+struct wdb_args {
+  int bw, bh, nbx, nby;           // block size, blocks per image row / column
+  int PW, NPR, drow;              // patch width, patch pixels, tap-row distance in image rows
+  int plane_bytes, num_tiles;
+};
+
+template <int TXS>
+__global__ __launch_bounds__(WD_THREADS) void conv_wgrad_b2d_kernel(
+    const iic_conv_geom g, const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+    float* __restrict__ partials, int nsplit, const wdb_args A, int abl) {
+  constexpr int COT = 128, CS = 2, NW = WD_THREADS / 64, DROW = COT * 2, WD_BM = 128;
+  constexpr int DB = WD_BM * DROW, DBLK = DB / 1024, NKS = WD_BM / 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  typedef unsigned char __attribute__((address_space(3))) * lds_u8_ptr;
+  const int plane_bytes = A.plane_bytes, xb_bytes = 2 * plane_bytes;
+  unsigned char* const sX = smem_raw;                        // [2][2 planes][plane_bytes]
+  unsigned char* const sD = smem_raw + 2 * xb_bytes;         // [2][DB]
+  const uint32_t sXo = (uint32_t)(uintptr_t)(lds_u8_ptr)sX, sDo = (uint32_t)(uintptr_t)(lds_u8_ptr)sD;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tg = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+  const int l31 = lane & 31;
+  const int q = lane >> 4, i16 = lane & 15;
+  const int ncit = g.Cin >> 6;
+  int tile, split;
+  wdp_xcd_map(tile, split);
+  const int cot = tile / ncit, cit = tile - cot * ncit;
+  const int co0 = cot * COT, ci0 = cit * 64;
+  const int per = (A.num_tiles + nsplit - 1) / nsplit;
+  const int kt0 = split * per;
+  const int kt1 = min(A.num_tiles, kt0 + per);
+  const int in_pixels = g.N * g.in_Hp * g.in_Wp;
+  const int tfirst = tg * 3;
+  const int bw = A.bw, bh = A.bh, PW = A.PW, nrows = bw * bh;
+
+  const int trow = 8 * (q >> 1) + (i16 >> 2);
+  const int tsub = (2 * (q & 1) + ((i16 & 3) >> 1)) * 16 + (i16 & 1) * 8;
+  uint32_t aoff[CS];
+#pragma unroll
+  for (int c = 0; c < CS; ++c) aoff[c] = trow * DROW + (((wm * 2 + c) ^ (trow & 3)) * 64) + tsub;
+  // this lane's K rows -> patch rows (relative to the buffer): 64 * ((ky + ty drow) PW + kx) in the wave's plane
+  // (absolute LDS addresses for buffer 0; the loop moves them to the other buffer and back in place)
+  uint32_t pb0[NKS], pb1[NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+      int k = ks * 16 + trow + 4 * rd;
+      k = k < nrows ? k : nrows - 1;              // rows past the block: dY is zero there, any patch row will do
+      const int ky = k / bw, kx = k - ky * bw;
+      const uint32_t v = sXo + (uint32_t)(((ky + tg * A.drow) * PW + kx) * 64) + wn * plane_bytes + tsub;
+      if (rd) pb1[ks] = v; else pb0[ks] = v;
+    }
+  }
+  // DMA roles of this wave's instruction slots (static): patch block (plane, 16 patch pixels) or dY block (4 rows)
+  const int nbp = (A.NPR + 15) >> 4;
+  const int total = 2 * nbp + DBLK;
+  const int NI = (total + NW - 1) / NW;             // <= WDB_MAXNI (host)
+  const uint32_t dyrb = (uint32_t)g.Cout * 2u;
+  const int drow_l = lane >> 4;
+  const uint32_t lane_d = (uint32_t)(((lane & 15) ^ ((drow_l & 3) << 2)) * 16);
+  // byte offset from the tile's first input pixel / first dY pixel (0xffffffff: a dY row past the block, never valid);
+  // the rare paths (a tile that touches the end of the tensor / the image edge) re-derive (py, px) / (ky, kx)
+  uint32_t voff[WDB_MAXNI];
+  // (`launder` keeps the rare paths' lane arithmetic out of the loop-invariant registers: the kernel sits at the
+  //  3-waves-per-SIMD register limit)
+  auto launder = [](int v) { asm volatile("" : "+v"(v)); return v; };
+  auto patch_pixel = [&](int j) {                  // pixel offset of this lane's patch row in block j
+    int r = j * 16 + (launder(lane) >> 2);
+    r = r < A.NPR ? r : A.NPR - 1;
+    const int py = r / PW;
+    return py * g.in_Wp + (r - py * PW);
+  };
+#pragma unroll
+  for (int i = 0; i < WDB_MAXNI; ++i) {
+    int b = wave + i * NW;
+    b = b < total ? b : total - 1;
+    if (b < 2 * nbp) {
+      const int pl = b >= nbp ? 1 : 0, j = b - pl * nbp;
+      voff[i] = (uint32_t)patch_pixel(j) * (uint32_t)(g.Cin * 2) + (lane & 3) * 16 + pl * 64;
+    } else {
+      const int k = (b - 2 * nbp) * 4 + drow_l;
+      const int ky = k / bw, kx = k - ky * bw;
+      voff[i] = k < nrows ? (uint32_t)(ky * g.out_Wp + kx) * dyrb + lane_d : 0xffffffffu;
+    }
+  }
+  const unsigned char* const xg = reinterpret_cast<const unsigned char*>(x) + (long)ci0 * 2;
+  const unsigned char* const dg = reinterpret_cast<const unsigned char*>(dy) + (long)co0 * 2;
+  const int tpi = A.nbx * A.nby;                   // tiles per image
+
+  f32x16 acc[3][CS];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int c = 0; c < CS; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][c][r] = 0.f;
+
+  if (kt0 < kt1) {
+    // uniform tile cursor (image, block row, block column) of the NEXT tile to fetch
+    int cn = kt0 / tpi, crem = kt0 - cn * tpi;
+    int cby = crem / A.nbx, cbx = crem - cby * A.nbx;
+    auto dma_issue = [&](int buf) {                // fetches the cursor's tile, then advances the cursor
+      const int y0 = cby * bh, x0 = cbx * bw;
+      const int pin0 = (cn * g.in_Hp + y0 + g.oy) * g.in_Wp + x0 + g.ox;
+      const int pout0 = (cn * g.out_Hp + y0 + g.py) * g.out_Wp + x0 + g.px;
+      const bool inside = pin0 + (A.NPR / PW) * g.in_Wp + PW < in_pixels;     // (whole patch before the tensor's end)
+      const int bhv = min(bh, g.MY - y0), bwv = min(bw, g.MX - x0);
+      const bool full = bhv == bh && bwv == bw;
+      const uint32_t dbase = (uint32_t)pout0 * dyrb;
+      unsigned char* const dX = sX + buf * xb_bytes;
+      unsigned char* const dD = sD + buf * DB;
+#pragma unroll
+      for (int i = 0; i < WDB_MAXNI; ++i) {
+        if (i < NI) {
+          int b = wave + i * NW;
+          b = b < total ? b : total - 1;
+          if (b < 2 * nbp) {
+            const int pl = b >= nbp ? 1 : 0, j = b - pl * nbp;
+            const unsigned char* src = xg + ((long)pin0 * g.Cin) * 2;
+            uint32_t vo = voff[i];
+            if (!inside) {                         // the last image's last blocks: pixels past the tensor re-read its last one
+              int pix = pin0 + patch_pixel(j);
+              pix = pix < in_pixels ? pix : in_pixels - 1;
+              src = xg;
+              vo = (uint32_t)pix * (uint32_t)(g.Cin * 2) + (launder(lane) & 3) * 16 + pl * 64;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)vo),
+                                             (__attribute__((address_space(3))) void*)(dX + pl * plane_bytes + j * 1024),
+                                             16, 0, 0);
+          } else {
+            const int bd = b - 2 * nbp;
+            bool valid = voff[i] != 0xffffffffu;
+            if (!full) {                           // a block at the image's right / bottom edge
+              const int k = bd * 4 + (launder(lane) >> 4);
+              const int ky = k / bw, kx = k - ky * bw;
+              valid = valid && ky < bhv && kx < bwv;
+            }
+            const uint32_t vo = valid ? dbase + voff[i] : lane_d;      // pixel 0 of the PT tensor: zero border
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dg + (size_t)vo),
+                                             (__attribute__((address_space(3))) void*)(dD + bd * 1024), 16, 0, 0);
+          }
+        }
+      }
+      if (++cbx == A.nbx) { cbx = 0; if (++cby == A.nby) { cby = 0; ++cn; } }
+    };
+    dma_issue(0);
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const int b = (kt - kt0) & 1;
+      if (!(abl & 4)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+      if (kt + 1 < kt1 && !(abl & 1)) dma_issue(b ^ 1);
+      uint32_t ab[CS];
+      if (kt > kt0) {                              // the read addresses move to the other patch buffer
+        const uint32_t d = b ? (uint32_t)xb_bytes : (uint32_t)(-xb_bytes);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          pb0[ks] += d;
+          pb1[ks] += d;
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(pb0[ks]), "+v"(pb1[ks]));
+#pragma unroll
+      for (int c = 0; c < CS; ++c) {
+        ab[c] = sDo + b * DB + aoff[c];
+        asm volatile("" : "+v"(ab[c]));
+      }
+      auto step = [&](auto KS) {
+        constexpr int ks = decltype(KS)::value;
+        bf16x8 a[CS], bfr[3];
+#pragma unroll
+        for (int c = 0; c < CS; ++c) a[c] = wdp_frag_pair<ks * 16 * DROW, 4 * DROW, true>(ab[c]);
+        bfr[0] = wdp_frag<0, true>(pb0[ks], pb1[ks]);
+        bfr[1] = wdp_frag<64 * TXS, true>(pb0[ks], pb1[ks]);
+        bfr[2] = wdp_frag<128 * TXS, true>(pb0[ks], pb1[ks]);
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a[0]), "+v"(a[1]), "+v"(bfr[0]));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < CS; ++c)
+          acc[0][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[c], bfr[0], acc[0][c], 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bfr[1]));
+#pragma unroll
+        for (int c = 0; c < CS; ++c)
+          acc[1][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[c], bfr[1], acc[1][c], 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bfr[2]));
+#pragma unroll
+        for (int c = 0; c < CS; ++c)
+          acc[2][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[c], bfr[2], acc[2][c], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      if (!(abl & 2)) wdp_unroll<NKS>(step);
+    }
+  }
+  if (abl & 8) return;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    float* dst = partials + (((long)split * g.ntaps + (tfirst + t)) * g.Cout + co0) * g.Cin + ci0;
+#pragma unroll
+    for (int c = 0; c < CS; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * (COT / 2) + c * 32 + mfma32_row(r, lane);
+        const int col = wn * 32 + l31;
+        dst[(long)row * g.Cin + col] = acc[t][c][r];
+      }
+  }
+}
+
 static long wdp_plane_bytes(int np) { return (((long)np * 64) + 1023) & ~1023L; }
 static long wdp_lds(int np, int cot, int bmk, int nbuf, int ntab) {
   return nbuf * (2 * wdp_plane_bytes(np) + (long)bmk * cot * 2) + (long)ntab * bmk * 8;
@@ -1168,6 +1392,54 @@ static int wdp_config(const iic_conv_geom* g, int* bmk, int* nbuf, int* ntab, in
   return 0;
 }
 
+// Block-tiled kernel (conv_wgrad_b2d_kernel): block shape by exhaustive search -- the fewest 128-row tiles per image, then
+// the smallest patch.  0 = not applicable.  mode (g_wd_b2d): 2 (default) = wherever it applies (every layer of
+// profiles/r06_wgrad_b2d_ab.txt is faster on it: 1.08-1.42 x), 1 = only where the planar kernels would need the 64-pixel
+// ring or bands, 0 = off.
+IIC_SWITCH(g_wd_b2d, 2, iic_debug_wgrad_b2d)
+static int wdb_config(const iic_conv_geom* g, wdb_args* A) {
+  if (!g_wd_b2d || !g_wd_enabled || g->ntaps != 9 || g->Cin % 64 != 0 || g->Cout % 128 != 0) return 0;
+  if (g->sy != 1 || g->sx != 1 || g->ty != 1 || g->tx != 1) return 0;
+  const int txs = wdp_txs(g);
+  if (!txs) return 0;
+  const int rowoff = g->tap_off[3] - g->tap_off[0];
+  if (rowoff <= 0 || rowoff % g->in_Wp != 0 || g->tap_off[6] - g->tap_off[3] != rowoff || g->tap_off[0] != 0) return 0;
+  const int drow = rowoff / g->in_Wp;
+  if ((long)g->N * g->out_Hp * g->out_Wp * g->Cout * 2 >= (1L << 32)) return 0;
+  if ((long)g->N * g->in_Hp * g->in_Wp * g->Cin * 2 >= (1L << 32)) return 0;       // 32-bit patch offsets (end-of-tensor path)
+  // small images: blocks within one image waste rows, and at 25 x 25 (ClusterNet5g layer 2: 5 x 25 blocks, 3 % faster
+  // alone) the step measured 0.1 ms slower (profiles/r06_wgrad_b2d_ab.txt) -- those stay on the planar kernels
+  if (g->MY < 32 || g->MX < 32) return 0;
+  // block shape: tiles x (MFMA time of a tile + half its DMA bytes, in units of a 64-KB tile) over the shapes that fit
+  double best = -1.0;
+  long best_tiles = 0;
+  int best_bw = 0;
+  for (int bw = 4; bw <= 64 && bw <= g->MX; ++bw) {
+    const int bh = 128 / bw;
+    if (bh < 1 || bh > g->MY) continue;
+    const long tiles = (long)((g->MX + bw - 1) / bw) * ((g->MY + bh - 1) / bh);
+    const int patch = (bw + 2 * txs) * (bh + 2 * drow);
+    const long plane = wdp_plane_bytes(patch);
+    if ((2 * ((patch + 15) >> 4) + 32 + 11) / 12 > WDB_MAXNI) continue;
+    if (2L * (2L * plane + 128 * 256) > 160 * 1024) continue;
+    const double cost = (double)tiles * (1.0 + 0.5 * ((double)patch * 128.0 + 32768.0) / 65536.0);
+    if (best < 0 || cost < best) { best = cost; best_tiles = tiles; best_bw = bw; }
+  }
+  if (best < 0) return 0;
+  A->bw = best_bw; A->bh = 128 / best_bw;
+  A->nbx = (g->MX + A->bw - 1) / A->bw; A->nby = (g->MY + A->bh - 1) / A->bh;
+  if ((double)g->MY * g->MX < 0.88 * 128.0 * (double)best_tiles) return 0;        // > 12 % idle rows: not worth it
+  A->PW = A->bw + 2 * txs; A->drow = drow;
+  A->NPR = A->PW * (A->bh + 2 * drow);
+  A->plane_bytes = (int)wdp_plane_bytes(A->NPR);
+  A->num_tiles = (int)(best_tiles * g->N);
+  if (g_wd_b2d == 1) {                             // only where the planar kernels fall off their 128-pixel contiguous layout
+    int bmk, nbuf, ntab, band;
+    if (wdp_config(g, &bmk, &nbuf, &ntab, &band) && bmk == 128 && band == 0) return 0;
+  }
+  return 1;
+}
+
 #ifdef IIC_DEBUG_HOOKS
 // Which weight-gradient kernel / layout a 3 x 3 geometry gets (tests: a layer must not fall off the planar kernels by a
 // few bytes of LDS unnoticed -- SegmentationNet10a c3 / c4 did, by 64): 0 = register-staged (conv_wgrad.hip),
@@ -1176,6 +1448,8 @@ static int wdp_config(const iic_conv_geom* g, int* bmk, int* nbuf, int* ntab, in
 IIC_HOOK int iic_debug_wgrad_config(const iic_conv_geom* g) {
   int bmk = 0, nbuf = 0, ntab = 0, band = 0;
   if (!g || !g_wd_enabled) return 0;
+  wdb_args A;
+  if (wdb_config(g, &A)) return 4 + 100 * 128 + 10000 * 2 + 1000000 * A.bw;      // 4 = block-tiled (+ 1e6 * block width)
   if (wdp_config(g, &bmk, &nbuf, &ntab, &band)) return (band > 0 ? 3 : 2) + 100 * bmk + 10000 * nbuf + 100000 * ntab;
   if (wd_config(g, &bmk, &nbuf)) return 1 + 100 * bmk + 10000 * nbuf + 100000 * WD_NTAB;
   return 0;
@@ -1185,7 +1459,8 @@ IIC_HOOK int iic_debug_wgrad_config(const iic_conv_geom* g) {
 // used by conv_wgrad.hip's dispatcher
 int iic_wgrad_dma_supported(const iic_conv_geom* g) {
   int bmk, nbuf, ntab, band;
-  return g_wd_enabled && (wdp_config(g, &bmk, &nbuf, &ntab, &band) || wd_config(g, &bmk, &nbuf));
+  wdb_args A;
+  return g_wd_enabled && (wdb_config(g, &A) || wdp_config(g, &bmk, &nbuf, &ntab, &band) || wd_config(g, &bmk, &nbuf));
 }
 
 int iic_wgrad_dma_launch(const iic_conv_geom* g, const void* x, const void* dy, float* partials,
@@ -1196,6 +1471,23 @@ int iic_wgrad_dma_launch(const iic_conv_geom* g, const void* x, const void* dy, 
   for (int i = 0; i < g->ntaps; ++i) mto = g->tap_off[i] > mto ? g->tap_off[i] : mto;
   dim3 grid((g->Cout / cot) * (g->Cin / 64), nsplit);
   hipStream_t s = (hipStream_t)stream;
+  wdb_args BA;
+  if (wdb_config(g, &BA)) {                            // block-tiled kernel (large images)
+    const long ldsb = 2L * (2L * BA.plane_bytes + 128 * 256);
+#define WDB_LAUNCH(TXS_)                                                                          \
+  do {                                                                                          \
+    static bool attr = false;                                                                   \
+    if (!attr) {                                                                                \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_b2d_kernel<TXS_>),    \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);        \
+      attr = true;                                                                              \
+    }                                                                                           \
+    hipLaunchKernelGGL((conv_wgrad_b2d_kernel<TXS_>), grid, dim3(WD_THREADS), ldsb, s, *g,      \
+                       (const bf16_t*)x, (const bf16_t*)dy, partials, nsplit, BA, g_wd_ablate); \
+  } while (0)
+    if (wdp_txs(g) == 1) WDB_LAUNCH(1); else WDB_LAUNCH(2);
+    return iic_launch_status();
+  }
   int pbmk = 0, pnbuf = 0, pntab = 0, pband = 0;
   if (wdp_config(g, &pbmk, &pnbuf, &pntab, &pband)) {  // planar-patch kernels
     const int txs = wdp_txs(g);
