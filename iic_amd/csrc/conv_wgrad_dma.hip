@@ -7,6 +7,8 @@
 //                                         128-cout tiles
 //   conv_wgrad_pl2_kernel   (round 6)     planar patch + per-tile work off the critical path + software-pipelined
 //                                         k-steps; the default for 64-cout tiles
+//   conv_wgrad_b2d_kernel   (round 6)     block-tiled K for images >= 32 pixels (a K-tile = a 2-D block of output pixels;
+//                                         its own summation order): the large-image layers of SegmentationNet10a
 // (see the comments at each kernel and LAB.md R6.8).  First generation: same math and work split as
 // conv_wgrad.hip,
 //   dW[t][co][ci] = sum_m dY[pout(m)][co] * X[pin(m) + tap_off[t]][ci],
