@@ -34,6 +34,18 @@ __device__ __forceinline__ void bd_bwait(u32x4& d) {
   asm volatile("s_waitcnt vmcnt(%1)" : "+v"(d) : "i"(N) : "memory");
 }
 
+// Block tiling (round 6, LAB.md R6.14; the weight gradient's form: conv_wgrad_dma.hip conv_wgrad_b2d_kernel): a 256-row tile
+// is a 2-D block of bw x bh OUTPUT pixels of one image instead of 256 consecutive rows of the row-major numbering, and
+// its LDS patch the (bw + max tap dx) x (bh + max tap dy) sub-image under it -- for 100-200-pixel image rows and dilated
+// taps 1.3-1.6 x the pixels used instead of 2.7-2.8 x, so the 64-KB patches of SegmentationNet10a's c2 / c5 / c6 shrink to
+// 41-51 KB (two workgroups per CU again).  Everything behind the patch loader works in PATCH coordinates: the row
+// table holds ky * PW + kx, the tap offsets become iy * PW + ix, the swizzle key counts patch rows.  Which tile computes
+// an output row changes; the row's own accumulation order does not: outputs are bit-identical to the row-major tiles.
+struct bd_blk {
+  int bw, bh, nbx, nby;      // bw == 0: row-major tiles
+  int PW, npix, mul;         // patch width, patch pixels, ceil(65536 / PW) (patch row / PW by multiply-shift)
+};
+
 #define BD_BM 256
 #define BD_BN 128
 #define BD_THREADS 256
@@ -74,8 +86,11 @@ __device__ __forceinline__ void bd_tile(
     const bf16_t* __restrict__ res_act, int accumulate, int lds_a_bytes,
     int dense_key, const bf16_t* __restrict__ red_y, const float* __restrict__ red_coef,
     const bf16_t* __restrict__ red_y2, float* __restrict__ red_stats, float* __restrict__ red_stats2,
-    unsigned long long* __restrict__ prof, int stagger, int blk_in_class, int nwg_class, int m_base) {
+    unsigned long long* __restrict__ prof, int stagger, int blk_in_class, int nwg_class, int m_base,
+    const bd_blk& B) {
   constexpr int BNT = WN * 64, NWM = 4 / WN;   // tile couts, wave row groups
+  constexpr bool CANBLK = !GATHER && DMA && MS == 4 && WN == 2;
+  const bool blk = CANBLK && B.bw > 0;         // uniform
   constexpr int CLD = BNT + 8;
   constexpr bool PROF = (ABL & 128) != 0;
   constexpr bool NEWORD = (ABL & 256) == 0;     // ABL bit 256: the round-2 K-loop order (A/B runs)
@@ -122,22 +137,44 @@ __device__ __forceinline__ void bd_tile(
   const int m0 = m_base + mtile * BM;
   const int in_pixels = g.N * g.in_Hp * g.in_Wp;
 
-  const int v_tapoff = g.tap_off[lane & (IIC_MAX_TAPS - 1)];
+  int v_tapoff = g.tap_off[lane & (IIC_MAX_TAPS - 1)];
   const int v_tapw = g.tap_w[lane & (IIC_MAX_TAPS - 1)];
-
-  if (tid < BM) {
+  // block tiling: this tile's image and block, its first input pixel (tap 0), whether the block is whole
+  int blk_glo = 0;
+  bool blk_full = true;
+  if (blk) {
+    const int tpi = B.nbx * B.nby;
+    const int bn = mtile / tpi, brem = mtile - bn * tpi;
+    const int by = brem / B.nbx, bx = brem - by * B.nbx;
+    const int y0 = by * B.bh, x0 = bx * B.bw;
+    blk_glo = (bn * g.in_Hp + y0 + g.oy) * g.in_Wp + x0 + g.ox;
+    blk_full = y0 + B.bh <= g.MY && x0 + B.bw <= g.MX && B.bw * B.bh == BM;
+    v_tapoff = (v_tapoff / g.in_Wp) * B.PW + v_tapoff % g.in_Wp;        // tap offsets in patch rows
+    if (tid < BM) {
+      int ky = tid / B.bw;
+      const int kx = tid - ky * B.bw;
+      const int y = y0 + ky, x = x0 + kx;
+      const bool valid = ky < B.bh && y < g.MY && x < g.MX;
+      ky = ky < B.bh ? ky : B.bh - 1;                                    // (rows past the block: any patch row)
+      s_pin[tid] = ky * B.PW + kx;
+      s_pout[tid] = valid ? (bn * g.out_Hp + y + g.py) * g.out_Wp + x + g.px : -1;
+    }
+  } else if (tid < BM) {
     int pin, pout;
     igemm_row_pixels(g, m0 + tid, pin, pout);
     s_pin[tid] = pin;
     s_pout[tid] = pout;
   }
   __syncthreads();
-  const int p_lo = s_pin[0];
-  const int npix = GATHER ? BM : (BM >= 192 ? g.NP256 : g.NP);    // (192-row tiles: bound checked by the host)
+  const int p_lo = blk ? 0 : s_pin[0];
+  const int npix = GATHER ? BM : (blk ? B.npix : (BM >= 192 ? g.NP256 : g.NP));    // (192-row tiles: bound checked by the host)
   // swizzle key of a pixel (see the header): D = p - J * (p / in_Wp); J must be even so that D keeps
   // the row parity (the 128-B half of the 256-B bank window is the physical row parity)
-  const int jskip = (dense_key && !GATHER && g.sx == 1 && ((g.in_Wp - g.MX) & 1) == 0) ? g.in_Wp - g.MX : 0;
-  auto dense_of = [&](int p) { return p - jskip * (p / g.in_Wp); };
+  // (block tiling: the same in patch coordinates -- row pitch PW, J = PW - bw, even by the host's choice)
+  const int keyw = blk ? B.PW : g.in_Wp;
+  const int jskip = blk ? B.PW - B.bw
+                        : ((dense_key && !GATHER && g.sx == 1 && ((g.in_Wp - g.MX) & 1) == 0) ? g.in_Wp - g.MX : 0);
+  auto dense_of = [&](int p) { return p - jskip * (p / keyw); };
   int arow[MS];     // !DMA: byte offset of the lane's row (tap 0) + k-chunk; DMA: patch row index
   int drow[MS];     // DMA: D of the lane's row at tap offset 0
 #pragma unroll
@@ -152,22 +189,27 @@ __device__ __forceinline__ void bd_tile(
     __syncthreads();
   }
   // per-tap increment of D: tap_off = dy * in_Wp + dx  ->  dy * (in_Wp - J) + dx
-  const int v_tapd = v_tapoff - jskip * (v_tapoff / g.in_Wp);
+  const int v_tapd = v_tapoff - jskip * (v_tapoff / keyw);
   // DMA patch loader: 1-KB blocks over the 4 waves; piece q -> LDS byte q*16 (row q>>3, physical
   // slot q&7), source = logical slot (q&7) ^ ((row>>1)&7) of the row's pixel
   const int nblk = (npix * 128 + 1023) >> 10;
   auto dma_patch = [&](int c0) {
-    for (int blk = wave; blk < nblk; blk += BD_THREADS / 64) {
-      const int q = blk * 64 + lane;
+    for (int kb = wave; kb < nblk; kb += BD_THREADS / 64) {
+      const int q = kb * 64 + lane;
       const int r = q >> 3;
       const int ls = (q & 7) ^ (GATHER ? ((r >> 1) & 7)
                                        : (jskip != 0 ? (int)s_key[r < npix ? r : npix - 1]
                                                      : (((p_lo + r) >> 1) & 7)));
       long p = GATHER ? (long)s_pin[r < BM ? r : BM - 1] : (long)p_lo + r;
+      if (blk) {                                   // patch row r = (py, px) of the sub-image under the block
+        const int rc = r < npix ? r : npix - 1;
+        const int py = (rc * B.mul) >> 16;
+        p = (long)blk_glo + py * g.in_Wp + (rc - py * B.PW);
+      }
       p = p < in_pixels ? p : in_pixels - 1;
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)(in + (p * g.Cin + c0 + ls * 8)),
-          (__attribute__((address_space(3))) void*)(sA + blk * 1024), 16, 0, 0);
+          (__attribute__((address_space(3))) void*)(sA + kb * 1024), 16, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
@@ -359,7 +401,7 @@ __device__ __forceinline__ void bd_tile(
     if (t == 123.f) out[0] = 1;
     return;
   }
-  const bool tail = igemm_tile_has_invalid(g, m0, BM);
+  const bool tail = blk ? !blk_full : igemm_tile_has_invalid(g, m0, BM);
   if (stats && !(ABL & 64)) {
     if (tail) {       // rows past the end / in the row padding do not count
 #pragma unroll
@@ -449,19 +491,20 @@ __global__ __launch_bounds__(BD_THREADS, ((MS == 4 || MS2 != 0 || WN == 1) ? 2 :
     const bf16_t* __restrict__ res_act, int accumulate, int num_mtiles, int lds_a_bytes,
     int dense_key, const bf16_t* __restrict__ red_y, const float* __restrict__ red_coef,
     const bf16_t* __restrict__ red_y2, float* __restrict__ red_stats, float* __restrict__ red_stats2,
-    unsigned long long* __restrict__ prof, int stagger, int n_big, int m_split) {
+    unsigned long long* __restrict__ prof, int stagger, int n_big, int m_split, const bd_blk B) {
+  const bd_blk B0 = {0, 0, 0, 0, 0, 0, 0};
   if (WN == 1) {
     bd_tile<GATHER, ABL, DMA, MS, RED, 1>(g, in, wfrag, out, stats, res_grad, res_act, accumulate, lds_a_bytes,
                                           dense_key, red_y, red_coef, red_y2, red_stats, red_stats2, prof, stagger,
-                                          (int)blockIdx.x, num_mtiles * (g.Cout / 64), 0);
+                                          (int)blockIdx.x, num_mtiles * (g.Cout / 64), 0, B0);
   } else if (MS2 == 0 || (int)blockIdx.x < n_big) {
     bd_tile<GATHER, ABL, DMA, MS, RED>(g, in, wfrag, out, stats, res_grad, res_act, accumulate, lds_a_bytes,
                                        dense_key, red_y, red_coef, red_y2, red_stats, red_stats2, prof, stagger,
-                                       (int)blockIdx.x, MS2 == 0 ? num_mtiles * (g.Cout / BD_BN) : n_big, 0);
+                                       (int)blockIdx.x, MS2 == 0 ? num_mtiles * (g.Cout / BD_BN) : n_big, 0, MS2 == 0 ? B : B0);
   } else {
     bd_tile<GATHER, ABL, DMA, (MS2 == 0 ? MS : MS2), RED>(
         g, in, wfrag, out, stats, res_grad, res_act, accumulate, lds_a_bytes, dense_key, red_y, red_coef, red_y2,
-        red_stats, red_stats2, prof, stagger, (int)blockIdx.x - n_big, (int)gridDim.x - n_big, m_split);
+        red_stats, red_stats2, prof, stagger, (int)blockIdx.x - n_big, (int)gridDim.x - n_big, m_split, B0);
   }
 }
 
@@ -584,6 +627,49 @@ int iic_conv_igemm_frag_red(const iic_conv_geom* g, const void* in, const void* 
                             float* red_stats, float* red_stats2, void* stream);
 
 /* 1 if iic_conv_igemm_frag_red can fuse a reduction into this geometry's launch. */
+// Block tiling of the 256-row tiles (see bd_blk): stride-1 multi-tap launches on images of at least 32 pixels whose
+// row-major 256-row patch is too big for two workgroups per CU, where the sub-image patch is not.  Block shape: fewest
+// tiles x (MFMA time + half the patch bytes), over shapes whose patch keeps two workgroups per CU.
+IIC_SWITCH(g_bd_blk, 1, iic_debug_bd_blk)       // 0: row-major tiles only; 2: block tiles wherever they apply (A/B)
+static int bd_block_config(const iic_conv_geom* g, bd_blk* B) {
+  B->bw = 0;
+  if (!g_bd_blk || !g_bd_dma || g->ntaps < 2 || g->Cout % BD_BN != 0 || g->Cin % 64 != 0) return 0;
+  if (g->sy != 1 || g->sx != 1 || g->ty != 1 || g->tx != 1 || g->MY < 32 || g->MX < 32 || g->NP256 <= 0) return 0;
+  int mix = 0, miy = 0;
+  for (int t = 0; t < g->ntaps; ++t) {
+    const int iy = g->tap_off[t] / g->in_Wp, ix = g->tap_off[t] % g->in_Wp;
+    if (ix > 8 || iy > 8) return 0;               // (taps on a small grid)
+    mix = ix > mix ? ix : mix;
+    miy = iy > miy ? iy : miy;
+  }
+  if (mix & 1) return 0;                          // swizzle key: the row-end skip of a patch row must be even
+  double best = -1.0;
+  int best_bw = 0;
+  long best_tiles = 0;
+  for (int bw = 8; bw <= 64 && bw <= g->MX; ++bw) {
+    const int bh = BD_BM / bw;
+    if (bh < 2 || bh > g->MY) continue;
+    const long tiles = (long)((g->MX + bw - 1) / bw) * ((g->MY + bh - 1) / bh);
+    const long npix = (long)(bw + mix) * (bh + miy);
+    const long a = (npix * 128 + 1023) & ~1023L;
+    const long c = (long)BD_BM * (BD_BN + 8) * 2;
+    const long tot = (a > c ? a : c) + 2L * BD_BM * 4 + 4L * BD_BN * 4 + ((npix + 15) & ~15L);
+    if (tot > 80 * 1024 || npix >= 65536 / (bw + mix)) continue;       // two workgroups per CU; multiply-shift division
+    const double cost = (double)tiles * (1.0 + 0.5 * (double)npix * 128.0 / 32768.0);
+    if (best < 0 || cost < best) { best = cost; best_bw = bw; best_tiles = tiles; }
+  }
+  if (best < 0) return 0;
+  const int bw = best_bw, bh = BD_BM / bw;
+  if ((double)g->MY * g->MX < 0.88 * (double)BD_BM * (double)best_tiles) return 0;      // > 12 % idle rows
+  const int npix = (bw + mix) * (bh + miy);
+  // worth it where the row-major patch costs the second workgroup of a CU or is much larger
+  if (g_bd_blk != 2 && !(bd_lds_total(g, 4) > 80 * 1024 || npix * 10 < g->NP256 * 7)) return 0;
+  B->bw = bw; B->bh = bh;
+  B->nbx = (g->MX + bw - 1) / bw; B->nby = (g->MY + bh - 1) / bh;
+  B->PW = bw + mix; B->npix = npix; B->mul = (65536 + B->PW - 1) / B->PW;
+  return 1;
+}
+
 int iic_conv_igemm_red_supported(const iic_conv_geom* g) {
   if (!g || !iic_conv_igemm_frag_supported(g)) return 0;
   if (g_p64_enabled && iic_p64_supported(g)) return g_p64_red;
@@ -642,21 +728,28 @@ int iic_conv_igemm_frag_red(const iic_conv_geom* g, const void* in, const void* 
                        (bf16_t*)out, stats, (const bf16_t*)res_grad, (const bf16_t*)res_act,           \
                        accumulate, mt1, la1, g_bd_dense_key, (const bf16_t*)red_y, red_coef,           \
                        (const bf16_t*)red_y2, red_stats, red_stats2, (unsigned long long*)nullptr, 0,  \
-                       0, 0);                                                                          \
+                       0, 0, bd_blk{0, 0, 0, 0, 0, 0, 0});                                             \
   } while (0)
     if (red == 0) BD_LAUNCH_W1(0); else if (red == 1) BD_LAUNCH_W1(1); else BD_LAUNCH_W1(2);
     return iic_launch_status();
   }
-  const int ms = bd_pick_ms(g);
+  bd_blk BB = {0, 0, 0, 0, 0, 0, 0};
+  const bool blocked = iic_debug_get_ablate() == 0 && bd_block_config(g, &BB) != 0;
+  const int ms = blocked ? 4 : bd_pick_ms(g);
   const int bm = ms * 64;
-  const int mt = (int)((M + bm - 1) / bm);
+  const int mt = blocked ? g->N * BB.nbx * BB.nby : (int)((M + bm - 1) / bm);
   const int nt = g->Cout / BD_BN;
   int grid = mt * nt;
-  const int la = (int)bd_lds_a(g, ms);
-  const long lds = bd_lds_total(g, ms);
+  int la = (int)bd_lds_a(g, ms);
+  long lds = bd_lds_total(g, ms);
+  if (blocked) {
+    const long a = ((long)BB.npix * 128 + 1023) & ~1023L, c = (long)BD_BM * (BD_BN + 8) * 2;
+    la = (int)(((a > c ? a : c) + 15) & ~15L);
+    lds = la + 2L * BD_BM * 4 + 4L * BD_BN * 4 + ((BB.npix + 15) & ~15L);
+  }
   // last partial round in smaller tiles (see conv_igemm_bd_kernel)
   int ms2 = 0, n_big = 0, m_split = 0;
-  if (g_bd_mixed && ms == 4 && g->ntaps > 1 && g_bd_dma && iic_debug_get_ablate() == 0) {
+  if (g_bd_mixed && !blocked && ms == 4 && g->ntaps > 1 && g_bd_dma && iic_debug_get_ablate() == 0) {
     const int slots = (lds <= 80 * 1024 ? 2 : 1) * 256;
     const int per_round = slots / nt;                       // m-tiles per round
     const int full = per_round > 0 ? mt / per_round : 0;    // whole rounds of 256-row tiles
@@ -698,7 +791,7 @@ int iic_conv_igemm_frag_red(const iic_conv_geom* g, const void* in, const void* 
                        (const bf16_t*)res_act, accumulate, mt, la, g_bd_dense_key,               \
                        (const bf16_t*)red_y, red_coef, (const bf16_t*)red_y2, red_stats,         \
                        red_stats2, g_bd_prof, g_bd_stagger * (g->ntaps > 1 ? g->ntaps : 0),      \
-                       n_big, m_split);                                                          \
+                       n_big, m_split, BB);                                                      \
   } while (0)
 #define BD_LAUNCH4(GA_, AB_, DM_, MS_, RD_)                                                       \
   do {                                                                                           \

@@ -568,6 +568,49 @@ def test_weight_gradient_k_loop_forms_are_bit_identical(cin, cout, H, dil, N, ns
   assert (got - ref).abs().max().item() <= 2e-3 * scale, (got - ref).abs().max().item() / scale
 
 
+@HOOKS
+@pytest.mark.parametrize("cin,cout,H,pad,dil,N", [(64, 128, 200, 1, 1, 1), (256, 512, 100, 1, 2, 2), (512, 512, 98, 1, 2, 1),
+                                                  (128, 256, 64, 1, 1, 3), (256, 512, 64, 1, 2, 2), (64, 128, 49, 1, 1, 5)])
+def test_block_tiled_conv_is_bit_identical_to_row_major_tiles(cin, cout, H, pad, dil, N):
+  """conv_igemm_bd.hip block tiling (a 256-row tile = a 2-D block of output pixels, the patch = the sub-image under it;
+  iic_debug_bd_blk 2 = wherever it applies, 0 = off): which tile computes an output row changes, the row's accumulation
+  order does not -- forward and backward-data outputs must carry the same bits (the BatchNorm statistics agree to fp32
+  rounding: their per-tile partials group other rows); the forward also against F.conv2d.  SegmentationNet10a shapes (PT border 3, dilated convs with padding 1) + a ragged 49 x 49."""
+  from iic_amd import geom, ops
+  K, P = 3, 3
+  x, w = _conv_inputs(cin, cout, K, N, H, 41)
+  y_ref = F.conv2d(x, bf16_round(w), stride=1, padding=pad, dilation=dil)
+  dy = bf16_round(torch.from_numpy(np.random.default_rng(12).standard_normal(tuple(y_ref.shape)).astype(np.float32)))
+  spec = geom.ConvSpec(cin, cout, K, 1, pad, dil)
+  gf = geom.fwd_geom(spec, N, H, H, P, P)
+  gb = geom.bwd_data_geoms(spec, N, H, H, P, P)
+  Ho = spec.out_size(H)
+  xp, dyp = ops.pt_from_nchw(x.to(dev()), P), ops.pt_from_nchw(dy.to(dev()), P)
+  pw = ops.PreppedWeights(w.to(dev()))
+  hook("iic_debug_enable_pw", 0)          # every launch on conv_igemm_bd_kernel
+  res = {}
+  try:
+    for mode in (0, 2):
+      hook("iic_debug_bd_blk", mode)
+      yo = torch.zeros(N, Ho + 2 * P, Ho + 2 * P, cout, dtype=torch.bfloat16, device=dev())
+      dx = torch.zeros(N, H + 2 * P, H + 2 * P, cin, dtype=torch.bfloat16, device=dev())
+      st = ops.new_stats(cout, dev())
+      ops.conv_igemm(gf, xp, pw[0], yo, stats=st)
+      for g in gb:
+        ops.conv_igemm(g, dyp, pw[1], dx)
+      torch.cuda.synchronize()
+      res[mode] = (yo.clone(), ops.stats_decode(st, cout).clone(), dx.clone())
+  finally:
+    hook("iic_debug_bd_blk", 1)
+    hook("iic_debug_enable_pw", 1)
+  assert torch.equal(res[0][0], res[2][0]) and torch.equal(res[0][2], res[2][2])
+  # (the statistics are sums of per-tile fp32 partials: the grouping of rows into tiles differs, the last bits may)
+  assert torch.allclose(res[0][1], res[2][1], rtol=2e-5, atol=1e-2)
+  got = ops.pt_to_nchw(res[2][0], P).float().cpu()
+  assert (got - y_ref).abs().max().item() <= 2e-2 * y_ref.abs().max().item()
+  assert float(res[2][0][:, :P].abs().max()) == 0.0 and float(res[2][0][:, :, -P:].abs().max()) == 0.0   # borders untouched
+
+
 @pytest.mark.parametrize("cin,cout,H,pad,dil,N", [
     (128, 256, 100, 1, 1, 3),     # Potsdam c3: padded numbering, 128-pixel tiles that fit 160 KB only with the 4-tile table ring
     (64, 128, 128, 1, 1, 2),      # COCO-Stuff c2: 64-pixel tiles, two buffers
