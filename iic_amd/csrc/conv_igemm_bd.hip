@@ -89,7 +89,7 @@ __device__ __forceinline__ void bd_tile(
     unsigned long long* __restrict__ prof, int stagger, int blk_in_class, int nwg_class, int m_base,
     const bd_blk& B) {
   constexpr int BNT = WN * 64, NWM = 4 / WN;   // tile couts, wave row groups
-  constexpr bool CANBLK = !GATHER && DMA && MS == 4 && WN == 2;
+  constexpr bool CANBLK = !GATHER && DMA && MS * 32 * (4 / WN) == 256;      // 256-row tiles of either width
   const bool blk = CANBLK && B.bw > 0;         // uniform
   constexpr int CLD = BNT + 8;
   constexpr bool PROF = (ABL & 128) != 0;
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(BD_THREADS, ((MS == 4 || MS2 != 0 || WN == 1) ? 2 :
   if (WN == 1) {
     bd_tile<GATHER, ABL, DMA, MS, RED, 1>(g, in, wfrag, out, stats, res_grad, res_act, accumulate, lds_a_bytes,
                                           dense_key, red_y, red_coef, red_y2, red_stats, red_stats2, prof, stagger,
-                                          (int)blockIdx.x, num_mtiles * (g.Cout / 64), 0, B0);
+                                          (int)blockIdx.x, num_mtiles * (g.Cout / 64), 0, B);
   } else if (MS2 == 0 || (int)blockIdx.x < n_big) {
     bd_tile<GATHER, ABL, DMA, MS, RED>(g, in, wfrag, out, stats, res_grad, res_act, accumulate, lds_a_bytes,
                                        dense_key, red_y, red_coef, red_y2, red_stats, red_stats2, prof, stagger,
@@ -631,9 +631,9 @@ int iic_conv_igemm_frag_red(const iic_conv_geom* g, const void* in, const void* 
 // row-major 256-row patch is too big for two workgroups per CU, where the sub-image patch is not.  Block shape: fewest
 // tiles x (MFMA time + half the patch bytes), over shapes whose patch keeps two workgroups per CU.
 IIC_SWITCH(g_bd_blk, 1, iic_debug_bd_blk)       // 0: row-major tiles only; 2: block tiles wherever they apply (A/B)
-static int bd_block_config(const iic_conv_geom* g, bd_blk* B) {
+static int bd_block_config(const iic_conv_geom* g, bd_blk* B, int wn = 2) {      // wn: the kernel's WN (tile couts / 64)
   B->bw = 0;
-  if (!g_bd_blk || !g_bd_dma || g->ntaps < 2 || g->Cout % BD_BN != 0 || g->Cin % 64 != 0) return 0;
+  if (!g_bd_blk || !g_bd_dma || g->ntaps < 2 || g->Cout % (wn * 64) != 0 || g->Cin % 64 != 0) return 0;
   if (g->sy != 1 || g->sx != 1 || g->ty != 1 || g->tx != 1 || g->MY < 32 || g->MX < 32 || g->NP256 <= 0) return 0;
   int mix = 0, miy = 0;
   for (int t = 0; t < g->ntaps; ++t) {
@@ -652,7 +652,7 @@ static int bd_block_config(const iic_conv_geom* g, bd_blk* B) {
     const long tiles = (long)((g->MX + bw - 1) / bw) * ((g->MY + bh - 1) / bh);
     const long npix = (long)(bw + mix) * (bh + miy);
     const long a = (npix * 128 + 1023) & ~1023L;
-    const long c = (long)BD_BM * (BD_BN + 8) * 2;
+    const long c = (long)BD_BM * (wn * 64 + 8) * 2;
     const long tot = (a > c ? a : c) + 2L * BD_BM * 4 + 4L * BD_BN * 4 + ((npix + 15) & ~15L);
     if (tot > 80 * 1024 || npix >= 65536 / (bw + mix)) continue;       // two workgroups per CU; multiply-shift division
     const double cost = (double)tiles * (1.0 + 0.5 * (double)npix * 128.0 / 32768.0);
@@ -663,7 +663,7 @@ static int bd_block_config(const iic_conv_geom* g, bd_blk* B) {
   if ((double)g->MY * g->MX < 0.88 * (double)BD_BM * (double)best_tiles) return 0;      // > 12 % idle rows
   const int npix = (bw + mix) * (bh + miy);
   // worth it where the row-major patch costs the second workgroup of a CU or is much larger
-  if (g_bd_blk != 2 && !(bd_lds_total(g, 4) > 80 * 1024 || npix * 10 < g->NP256 * 7)) return 0;
+  if (g_bd_blk != 2 && !(bd_lds_total(g, wn == 2 ? 4 : 2, wn) > 80 * 1024 || npix * 10 < g->NP256 * 7)) return 0;
   B->bw = bw; B->bh = bh;
   B->nbx = (g->MX + bw - 1) / bw; B->nby = (g->MY + bh - 1) / bh;
   B->PW = bw + mix; B->npix = npix; B->mul = (65536 + B->PW - 1) / B->PW;
@@ -709,10 +709,17 @@ int iic_conv_igemm_frag_red(const iic_conv_geom* g, const void* in, const void* 
   if (M <= 0) return IIC_ERR_ARG;
   if (M >= (1L << 31) || (long)g->N * g->in_Hp * g->in_Wp >= (1L << 31)) return IIC_ERR_UNSUPPORTED;
   if (g->Cout % BD_BN != 0) {       // 64-cout tiles
-    const int mt1 = (int)((M + 255) / 256);
+    bd_blk B1 = {0, 0, 0, 0, 0, 0, 0};
+    const bool blocked1 = bd_block_config(g, &B1, 1) != 0;
+    const int mt1 = blocked1 ? g->N * B1.nbx * B1.nby : (int)((M + 255) / 256);
     const int grid1 = mt1 * (g->Cout / 64);
-    const int la1 = (int)bd_lds_a(g, 2, 1);
-    const long lds1 = bd_lds_total(g, 2, 1);
+    int la1 = (int)bd_lds_a(g, 2, 1);
+    long lds1 = bd_lds_total(g, 2, 1);
+    if (blocked1) {
+      const long a = ((long)B1.npix * 128 + 1023) & ~1023L, c = (long)BD_BM * (64 + 8) * 2;
+      la1 = (int)(((a > c ? a : c) + 15) & ~15L);
+      lds1 = la1 + 2L * BD_BM * 4 + 4L * BD_BN * 4 + ((B1.npix + 15) & ~15L);
+    }
     hipStream_t s1 = (hipStream_t)stream;
 #define BD_LAUNCH_W1(RD_)                                                                              \
   do {                                                                                                 \
@@ -728,7 +735,7 @@ int iic_conv_igemm_frag_red(const iic_conv_geom* g, const void* in, const void* 
                        (bf16_t*)out, stats, (const bf16_t*)res_grad, (const bf16_t*)res_act,           \
                        accumulate, mt1, la1, g_bd_dense_key, (const bf16_t*)red_y, red_coef,           \
                        (const bf16_t*)red_y2, red_stats, red_stats2, (unsigned long long*)nullptr, 0,  \
-                       0, 0, bd_blk{0, 0, 0, 0, 0, 0, 0});                                             \
+                       0, 0, B1);                                                                      \
   } while (0)
     if (red == 0) BD_LAUNCH_W1(0); else if (red == 1) BD_LAUNCH_W1(1); else BD_LAUNCH_W1(2);
     return iic_launch_status();
