@@ -569,46 +569,63 @@ def test_weight_gradient_k_loop_forms_are_bit_identical(cin, cout, H, dil, N, ns
 
 
 @HOOKS
-@pytest.mark.parametrize("cin,cout,H,pad,dil,N", [(64, 128, 200, 1, 1, 1), (256, 512, 100, 1, 2, 2), (512, 512, 98, 1, 2, 1),
-                                                  (128, 256, 64, 1, 1, 3), (256, 512, 64, 1, 2, 2), (64, 128, 49, 1, 1, 5)])
-def test_block_tiled_conv_is_bit_identical_to_row_major_tiles(cin, cout, H, pad, dil, N):
+@pytest.mark.parametrize("cin,cout,H,W,pad,dil,N", [(64, 128, 200, 200, 1, 1, 1), (256, 512, 100, 100, 1, 2, 2), (512, 512, 98, 98, 1, 2, 1),
+                                                    (128, 256, 64, 64, 1, 1, 3), (256, 512, 64, 64, 1, 2, 2), (64, 128, 49, 49, 1, 1, 5),
+                                                    (128, 128, 40, 75, 1, 1, 2), (64, 128, 67, 33, 1, 2, 3)])
+def test_block_tiled_conv_is_bit_identical_to_row_major_tiles(cin, cout, H, W, pad, dil, N):
   """conv_igemm_bd.hip block tiling (a 256-row tile = a 2-D block of output pixels, the patch = the sub-image under it;
   iic_debug_bd_blk 2 = wherever it applies, 0 = off): which tile computes an output row changes, the row's accumulation
-  order does not -- forward and backward-data outputs must carry the same bits (the BatchNorm statistics agree to fp32
-  rounding: their per-tile partials group other rows); the forward also against F.conv2d.  SegmentationNet10a shapes (PT border 3, dilated convs with padding 1) + a ragged 49 x 49."""
+  order does not -- forward and backward-data outputs must carry the same bits, with and without the epilogue's residual
+  add / ReLU mask / fused BatchNorm-backward reduction (the BatchNorm statistics and the fused sums agree to fp32
+  rounding: their per-tile partials group other rows); the forward also against F.conv2d.  SegmentationNet10a shapes (PT
+  border 3, dilated convs with padding 1, both kernel widths: the backward-data of 64 -> 128 has 64-cout tiles), a ragged
+  49 x 49 and two non-square images."""
   from iic_amd import geom, ops
   K, P = 3, 3
-  x, w = _conv_inputs(cin, cout, K, N, H, 41)
+  rng = np.random.default_rng(41)
+  x = bf16_round(torch.from_numpy(rng.standard_normal((N, cin, H, W)).astype(np.float32)))
+  w = torch.from_numpy((rng.standard_normal((cout, cin, K, K)) / math.sqrt(cin * K * K)).astype(np.float32))
   y_ref = F.conv2d(x, bf16_round(w), stride=1, padding=pad, dilation=dil)
-  dy = bf16_round(torch.from_numpy(np.random.default_rng(12).standard_normal(tuple(y_ref.shape)).astype(np.float32)))
+  dy = bf16_round(torch.from_numpy(rng.standard_normal(tuple(y_ref.shape)).astype(np.float32)))
   spec = geom.ConvSpec(cin, cout, K, 1, pad, dil)
-  gf = geom.fwd_geom(spec, N, H, H, P, P)
-  gb = geom.bwd_data_geoms(spec, N, H, H, P, P)
-  Ho = spec.out_size(H)
+  gf = geom.fwd_geom(spec, N, H, W, P, P)
+  gb = geom.bwd_data_geoms(spec, N, H, W, P, P)
+  Ho, Wo = y_ref.shape[2], y_ref.shape[3]
   xp, dyp = ops.pt_from_nchw(x.to(dev()), P), ops.pt_from_nchw(dy.to(dev()), P)
+  res = ops.pt_from_nchw(bf16_round(torch.from_numpy(rng.standard_normal((N, cin, H, W)).astype(np.float32))).to(dev()), P)
+  act = ops.pt_from_nchw(bf16_round(torch.from_numpy(rng.standard_normal((N, cin, H, W)).astype(np.float32))).to(dev()), P)
+  coef = torch.stack([torch.rand(cin) + 0.5, torch.randn(cin) * 0.3, torch.zeros(cin), torch.ones(cin), torch.zeros(cin)]).to(dev())
   pw = ops.PreppedWeights(w.to(dev()))
   hook("iic_debug_enable_pw", 0)          # every launch on conv_igemm_bd_kernel
-  res = {}
+  out = {}
   try:
     for mode in (0, 2):
       hook("iic_debug_bd_blk", mode)
-      yo = torch.zeros(N, Ho + 2 * P, Ho + 2 * P, cout, dtype=torch.bfloat16, device=dev())
-      dx = torch.zeros(N, H + 2 * P, H + 2 * P, cin, dtype=torch.bfloat16, device=dev())
-      st = ops.new_stats(cout, dev())
+      for g in gb:
+        g._red_ok = None
+      yo = torch.zeros(N, Ho + 2 * P, Wo + 2 * P, cout, dtype=torch.bfloat16, device=dev())
+      dx = torch.zeros(N, H + 2 * P, W + 2 * P, cin, dtype=torch.bfloat16, device=dev())
+      dx2 = torch.zeros_like(dx)
+      st, s1 = ops.new_stats(cout, dev()), ops.new_stats(cin, dev())
       ops.conv_igemm(gf, xp, pw[0], yo, stats=st)
       for g in gb:
         ops.conv_igemm(g, dyp, pw[1], dx)
+      assert len(gb) == 1 and ops.red_supported(gb[0], pw[1])
+      ops.conv_igemm(gb[0], dyp, pw[1], dx2, res_grad=res, res_act=act, premask=True, red=(xp, coef, s1, None, None))
       torch.cuda.synchronize()
-      res[mode] = (yo.clone(), ops.stats_decode(st, cout).clone(), dx.clone())
+      out[mode] = (yo.clone(), dx.clone(), dx2.clone(), ops.stats_decode(st, cout).clone(), ops.stats_decode(s1, cin).clone())
   finally:
     hook("iic_debug_bd_blk", 1)
     hook("iic_debug_enable_pw", 1)
-  assert torch.equal(res[0][0], res[2][0]) and torch.equal(res[0][2], res[2][2])
-  # (the statistics are sums of per-tile fp32 partials: the grouping of rows into tiles differs, the last bits may)
-  assert torch.allclose(res[0][1], res[2][1], rtol=2e-5, atol=1e-2)
-  got = ops.pt_to_nchw(res[2][0], P).float().cpu()
+  for i in range(3):
+    assert torch.equal(out[0][i], out[2][i]), i
+  for i in (3, 4):      # sums of per-tile fp32 partials: the grouping of rows into tiles differs, the last bits may
+    scale = float(out[0][i].abs().max())
+    assert float((out[0][i] - out[2][i]).abs().max()) <= 2e-5 * scale + 1e-6, i
+  got = ops.pt_to_nchw(out[2][0], P).float().cpu()
   assert (got - y_ref).abs().max().item() <= 2e-2 * y_ref.abs().max().item()
-  assert float(res[2][0][:, :P].abs().max()) == 0.0 and float(res[2][0][:, :, -P:].abs().max()) == 0.0   # borders untouched
+  assert float(out[2][0][:, :P].abs().max()) == 0.0 and float(out[2][0][:, :, -P:].abs().max()) == 0.0   # borders untouched
+  assert float(out[2][1][:, :P].abs().max()) == 0.0 and float(out[2][1][:, :, -P:].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("cin,cout,H,pad,dil,N", [
