@@ -612,13 +612,16 @@ static int bd_pick_ms(const iic_conv_geom* g) {
   return ok4 ? 4 : (ok2 ? 2 : 0);
 }
 
+static int bd_block_config(const iic_conv_geom* g, bd_blk* B, int wn);
 /* 1 if iic_conv_igemm_frag can run this geometry (else use iic_conv_igemm). */
 int iic_conv_igemm_frag_supported(const iic_conv_geom* g) {
   if (!g) return 0;
   if (g_p64_enabled && iic_p64_supported(g)) return 1;
   if (g->Cin % 64 != 0 || g->ntaps < 1 || g->ntaps > IIC_MAX_TAPS) return 0;
-  if (g->Cout % BD_BN != 0) return bd_w1_ok(g) ? 1 : 0;
-  return bd_pick_ms(g) != 0;
+  // (images too wide for any row-major patch -- > ~290 pixels at dilation 2 -- still run here on block tiles)
+  bd_blk B;
+  if (g->Cout % BD_BN != 0) return (bd_w1_ok(g) || (g->Cout % 64 == 0 && bd_block_config(g, &B, 1))) ? 1 : 0;
+  return bd_pick_ms(g) != 0 || bd_block_config(g, &B, 2) != 0;
 }
 
 int iic_conv_igemm_frag_red(const iic_conv_geom* g, const void* in, const void* wfrag, void* out,
@@ -631,7 +634,7 @@ int iic_conv_igemm_frag_red(const iic_conv_geom* g, const void* in, const void* 
 // row-major 256-row patch is too big for two workgroups per CU, where the sub-image patch is not.  Block shape: fewest
 // tiles x (MFMA time + half the patch bytes), over shapes whose patch keeps two workgroups per CU.
 IIC_SWITCH(g_bd_blk, 1, iic_debug_bd_blk)       // 0: row-major tiles only; 2: block tiles wherever they apply (A/B)
-static int bd_block_config(const iic_conv_geom* g, bd_blk* B, int wn = 2) {      // wn: the kernel's WN (tile couts / 64)
+static int bd_block_config(const iic_conv_geom* g, bd_blk* B, int wn) {      // wn: the kernel's WN (tile couts / 64)
   B->bw = 0;
   if (!g_bd_blk || !g_bd_dma || g->ntaps < 2 || g->Cout % (wn * 64) != 0 || g->Cin % 64 != 0) return 0;
   if (g->sy != 1 || g->sx != 1 || g->ty != 1 || g->tx != 1 || g->MY < 32 || g->MX < 32 || g->NP256 <= 0) return 0;
@@ -741,8 +744,9 @@ int iic_conv_igemm_frag_red(const iic_conv_geom* g, const void* in, const void* 
     return iic_launch_status();
   }
   bd_blk BB = {0, 0, 0, 0, 0, 0, 0};
-  const bool blocked = iic_debug_get_ablate() == 0 && bd_block_config(g, &BB) != 0;
+  const bool blocked = iic_debug_get_ablate() == 0 && bd_block_config(g, &BB, 2) != 0;
   const int ms = blocked ? 4 : bd_pick_ms(g);
+  if (ms == 0) return IIC_ERR_UNSUPPORTED;      // (only block tiles fit and an ablation build / switch turned them off)
   const int bm = ms * 64;
   const int mt = blocked ? g->N * BB.nbx * BB.nby : (int)((M + bm - 1) / bm);
   const int nt = g->Cout / BD_BN;

@@ -628,6 +628,44 @@ def test_block_tiled_conv_is_bit_identical_to_row_major_tiles(cin, cout, H, W, p
   assert float(out[2][1][:, :P].abs().max()) == 0.0 and float(out[2][1][:, :, -P:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("cin,cout,H,W,dil", [(64, 128, 320, 320, 2), (64, 128, 40, 640, 1)])
+def test_wide_images_run_on_block_tiles(cin, cout, H, W, dil):
+  """Images too wide for any row-major LDS patch of the weights-direct kernel (> ~290 pixels at dilation 2, > ~580 at
+  dilation 1: the span of 128 output rows + the tap halo exceeds 160 KB) used to fall back to the first-generation
+  kernel; with block tiles (conv_igemm_bd.hip bd_block_config) the patch is the sub-image under a 2-D block and they stay on
+  the weights-direct kernel, both widths (backward-data of 64 -> 128 has 64-cout tiles).  Forward and backward-data
+  against F.conv2d and its autograd."""
+  from iic_amd import geom, ops
+  P = 3
+  rng = np.random.default_rng(7)
+  x = bf16_round(torch.from_numpy(rng.standard_normal((1, cin, H, W)).astype(np.float32))).requires_grad_(True)
+  w = torch.from_numpy((rng.standard_normal((cout, cin, 3, 3)) / math.sqrt(cin * 9)).astype(np.float32))
+  y_ref = F.conv2d(x, bf16_round(w), stride=1, padding=1, dilation=dil)
+  dy = bf16_round(torch.from_numpy(rng.standard_normal(tuple(y_ref.shape)).astype(np.float32)))
+  y_ref.backward(dy)
+  spec = geom.ConvSpec(cin, cout, 3, 1, 1, dil)
+  gf = geom.fwd_geom(spec, 1, H, W, P, P)
+  (gb,) = geom.bwd_data_geoms(spec, 1, H, W, P, P)
+  assert ops.frag_supported(gf) and ops.frag_supported(gb)
+  Ho, Wo = y_ref.shape[2], y_ref.shape[3]
+  xp, dyp = ops.pt_from_nchw(x.detach().to(dev()), P), ops.pt_from_nchw(dy.to(dev()), P)
+  pw = ops.PreppedWeights(w.to(dev()))
+  yo = torch.zeros(1, Ho + 2 * P, Wo + 2 * P, cout, dtype=torch.bfloat16, device=dev())
+  dx = torch.zeros(1, H + 2 * P, W + 2 * P, cin, dtype=torch.bfloat16, device=dev())
+  st = ops.new_stats(cout, dev())
+  ops.conv_igemm(gf, xp, pw[0], yo, stats=st)
+  ops.conv_igemm(gb, dyp, pw[1], dx)
+  torch.cuda.synchronize()
+  got = ops.pt_to_nchw(yo, P).cpu()
+  assert (got - y_ref.detach()).abs().max().item() <= 2e-2 * y_ref.abs().max().item()
+  gdx = ops.pt_to_nchw(dx, P).cpu()
+  assert (gdx - x.grad).abs().max().item() <= 2e-2 * x.grad.abs().max().item()
+  sums = ops.stats_decode(st, cout).cpu()
+  ref_s = torch.stack([got.double().sum((0, 2, 3)), (got.double() ** 2).sum((0, 2, 3))])
+  assert float((sums - ref_s).abs().max()) <= 2e-3 * float(ref_s.abs().max())     # (statistics from the fp32 accumulators, got is bf16)
+  assert float(yo[:, :P].abs().max()) == 0.0 and float(dx[:, :, -P:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("cin,cout,H,pad,dil,N", [
     (128, 256, 100, 1, 1, 3),     # Potsdam c3: padded numbering, 128-pixel tiles that fit 160 KB only with the 4-tile table ring
     (64, 128, 128, 1, 1, 2),      # COCO-Stuff c2: 64-pixel tiles, two buffers
