@@ -634,6 +634,7 @@ int iic_conv_igemm_frag_red(const iic_conv_geom* g, const void* in, const void* 
 // row-major 256-row patch is too big for two workgroups per CU, where the sub-image patch is not.  Block shape: fewest
 // tiles x (MFMA time + half the patch bytes), over shapes whose patch keeps two workgroups per CU.
 IIC_SWITCH(g_bd_blk, 1, iic_debug_bd_blk)       // 0: row-major tiles only; 2: block tiles wherever they apply (A/B)
+IIC_SWITCH(g_bd_blk_bw, 0, iic_debug_bd_blk_bw)  // > 0: force this block width where it is valid (shape sweeps)
 static int bd_block_config(const iic_conv_geom* g, bd_blk* B, int wn) {      // wn: the kernel's WN (tile couts / 64)
   B->bw = 0;
   if (!g_bd_blk || !g_bd_dma || g->ntaps < 2 || g->Cout % (wn * 64) != 0 || g->Cin % 64 != 0) return 0;
@@ -652,6 +653,7 @@ static int bd_block_config(const iic_conv_geom* g, bd_blk* B, int wn) {      // 
   for (int bw = 8; bw <= 64 && bw <= g->MX; ++bw) {
     const int bh = BD_BM / bw;
     if (bh < 2 || bh > g->MY) continue;
+    if (g_bd_blk_bw > 0 && bw != g_bd_blk_bw) continue;
     const long tiles = (long)((g->MX + bw - 1) / bw) * ((g->MY + bh - 1) / bh);
     const long npix = (long)(bw + mix) * (bh + miy);
     const long a = (npix * 128 + 1023) & ~1023L;
@@ -663,7 +665,7 @@ static int bd_block_config(const iic_conv_geom* g, bd_blk* B, int wn) {      // 
   }
   if (best < 0) return 0;
   const int bw = best_bw, bh = BD_BM / bw;
-  if ((double)g->MY * g->MX < 0.88 * (double)BD_BM * (double)best_tiles) return 0;      // > 12 % idle rows
+  if (g_bd_blk_bw == 0 && (double)g->MY * g->MX < 0.88 * (double)BD_BM * (double)best_tiles) return 0;      // > 12 % idle rows
   const int npix = (bw + mix) * (bh + miy);
   // worth it where the row-major patch costs the second workgroup of a CU or is much larger
   if (g_bd_blk != 2 && !(bd_lds_total(g, wn == 2 ? 4 : 2, wn) > 80 * 1024 || npix * 10 < g->NP256 * 7)) return 0;
